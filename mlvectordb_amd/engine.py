@@ -1,0 +1,165 @@
+"""Scan engines: what an ``Index`` namespace delegates its arithmetic to.
+
+``HipScanEngine`` is the product backend -- a ctypes handle onto one ``mlvdb_index`` in
+HBM (include/mlvdb_hip.h).  It takes the role hnswlib.Index plays in the reference
+(src/mlvectordb/implementations/index.py:36-38,65,80,111).  There is deliberately no
+CPU engine in this package: tests inject the oracle's engine through ``Index(engine_factory=...)``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Protocol, Tuple
+
+import numpy as np
+
+from . import _native
+
+
+class ScanEngine(Protocol):
+    """One namespace's corpus: dense labels 0..total-1 in insertion order."""
+
+    dim: int
+    space: str
+
+    def append(self, rows: np.ndarray) -> int: ...
+
+    def tombstone(self, labels: np.ndarray) -> int: ...
+
+    def counts(self) -> Tuple[int, int]: ...
+
+    def search(self, queries: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]: ...
+
+    def range(self, queries: np.ndarray, radius: float, capacity: int) -> List[Tuple[np.ndarray, np.ndarray]]: ...
+
+    def close(self) -> None: ...
+
+
+class HipScanEngine:
+    """Exhaustive fp32 corpus scan on one MI355X, through the C ABI."""
+
+    def __init__(self, dim: int, space: str, device: int = 0, capacity_hint: int = 0,
+                 strategy: str = "auto") -> None:
+        if space not in _native.SPACE_CODES:
+            # hnswlib raises RuntimeError("Space name must be one of l2, ip, or cosine.")
+            raise RuntimeError(f"space must be one of l2, ip, cosine (got {space!r})")
+        self._lib = _native.load()
+        self.dim = int(dim)
+        self.space = space
+        self.device = int(device)
+        handle = C.c_void_p()
+        rc = self._lib.mlvdb_index_create(self.device, self.dim, _native.SPACE_CODES[space],
+                                          int(capacity_hint), C.byref(handle))
+        if rc != _native.OK:
+            msg = self._lib.mlvdb_last_global_error().decode(errors="replace")
+            raise RuntimeError(f"mlvdb_index_create failed ({rc}): {msg}")
+        self._h = handle
+        if strategy != "auto":
+            self.set_strategy(strategy)
+
+    # -- helpers -------------------------------------------------------------------
+    def _check(self, rc: int, what: str, allow=()) -> int:
+        if rc != _native.OK and rc not in allow:
+            msg = self._lib.mlvdb_last_error(self._h).decode(errors="replace")
+            raise RuntimeError(f"{what} failed ({rc}): {msg}")
+        return rc
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._h
+
+    def set_strategy(self, strategy: str) -> None:
+        self._check(self._lib.mlvdb_index_set_strategy(self._h, _native.STRATEGY_CODES[strategy]), "set_strategy")
+
+    def set_profiling(self, enabled: bool) -> None:
+        self._check(self._lib.mlvdb_index_set_profiling(self._h, int(bool(enabled))), "set_profiling")
+
+    def last_stats(self) -> dict:
+        st = _native.Stats()
+        self._check(self._lib.mlvdb_index_last_stats(self._h, C.byref(st)), "last_stats")
+        return {name: getattr(st, name) for name, _ in _native.Stats._fields_}
+
+    # -- ScanEngine ----------------------------------------------------------------
+    def append(self, rows: np.ndarray) -> int:
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise RuntimeError(f"Wrong dimensionality of the vectors: got {rows.shape}, index dim {self.dim}")
+        first = C.c_int64(-1)
+        self._check(self._lib.mlvdb_index_append(self._h, rows.ctypes.data, rows.shape[0], C.byref(first)), "append")
+        return int(first.value)
+
+    def append_device(self, device_ptr: int, n: int) -> int:
+        first = C.c_int64(-1)
+        self._check(self._lib.mlvdb_index_append_device(self._h, C.c_void_p(device_ptr), int(n), C.byref(first)),
+                    "append_device")
+        return int(first.value)
+
+    def tombstone(self, labels: np.ndarray) -> int:
+        labels = np.ascontiguousarray(labels, dtype=np.int64)
+        changed = C.c_int64(0)
+        self._check(self._lib.mlvdb_index_tombstone(self._h, labels.ctypes.data, labels.size, C.byref(changed)),
+                    "tombstone")
+        return int(changed.value)
+
+    def counts(self) -> Tuple[int, int]:
+        total, deleted = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.mlvdb_index_counts(self._h, C.byref(total), C.byref(deleted)), "counts")
+        return int(total.value), int(deleted.value)
+
+    def reset(self, space: str | None = None) -> None:
+        code = -1 if space is None else _native.SPACE_CODES[space]
+        self._check(self._lib.mlvdb_index_reset(self._h, code), "reset")
+        if space is not None:
+            self.space = space
+
+    def get_rows(self, first: int, n: int) -> np.ndarray:
+        out = np.empty((n, self.dim), dtype=np.float32)
+        self._check(self._lib.mlvdb_index_get_rows(self._h, int(first), int(n), out.ctypes.data), "get_rows")
+        return out
+
+    def search(self, queries: np.ndarray, k: int):
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        if queries.ndim != 2 or queries.shape[1] != self.dim:
+            raise RuntimeError(f"Wrong dimensionality of the vectors: got {queries.shape}, index dim {self.dim}")
+        nq = queries.shape[0]
+        labels = np.empty((nq, k), dtype=np.int64)
+        dist = np.empty((nq, k), dtype=np.float32)
+        counts = np.empty(nq, dtype=np.int32)
+        self._check(self._lib.mlvdb_search_batch(self._h, queries.ctypes.data, nq, int(k), labels.ctypes.data,
+                                                 dist.ctypes.data, counts.ctypes.data), "search_batch")
+        return labels, dist, counts
+
+    def search_device(self, q_ptr: int, nq: int, k: int, labels_ptr: int, dist_ptr: int, counts_ptr: int,
+                      stream: int = 0) -> None:
+        """Device-pointer search; results are complete when ``stream`` is."""
+        self._check(self._lib.mlvdb_search_batch_device(
+            self._h, C.c_void_p(q_ptr), int(nq), int(k), C.c_void_p(labels_ptr), C.c_void_p(dist_ptr),
+            C.c_void_p(counts_ptr), C.c_void_p(stream)), "search_batch_device")
+
+    def range(self, queries: np.ndarray, radius: float, capacity: int):
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        if queries.ndim != 2 or queries.shape[1] != self.dim:
+            raise RuntimeError(f"Wrong dimensionality of the vectors: got {queries.shape}, index dim {self.dim}")
+        nq = queries.shape[0]
+        capacity = max(1, int(capacity))
+        while True:
+            labels = np.empty((nq, capacity), dtype=np.int64)
+            dist = np.empty((nq, capacity), dtype=np.float32)
+            counts = np.empty(nq, dtype=np.int64)
+            rc = self._check(self._lib.mlvdb_range_batch(self._h, queries.ctypes.data, nq, float(radius), capacity,
+                                                         labels.ctypes.data, dist.ctypes.data, counts.ctypes.data),
+                             "range_batch", allow=(_native.ERR_OVERFLOW,))
+            if rc == _native.OK:
+                break
+            capacity = int(counts.max())  # exact hit counts are reported even on overflow: retry once, sized
+        return [(labels[i, :counts[i]].copy(), dist[i, :counts[i]].copy()) for i in range(nq)]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.mlvdb_index_destroy(self._h)
+            self._h = None
+
+    def __del__(self) -> None:  # best effort; HBM is released with the handle
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,97 @@
+"""``QueryProcessor``: storage + index orchestration around the search hot path.
+
+Counterpart of the reference's ``QueryProcessor``
+(src/mlvectordb/implementations/query_processor.py:11-82).  ``find_similar`` is the
+dispatch the north star names: ``Index.search`` then enrichment of each hit with the stored
+values/metadata, in index order, silently dropping ids the storage no longer has
+(query_processor.py:33-49).  ``find_similar_many`` is the additive batched sibling: one
+corpus scan for the whole query batch.
+
+Deliberate divergence: the reference's ``delete`` rebuilds the index
+from *only* the affected namespace (query_processor.py:60), and ``Index.rebuild`` clears
+every namespace first (index.py:136-143), so other namespaces silently vanish from the
+index.  Here the rebuild source is the whole storage map; pass ``rebuild_scope="namespace"``
+to reproduce the reference byte for byte.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Iterable, List, Sequence
+from uuid import UUID
+
+from .interfaces import IndexProtocol, VectorDTO
+from .vector import Vector
+
+
+class QueryProcessor:
+    def __init__(self, storage_engine, index: IndexProtocol, *, rebuild_scope: str = "all") -> None:
+        if rebuild_scope not in ("all", "namespace"):
+            raise ValueError("rebuild_scope must be 'all' or 'namespace'")
+        self._storage = storage_engine
+        self._index = index
+        self._rebuild_scope = rebuild_scope
+
+    # ---- writes (query_processor.py:16-24): every call mints new ids, nothing is updated in place
+    def insert(self, vector: VectorDTO, namespace: str = "default") -> None:
+        row = Vector(values=vector.values, metadata=vector.metadata)
+        self._storage.write(row, namespace)
+        self._index.add([row], namespace)
+
+    def upsert_many(self, vectors: Iterable[VectorDTO], namespace: str = "default") -> None:
+        rows = [Vector(values=v.values, metadata=v.metadata) for v in vectors]
+        self._storage.write_vectors(rows, namespace)
+        self._index.add(rows, namespace)
+
+    # ---- the hot path
+    def _enrich(self, hits, namespace: str) -> List[dict]:
+        if not hits:
+            return []
+        stored = {v.id: v for v in self._storage.read_vectors([h.vector_id for h in hits], namespace) if v}
+        out = []
+        for h in hits:
+            v = stored.get(h.vector_id)
+            if v:
+                out.append({"id": v.id, "values": v.values, "metadata": v.metadata, "score": h.score})
+        return out
+
+    def find_similar(self, query: VectorDTO, top_k: int, namespace: str = "default",
+                     metric: str = "cosine") -> List[dict]:
+        hits = self._index.search(query, top_k=top_k, namespace=namespace, metric=metric)
+        return self._enrich(hits, namespace)
+
+    def find_similar_many(self, queries, top_k: int, namespace: str = "default",
+                          metric: str = "cosine") -> List[List[dict]]:
+        """Batched ``find_similar``: ``queries`` is an [nq, dim] array or a sequence of VectorDTO."""
+        per_query = self._index.search_many(queries, top_k=top_k, namespace=namespace, metric=metric)
+        return [self._enrich(hits, namespace) for hits in per_query]
+
+    def find_in_radius(self, query: VectorDTO, radius: float, namespace: str = "default",
+                       metric: str = "cosine", max_results: int = 1024) -> List[dict]:
+        """Range query (no reference counterpart; README.md:30-41 intent only)."""
+        hits = self._index.range_search(query, radius, namespace=namespace, metric=metric, max_results=max_results)
+        return self._enrich(hits, namespace)
+
+    # ---- delete -> lazy rebuild (query_processor.py:51-62)
+    def delete(self, ids: Sequence[UUID], namespace: str = "default") -> Sequence[UUID]:
+        removed = [vid for vid in ids if self._storage.delete(vid, namespace)]
+        self._index.remove(ids, namespace)
+        probe = getattr(self._index, "is_rebuild_required", None)
+        if probe and probe(namespace):
+            full = self._storage.namespace_map
+            if self._rebuild_scope == "namespace":
+                source = {namespace: full.get(namespace, [])}
+            else:
+                source = dict(full)
+                source.setdefault(namespace, [])
+            self._index.rebuild(source, metric=self._index._space)
+        return removed
+
+    # ---- introspection (query_processor.py:64-82)
+    def list_namespaces(self) -> List[str]:
+        return self._storage.list_namespaces
+
+    def get_namespace_vectors(self, namespace: str) -> List[Dict[str, Any]]:
+        return [{"id": v.id, "values": v.values, "metadata": v.metadata}
+                for v in self._storage.namespace_map.get(namespace, [])]
+
+    def get_namespace_count(self, namespace: str) -> int:
+        return len(self._storage.namespace_map.get(namespace, []))

@@ -1,0 +1,52 @@
+"""Oracle-backed ``ScanEngine`` (TEST INFRASTRUCTURE; see oracle/__init__.py).
+
+Implements the engine interface of ``mlvectordb_amd.engine.ScanEngine`` on top of the NumPy
+exact scan, so that the host logic of ``mlvectordb_amd.Index`` (UUID maps, clamping, score
+flip, tombstone accounting) can be exercised on a machine without a GPU, and so the HIP
+engine's answers can be compared call for call.  Injected by tests via
+``Index(engine_factory=OracleScanEngine)``; never imported by the product package.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import exact_scan
+
+
+class OracleScanEngine:
+    def __init__(self, dim: int, space: str) -> None:
+        if space not in exact_scan.SPACES:
+            raise RuntimeError(f"space must be one of l2, ip, cosine (got {space!r})")
+        self.dim = int(dim)
+        self.space = space
+        self._rows = np.zeros((0, self.dim), dtype=np.float32)
+        self._deleted = np.zeros(0, dtype=bool)
+
+    def append(self, rows: np.ndarray) -> int:
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise RuntimeError(f"Wrong dimensionality of the vectors: got {rows.shape}, index dim {self.dim}")
+        first = self._rows.shape[0]
+        self._rows = np.concatenate([self._rows, rows], axis=0)
+        self._deleted = np.concatenate([self._deleted, np.zeros(rows.shape[0], dtype=bool)])
+        return first
+
+    def tombstone(self, labels: np.ndarray) -> int:
+        labels = np.asarray(labels, dtype=np.int64)
+        labels = labels[(labels >= 0) & (labels < self._deleted.size)]
+        fresh = np.unique(labels[~self._deleted[labels]])
+        self._deleted[fresh] = True
+        return int(fresh.size)
+
+    def counts(self):
+        return int(self._rows.shape[0]), int(self._deleted.sum())
+
+    def search(self, queries: np.ndarray, k: int):
+        return exact_scan.knn(queries, self._rows, k, self.space, deleted=self._deleted)
+
+    def range(self, queries: np.ndarray, radius: float, capacity: int):
+        return exact_scan.range_query(queries, self._rows, radius, self.space, deleted=self._deleted)
+
+    def close(self) -> None:
+        self._rows = np.zeros((0, self.dim), dtype=np.float32)
+        self._deleted = np.zeros(0, dtype=bool)
