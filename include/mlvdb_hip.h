@@ -126,10 +126,12 @@ int mlvdb_search_batch(mlvdb_index* h, const float* queries, int64_t nq, int32_t
                        int64_t* out_labels, float* out_dist, int32_t* out_counts);
 /* Same with every buffer on the index's device; work is enqueued on `stream`
  * (a hipStream_t passed as void*, NULL = default stream) and is complete when the
- * stream is: the call itself only synchronises when a fallback decision needs it. */
+ * stream is: the call itself only synchronises when a fallback decision needs it.
+ * out_dist64_device (optional, may be NULL) receives the unrounded fp64 distances [nq, k]:
+ * a caller that merges per-shard results must rank on these, not on the fp32 roundings. */
 int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64_t nq, int32_t k,
                               int64_t* out_labels_device, float* out_dist_device,
-                              int32_t* out_counts_device, void* stream);
+                              int32_t* out_counts_device, double* out_dist64_device, void* stream);
 
 /*
  * Batched range query: every live row with distance <= radius (distance in the

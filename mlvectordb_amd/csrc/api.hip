@@ -1,0 +1,675 @@
+// C ABI of libmlvdb_hip.so (declared in include/mlvdb_hip.h): index handle, HBM management,
+// and the orchestration of the scan kernels.  Nothing here touches the CPU for arithmetic:
+// if no HIP device is usable every entry point fails with MLVDB_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "internal.h"
+
+using namespace mlvdb;
+
+namespace {
+
+thread_local std::string g_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t want = need + need / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            want = need;
+            e = hipMalloc(&p, want);
+        }
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T* as() const {
+        return static_cast<T*>(p);
+    }
+};
+
+}  // namespace
+
+struct mlvdb_index {
+    int device = 0;
+    int32_t dim = 0, ld = 0, space = 0;
+    int32_t strategy = MLVDB_STRATEGY_AUTO;
+    bool profiling = false;
+    float* X = nullptr;   // panels, capacity * ld floats
+    float* rn = nullptr;  // row norms, NaN = tombstoned / not a row
+    int64_t capacity = 0, total = 0, deleted = 0;
+    hipStream_t stream = nullptr;
+    // workspaces (grow only)
+    DevBuf stage, qpad, qaux, partial, qsel, seed_lab, seed_dist, seed_cnt, seed_d64;
+    DevBuf qimg, fmisc, cand, io_q, io_lab, io_dist, io_cnt, counters, labels_in;
+    uint32_t* host_flags = nullptr;  // pinned, kFilterQueries words
+    std::string err;
+    // statistics / profiling
+    mlvdb_stats stats{};
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> scan_events;
+    size_t scan_events_used = 0;
+    hipEvent_t total_events[2] = {nullptr, nullptr};
+    bool stats_pending = false;
+};
+
+namespace {
+
+int fail(mlvdb_index* h, int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    if (h)
+        h->err = buf;
+    else
+        g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, call)                                                                    \
+    do {                                                                                    \
+        hipError_t e__ = (call);                                                            \
+        if (e__ != hipSuccess)                                                              \
+            return fail(h, e__ == hipErrorOutOfMemory ? MLVDB_ERR_OUT_OF_MEMORY : MLVDB_ERR_HIP, #call, e__); \
+    } while (0)
+
+int reserve_rows(mlvdb_index* h, int64_t rows) {
+    if (rows <= h->capacity) return MLVDB_OK;
+    int64_t want = rows;
+    if (h->capacity > 0 && want < h->capacity + h->capacity / 2) want = h->capacity + h->capacity / 2;
+    const int64_t cap = round_up_rows(want);
+    float* nX = nullptr;
+    float* nrn = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&nX), (size_t)cap * h->ld * sizeof(float)));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&nrn), (size_t)cap * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipFree(nX);
+        return fail(h, MLVDB_ERR_OUT_OF_MEMORY, "hipMalloc(row norms)", e);
+    }
+    const size_t used_floats = (size_t)((h->total + 15) / 16) * 16 * h->ld;
+    HIP_TRY(h, hipMemsetAsync(nX + used_floats, 0, ((size_t)cap * h->ld - used_floats) * sizeof(float), h->stream));
+    HIP_TRY(h, hipMemsetAsync(nrn, 0xFF, (size_t)cap * sizeof(float), h->stream));  // 0xFFFFFFFF = NaN
+    if (h->total > 0) {
+        HIP_TRY(h, hipMemcpyAsync(nX, h->X, used_floats * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(nrn, h->rn, (size_t)h->total * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (h->X) (void)hipFree(h->X);
+    if (h->rn) (void)hipFree(h->rn);
+    h->X = nX;
+    h->rn = nrn;
+    h->capacity = cap;
+    return MLVDB_OK;
+}
+
+// ---- profiling helpers
+int begin_call(mlvdb_index* h, hipStream_t s) {
+    h->stats = mlvdb_stats{};
+    h->scan_events_used = 0;
+    h->stats_pending = false;
+    if (h->profiling) {
+        for (auto& ev : h->total_events)
+            if (!ev) HIP_TRY(h, hipEventCreate(&ev));
+        HIP_TRY(h, hipEventRecord(h->total_events[0], s));
+    }
+    return MLVDB_OK;
+}
+
+int end_call(mlvdb_index* h, hipStream_t s) {
+    if (h->profiling) {
+        HIP_TRY(h, hipEventRecord(h->total_events[1], s));
+        h->stats_pending = true;
+    }
+    return MLVDB_OK;
+}
+
+int scan_event(mlvdb_index* h, hipStream_t s, bool start) {
+    if (!h->profiling) return MLVDB_OK;
+    if (start) {
+        if (h->scan_events_used == h->scan_events.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIP_TRY(h, hipEventCreate(&a));
+            HIP_TRY(h, hipEventCreate(&b));
+            h->scan_events.emplace_back(a, b);
+        }
+        HIP_TRY(h, hipEventRecord(h->scan_events[h->scan_events_used].first, s));
+    } else {
+        HIP_TRY(h, hipEventRecord(h->scan_events[h->scan_events_used].second, s));
+        ++h->scan_events_used;
+    }
+    return MLVDB_OK;
+}
+
+// ---- exact scan of rows [row_begin,row_end) for a set of queries of the prepared batch.
+// Qpad/qaux point at query 0 of the set's index space; qsel (device) lists the members or is null.
+int run_exact(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qaux, int32_t nq_sel,
+              const int32_t* qsel, int64_t row_begin, int64_t row_end, int32_t k, int64_t* out_labels,
+              float* out_dist, int32_t* out_counts, double* out_d64, bool is_main_scan) {
+    if (nq_sel <= 0) return MLVDB_OK;
+    const ExactPlan plan = plan_exact(row_end - row_begin, h->ld, nq_sel, k);
+    HIP_TRY(h, h->partial.ensure((size_t)nq_sel * plan.nblk * k * sizeof(TopEntry)));
+    ExactArgs a{};
+    a.X = h->X;
+    a.rn = h->rn;
+    a.row_begin = row_begin;
+    a.row_end = row_end;
+    a.ld = h->ld;
+    a.space = h->space;
+    a.Qpad = Qpad;
+    a.qaux = qaux;
+    a.qsel = qsel;
+    a.nq_sel = nq_sel;
+    a.k = k;
+    a.cursor_d = nullptr;
+    a.cursor_l = nullptr;
+    a.partial = h->partial.as<TopEntry>();
+    if (is_main_scan) {
+        int rc = scan_event(h, s, true);
+        if (rc) return rc;
+    }
+    HIP_TRY(h, launch_exact_scan(a, plan, s));
+    if (is_main_scan) {
+        int rc = scan_event(h, s, false);
+        if (rc) return rc;
+        h->stats.scan_launches += 1;
+        h->stats.rows_scanned += (row_end - row_begin) * plan.nqtiles;
+    }
+    HIP_TRY(h, launch_exact_merge(a.partial, nq_sel, qsel, plan.nblk, k, out_labels, out_dist, out_counts, out_d64, s));
+    return MLVDB_OK;
+}
+
+__global__ void fill_empty_kernel(int64_t* labels, float* dist, int32_t* counts, double* d64, int64_t nq, int32_t k) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq * k) {
+        labels[i] = -1;
+        dist[i] = __builtin_inff();
+        if (d64) d64[i] = __builtin_inf();
+    }
+    if (i < nq) counts[i] = 0;
+}
+
+struct FilterWs {
+    FilterArgs fa;
+};
+
+int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const double* qaux, int32_t nq) {
+    HIP_TRY(h, h->qimg.ensure(filter_qimg_bytes(h->ld)));
+    HIP_TRY(h, h->fmisc.ensure(4 * kFilterQueries * sizeof(uint32_t)));
+    HIP_TRY(h, h->cand.ensure((size_t)kFilterQueries * kCandCap * sizeof(CandEntry)));
+    if (!h->host_flags)
+        HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->host_flags), kFilterQueries * sizeof(uint32_t), 0));
+    fa.X = h->X;
+    fa.rn = h->rn;
+    fa.total = h->total;
+    fa.ld = h->ld;
+    fa.space = h->space;
+    fa.Qpad = Qpad;
+    fa.qaux = qaux;
+    fa.nq = nq;
+    fa.qimg = h->qimg.p;
+    fa.qscale = h->fmisc.as<float>();
+    fa.thr = h->fmisc.as<float>() + kFilterQueries;
+    fa.cnt = h->fmisc.as<uint32_t>() + 2 * kFilterQueries;
+    fa.overflow = h->fmisc.as<uint32_t>() + 3 * kFilterQueries;
+    fa.cand = h->cand.as<CandEntry>();
+    return MLVDB_OK;
+}
+
+// Collect the overflowed queries of a pass on the host; returns their count (device list in h->qsel).
+int collect_overflow(mlvdb_index* h, hipStream_t s, const FilterArgs& fa, int32_t* n_flagged) {
+    HIP_TRY(h, hipMemcpyAsync(h->host_flags, fa.overflow, kFilterQueries * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    int32_t sel[kFilterQueries];
+    int32_t n = 0;
+    for (int q = 0; q < fa.nq; ++q)
+        if (h->host_flags[q]) sel[n++] = q;
+    *n_flagged = n;
+    if (n) {
+        HIP_TRY(h, h->qsel.ensure(kFilterQueries * sizeof(int32_t)));
+        HIP_TRY(h, hipMemcpyAsync(h->qsel.p, sel, n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(h, hipStreamSynchronize(s));  // `sel` is on this stack frame
+    }
+    return MLVDB_OK;
+}
+
+// One pass of <= 256 queries through the filter path; outputs at query index q0.. of the batch.
+int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qaux, int32_t q0, int32_t nq,
+                    int32_t k, int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_d64) {
+    FilterArgs fa{};
+    int rc = setup_filter_ws(h, fa, Qpad + (size_t)q0 * h->ld, qaux + q0, nq);
+    if (rc) return rc;
+    HIP_TRY(h, launch_filter_prep(fa, s));
+    // seed thresholds with the exact k-th best of a prefix (those rows are scanned again below)
+    const int64_t n_seed = std::min<int64_t>(h->total, 1024);
+    HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * k * sizeof(int64_t)));
+    HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * k * sizeof(float)));
+    HIP_TRY(h, h->seed_cnt.ensure(kFilterQueries * sizeof(int32_t)));
+    HIP_TRY(h, h->seed_d64.ensure((size_t)kFilterQueries * k * sizeof(double)));
+    rc = run_exact(h, s, fa.Qpad, fa.qaux, nq, nullptr, 0, n_seed, k, h->seed_lab.as<int64_t>(),
+                   h->seed_dist.as<float>(), h->seed_cnt.as<int32_t>(), h->seed_d64.as<double>(), false);
+    if (rc) return rc;
+    HIP_TRY(h, launch_filter_seed_thr(fa, h->seed_d64.as<double>(), k, s));
+    // scan in rounds of growing size; thresholds tighten between rounds
+    const int64_t bounds[] = {0, (int64_t)kFilterTile * 341, (int64_t)kFilterTile * 10923, h->total};
+    for (int r = 0; r < 3; ++r) {
+        const int64_t b = std::min(bounds[r], h->total), e = std::min(bounds[r + 1], h->total);
+        if (e <= b) continue;
+        rc = scan_event(h, s, true);
+        if (rc) return rc;
+        HIP_TRY(h, launch_filter_scan(fa, b, e, s));
+        rc = scan_event(h, s, false);
+        if (rc) return rc;
+        h->stats.scan_launches += 1;
+        h->stats.rows_scanned += e - b;
+        HIP_TRY(h, launch_filter_update(fa, k, s));
+    }
+    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, sizeof(unsigned long long), s));
+    HIP_TRY(h, launch_filter_rescore(fa, k, q0, out_labels, out_dist, out_counts, out_d64,
+                                     h->counters.as<unsigned long long>(), s));
+    int32_t n_flagged = 0;
+    rc = collect_overflow(h, s, fa, &n_flagged);
+    if (rc) return rc;
+    unsigned long long rescored = 0;
+    HIP_TRY(h, hipMemcpy(&rescored, h->counters.p, sizeof rescored, hipMemcpyDeviceToHost));
+    h->stats.candidates_rescored += (int64_t)rescored;
+    if (n_flagged) {
+        h->stats.fallback_queries += n_flagged;
+        // outputs are indexed by batch position: shift the output base so query i lands at q0 + i
+        rc = run_exact(h, s, fa.Qpad, fa.qaux, n_flagged, h->qsel.as<int32_t>(), 0, h->total, k,
+                       out_labels + (size_t)q0 * k, out_dist + (size_t)q0 * k, out_counts + q0,
+                       out_d64 ? out_d64 + (size_t)q0 * k : nullptr, true);
+        if (rc) return rc;
+    }
+    return MLVDB_OK;
+}
+
+bool use_filter(const mlvdb_index* h, int64_t nq) {
+    if (h->strategy == MLVDB_STRATEGY_EXACT || !filter_supported(h->ld)) return false;
+    if (h->strategy == MLVDB_STRATEGY_FILTER) return true;
+    return nq >= 12 && h->total >= 32768;
+}
+
+int check_handle(mlvdb_index* h) {
+    if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return fail(h, MLVDB_ERR_HIP, "hipSetDevice", e);
+    return MLVDB_OK;
+}
+
+}  // namespace
+
+// ============================================================================== C ABI
+extern "C" {
+
+int mlvdb_abi_version(void) { return MLVDB_ABI_VERSION; }
+
+const char* mlvdb_last_global_error(void) { return g_error.c_str(); }
+
+const char* mlvdb_last_error(const mlvdb_index* h) { return h ? h->err.c_str() : g_error.c_str(); }
+
+int mlvdb_device_count(int* count) {
+    if (!count) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        *count = 0;
+        return fail(nullptr, MLVDB_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU fallback)", e);
+    }
+    *count = n;
+    return MLVDB_OK;
+}
+
+int64_t mlvdb_layout_offset(int64_t row, int32_t col, int32_t ld) { return layout_offset(row, col, ld); }
+int32_t mlvdb_layout_ld(int32_t dim) { return layout_ld(dim); }
+
+int mlvdb_index_create(int device, int32_t dim, int32_t space, int64_t capacity_hint, mlvdb_index** out) {
+    if (!out) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "out is null");
+    *out = nullptr;
+    if (dim <= 0 || dim > 8192) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "dim must be in 1..8192");
+    if (space < 0 || space > 2) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "space must be MLVDB_SPACE_L2/COSINE/IP");
+    if (capacity_hint < 0) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "capacity_hint < 0");
+    int n = 0;
+    int rc = mlvdb_device_count(&n);
+    if (rc) return rc;
+    if (device < 0 || device >= n) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "device index out of range");
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, MLVDB_ERR_HIP, "hipSetDevice", e);
+    mlvdb_index* h = new (std::nothrow) mlvdb_index();
+    if (!h) return fail(nullptr, MLVDB_ERR_OUT_OF_MEMORY, "host allocation failed");
+    h->device = device;
+    h->dim = dim;
+    h->ld = layout_ld(dim);
+    h->space = space;
+    e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete h;
+        return fail(nullptr, MLVDB_ERR_HIP, "hipStreamCreate", e);
+    }
+    e = h->counters.ensure(64);
+    if (e != hipSuccess) {
+        mlvdb_index_destroy(h);
+        return fail(nullptr, MLVDB_ERR_HIP, "hipMalloc(counters)", e);
+    }
+    if (capacity_hint > 0) {
+        rc = reserve_rows(h, capacity_hint);
+        if (rc) {
+            g_error = h->err;
+            mlvdb_index_destroy(h);
+            return rc;
+        }
+    }
+    *out = h;
+    return MLVDB_OK;
+}
+
+int mlvdb_index_destroy(mlvdb_index* h) {
+    if (!h) return MLVDB_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipDeviceSynchronize();
+    if (h->X) (void)hipFree(h->X);
+    if (h->rn) (void)hipFree(h->rn);
+    for (DevBuf* b : {&h->stage, &h->qpad, &h->qaux, &h->partial, &h->qsel, &h->seed_lab, &h->seed_dist, &h->seed_cnt,
+                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt,
+                      &h->counters, &h->labels_in})
+        b->release();
+    if (h->host_flags) (void)hipHostFree(h->host_flags);
+    for (auto& p : h->scan_events) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    for (auto& ev : h->total_events)
+        if (ev) (void)hipEventDestroy(ev);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return MLVDB_OK;
+}
+
+int mlvdb_index_append_device(mlvdb_index* h, const float* rows_device, int64_t n, int64_t* first_label) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !rows_device)) return fail(h, MLVDB_ERR_INVALID_ARG, "bad rows / n");
+    if (h->total + n > 0x7fffff00ll) return fail(h, MLVDB_ERR_UNSUPPORTED, "more than 2^31 rows per index");
+    if (first_label) *first_label = h->total;
+    if (n == 0) return MLVDB_OK;
+    rc = reserve_rows(h, h->total + n);
+    if (rc) return rc;
+    HIP_TRY(h, launch_scatter_rows(rows_device, h->X, h->total, n, h->dim, h->ld, h->stream));
+    HIP_TRY(h, launch_row_norms(h->X, h->rn, h->total, n, h->ld, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->total += n;
+    return MLVDB_OK;
+}
+
+int mlvdb_index_append(mlvdb_index* h, const float* rows, int64_t n, int64_t* first_label) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !rows)) return fail(h, MLVDB_ERR_INVALID_ARG, "bad rows / n");
+    if (h->total + n > 0x7fffff00ll) return fail(h, MLVDB_ERR_UNSUPPORTED, "more than 2^31 rows per index");
+    if (first_label) *first_label = h->total;
+    if (n == 0) return MLVDB_OK;
+    rc = reserve_rows(h, h->total + n);
+    if (rc) return rc;
+    const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(256u << 20) / ((int64_t)h->dim * 4));
+    for (int64_t done = 0; done < n; done += chunk_rows) {
+        const int64_t m = std::min(chunk_rows, n - done);
+        HIP_TRY(h, h->stage.ensure((size_t)m * h->dim * sizeof(float)));
+        HIP_TRY(h, hipMemcpyAsync(h->stage.p, rows + (size_t)done * h->dim, (size_t)m * h->dim * sizeof(float),
+                                  hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(h, launch_scatter_rows(h->stage.as<float>(), h->X, h->total + done, m, h->dim, h->ld, h->stream));
+        HIP_TRY(h, launch_row_norms(h->X, h->rn, h->total + done, m, h->ld, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    h->total += n;
+    return MLVDB_OK;
+}
+
+int mlvdb_index_tombstone(mlvdb_index* h, const int64_t* labels, int64_t n, int64_t* newly_deleted) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && !labels)) return fail(h, MLVDB_ERR_INVALID_ARG, "bad labels / n");
+    if (newly_deleted) *newly_deleted = 0;
+    if (n == 0 || h->total == 0) return MLVDB_OK;
+    HIP_TRY(h, h->labels_in.ensure((size_t)n * sizeof(int64_t)));
+    HIP_TRY(h, hipMemcpyAsync(h->labels_in.p, labels, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, sizeof(unsigned long long), h->stream));
+    HIP_TRY(h, launch_tombstone(h->rn, h->labels_in.as<int64_t>(), n, h->total, h->counters.as<unsigned long long>(),
+                                h->stream));
+    unsigned long long changed = 0;
+    HIP_TRY(h, hipMemcpyAsync(&changed, h->counters.p, sizeof changed, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->deleted += (int64_t)changed;
+    if (newly_deleted) *newly_deleted = (int64_t)changed;
+    return MLVDB_OK;
+}
+
+int mlvdb_index_counts(const mlvdb_index* h, int64_t* total, int64_t* deleted) {
+    if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");
+    if (total) *total = h->total;
+    if (deleted) *deleted = h->deleted;
+    return MLVDB_OK;
+}
+
+int mlvdb_index_reset(mlvdb_index* h, int32_t space) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (space > 2) return fail(h, MLVDB_ERR_INVALID_ARG, "space must be < 0 (keep) or a MLVDB_SPACE_* value");
+    if (h->capacity > 0) {
+        HIP_TRY(h, hipMemsetAsync(h->X, 0, (size_t)h->capacity * h->ld * sizeof(float), h->stream));
+        HIP_TRY(h, hipMemsetAsync(h->rn, 0xFF, (size_t)h->capacity * sizeof(float), h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    h->total = 0;
+    h->deleted = 0;
+    if (space >= 0) h->space = space;
+    return MLVDB_OK;
+}
+
+int mlvdb_index_get_rows(mlvdb_index* h, int64_t first, int64_t n, float* out_rows) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (first < 0 || n < 0 || first + n > h->total || (n > 0 && !out_rows))
+        return fail(h, MLVDB_ERR_INVALID_ARG, "row range out of bounds");
+    const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(256u << 20) / ((int64_t)h->dim * 4));
+    for (int64_t done = 0; done < n; done += chunk_rows) {
+        const int64_t m = std::min(chunk_rows, n - done);
+        HIP_TRY(h, h->stage.ensure((size_t)m * h->dim * sizeof(float)));
+        HIP_TRY(h, launch_gather_rows(h->X, h->stage.as<float>(), first + done, m, h->dim, h->ld, h->stream));
+        HIP_TRY(h, hipMemcpyAsync(out_rows + (size_t)done * h->dim, h->stage.p, (size_t)m * h->dim * sizeof(float),
+                                  hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+    }
+    return MLVDB_OK;
+}
+
+int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64_t nq, int32_t k,
+                              int64_t* out_labels_device, float* out_dist_device, int32_t* out_counts_device,
+                              double* out_dist64_device, void* stream) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (nq < 0 || nq > (1 << 24)) return fail(h, MLVDB_ERR_INVALID_ARG, "nq out of range");
+    if (k < 1) return fail(h, MLVDB_ERR_INVALID_ARG, "k must be >= 1");
+    if (k > MLVDB_MAX_TOPK) return fail(h, MLVDB_ERR_UNSUPPORTED, "k above MLVDB_MAX_TOPK");
+    if (nq == 0) return MLVDB_OK;
+    if (!queries_device || !out_labels_device || !out_dist_device || !out_counts_device)
+        return fail(h, MLVDB_ERR_INVALID_ARG, "null buffer");
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    rc = begin_call(h, s);
+    if (rc) return rc;
+    if (h->total == 0 || h->total == h->deleted) {
+        fill_empty_kernel<<<(unsigned)((nq * k + 255) / 256), 256, 0, s>>>(out_labels_device, out_dist_device,
+                                                                            out_counts_device, out_dist64_device, nq, k);
+        HIP_TRY(h, hipGetLastError());
+        return end_call(h, s);
+    }
+    HIP_TRY(h, h->qpad.ensure((size_t)nq * h->ld * sizeof(float)));
+    HIP_TRY(h, h->qaux.ensure((size_t)nq * sizeof(double)));
+    HIP_TRY(h, launch_query_prep(queries_device, (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
+                                 h->qaux.as<double>(), s));
+    if (use_filter(h, nq)) {
+        h->stats.strategy_used = MLVDB_STRATEGY_FILTER;
+        for (int64_t q0 = 0; q0 < nq; q0 += kFilterQueries) {
+            const int32_t n = (int32_t)std::min<int64_t>(kFilterQueries, nq - q0);
+            rc = run_filter_pass(h, s, h->qpad.as<float>(), h->qaux.as<double>(), (int32_t)q0, n, k, out_labels_device,
+                                 out_dist_device, out_counts_device, out_dist64_device);
+            if (rc) return rc;
+        }
+    } else {
+        h->stats.strategy_used = MLVDB_STRATEGY_EXACT;
+        rc = run_exact(h, s, h->qpad.as<float>(), h->qaux.as<double>(), (int32_t)nq, nullptr, 0, h->total, k,
+                       out_labels_device, out_dist_device, out_counts_device, out_dist64_device, true);
+        if (rc) return rc;
+    }
+    return end_call(h, s);
+}
+
+int mlvdb_search_batch(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, int64_t* out_labels,
+                       float* out_dist, int32_t* out_counts) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (nq < 0 || nq > (1 << 24)) return fail(h, MLVDB_ERR_INVALID_ARG, "nq out of range");
+    if (k < 1) return fail(h, MLVDB_ERR_INVALID_ARG, "k must be >= 1");
+    if (k > MLVDB_MAX_TOPK) return fail(h, MLVDB_ERR_UNSUPPORTED, "k above MLVDB_MAX_TOPK");
+    if (nq == 0) return MLVDB_OK;
+    if (!queries || !out_labels || !out_dist || !out_counts) return fail(h, MLVDB_ERR_INVALID_ARG, "null buffer");
+    HIP_TRY(h, h->io_q.ensure((size_t)nq * h->dim * sizeof(float)));
+    HIP_TRY(h, h->io_lab.ensure((size_t)nq * k * sizeof(int64_t)));
+    HIP_TRY(h, h->io_dist.ensure((size_t)nq * k * sizeof(float)));
+    HIP_TRY(h, h->io_cnt.ensure((size_t)nq * sizeof(int32_t)));
+    HIP_TRY(h, hipMemcpyAsync(h->io_q.p, queries, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    rc = mlvdb_search_batch_device(h, h->io_q.as<float>(), nq, k, h->io_lab.as<int64_t>(), h->io_dist.as<float>(),
+                                   h->io_cnt.as<int32_t>(), nullptr, h->stream);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(out_labels, h->io_lab.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_dist, h->io_dist.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(out_counts, h->io_cnt.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return MLVDB_OK;
+}
+
+int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float radius, int64_t capacity,
+                      int64_t* out_labels, float* out_dist, int64_t* out_counts) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (nq < 0 || nq > (1 << 24)) return fail(h, MLVDB_ERR_INVALID_ARG, "nq out of range");
+    if (capacity < 1) return fail(h, MLVDB_ERR_INVALID_ARG, "capacity must be >= 1");
+    if (nq == 0) return MLVDB_OK;
+    if (!queries || !out_labels || !out_dist || !out_counts) return fail(h, MLVDB_ERR_INVALID_ARG, "null buffer");
+    hipStream_t s = h->stream;
+    rc = begin_call(h, s);
+    if (rc) return rc;
+    if (h->total == 0 || h->total == h->deleted) {
+        for (int64_t i = 0; i < nq; ++i) out_counts[i] = 0;
+        return end_call(h, s);
+    }
+    HIP_TRY(h, h->io_q.ensure((size_t)nq * h->dim * sizeof(float)));
+    HIP_TRY(h, h->qpad.ensure((size_t)nq * h->ld * sizeof(float)));
+    HIP_TRY(h, h->qaux.ensure((size_t)nq * sizeof(double)));
+    const int64_t cap_eff = std::min<int64_t>(capacity, kCandCap);
+    HIP_TRY(h, h->io_lab.ensure((size_t)nq * cap_eff * sizeof(int64_t)));
+    HIP_TRY(h, h->io_dist.ensure((size_t)nq * cap_eff * sizeof(float)));
+    HIP_TRY(h, h->io_cnt.ensure((size_t)nq * sizeof(int64_t)));
+    HIP_TRY(h, hipMemcpyAsync(h->io_q.p, queries, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, launch_query_prep(h->io_q.as<float>(), (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
+                                 h->qaux.as<double>(), s));
+    const bool filt = h->strategy != MLVDB_STRATEGY_EXACT && filter_supported(h->ld) &&
+                      (h->strategy == MLVDB_STRATEGY_FILTER || (nq >= 12 && h->total >= 32768));
+    h->stats.strategy_used = filt ? MLVDB_STRATEGY_FILTER : MLVDB_STRATEGY_EXACT;
+    for (int64_t q0 = 0; q0 < nq; q0 += kFilterQueries) {
+        const int32_t n = (int32_t)std::min<int64_t>(kFilterQueries, nq - q0);
+        FilterArgs fa{};
+        rc = setup_filter_ws(h, fa, h->qpad.as<float>() + (size_t)q0 * h->ld, h->qaux.as<double>() + q0, n);
+        if (rc) return rc;
+        HIP_TRY(h, launch_filter_prep(fa, s));  // also clears the candidate counters
+        rc = scan_event(h, s, true);
+        if (rc) return rc;
+        if (filt) {
+            HIP_TRY(h, launch_filter_range_thr(fa, radius, s));
+            HIP_TRY(h, launch_filter_scan(fa, 0, h->total, s));
+        } else {
+            HIP_TRY(h, launch_exact_range_scan(fa, radius, s));
+        }
+        rc = scan_event(h, s, false);
+        if (rc) return rc;
+        h->stats.scan_launches += 1;
+        h->stats.rows_scanned += h->total;
+        int32_t n_flagged = 0;
+        rc = collect_overflow(h, s, fa, &n_flagged);
+        if (rc) return rc;
+        if (n_flagged)
+            return fail(h, MLVDB_ERR_UNSUPPORTED,
+                        "range query admits more than 8192 candidate rows for some query; use a smaller radius");
+        HIP_TRY(h, launch_range_rescore(fa, radius, (int32_t)q0, cap_eff, h->io_lab.as<int64_t>(),
+                                        h->io_dist.as<float>(), h->io_cnt.as<int64_t>(), s));
+    }
+    // copy back (rows of cap_eff entries into rows of `capacity` entries)
+    std::vector<int64_t> counts(nq);
+    HIP_TRY(h, hipMemcpyAsync(counts.data(), h->io_cnt.p, (size_t)nq * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpy2DAsync(out_labels, (size_t)capacity * sizeof(int64_t), h->io_lab.p, (size_t)cap_eff * sizeof(int64_t),
+                                (size_t)cap_eff * sizeof(int64_t), (size_t)nq, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipMemcpy2DAsync(out_dist, (size_t)capacity * sizeof(float), h->io_dist.p, (size_t)cap_eff * sizeof(float),
+                                (size_t)cap_eff * sizeof(float), (size_t)nq, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    bool over = false;
+    for (int64_t i = 0; i < nq; ++i) {
+        out_counts[i] = counts[i];
+        over |= counts[i] > capacity;
+    }
+    rc = end_call(h, s);
+    if (rc) return rc;
+    if (over) return fail(h, MLVDB_ERR_OVERFLOW, "some query has more hits than `capacity`; out_counts holds the exact counts");
+    return MLVDB_OK;
+}
+
+int mlvdb_index_set_strategy(mlvdb_index* h, int32_t strategy) {
+    if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");
+    if (strategy < 0 || strategy > 2) return fail(h, MLVDB_ERR_INVALID_ARG, "unknown strategy");
+    if (strategy == MLVDB_STRATEGY_FILTER && !filter_supported(h->ld))
+        return fail(h, MLVDB_ERR_UNSUPPORTED, "filter strategy needs dim padded to a multiple of 64");
+    h->strategy = strategy;
+    return MLVDB_OK;
+}
+
+int mlvdb_index_set_profiling(mlvdb_index* h, int32_t enabled) {
+    if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");
+    h->profiling = enabled != 0;
+    return MLVDB_OK;
+}
+
+int mlvdb_index_last_stats(mlvdb_index* h, mlvdb_stats* out) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!out) return fail(h, MLVDB_ERR_INVALID_ARG, "out is null");
+    if (h->stats_pending) {
+        HIP_TRY(h, hipEventSynchronize(h->total_events[1]));
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->total_events[0], h->total_events[1]));
+        h->stats.total_ms = ms;
+        double scan = 0.0;
+        for (size_t i = 0; i < h->scan_events_used; ++i) {
+            HIP_TRY(h, hipEventElapsedTime(&ms, h->scan_events[i].first, h->scan_events[i].second));
+            scan += ms;
+        }
+        h->stats.scan_ms = scan;
+        h->stats_pending = false;
+    }
+    *out = h->stats;
+    return MLVDB_OK;
+}
+
+}  // extern "C"

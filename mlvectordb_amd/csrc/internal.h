@@ -1,0 +1,108 @@
+// Internal declarations shared by the translation units of libmlvdb_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mlvdb_hip.h"
+#include "layout.h"
+#include "wave_topk.h"
+
+namespace mlvdb {
+
+// ---------------------------------------------------------------- layout kernels (kernels_layout.hip)
+// stage: row-major [n, dim] on the device -> panels; rows first_row..first_row+n-1
+hipError_t launch_scatter_rows(const float* stage, float* X, int64_t first_row, int64_t n, int32_t dim, int32_t ld,
+                               hipStream_t s);
+// rn[row] = (float)|x_row| for the same rows (fp64 sum of squares)
+hipError_t launch_row_norms(const float* X, float* rn, int64_t first_row, int64_t n, int32_t ld, hipStream_t s);
+// panels -> row-major [n, dim]
+hipError_t launch_gather_rows(const float* X, float* out, int64_t first_row, int64_t n, int32_t dim, int32_t ld,
+                              hipStream_t s);
+// rn[label] = NaN for each valid, live label; *changed += number of rows that changed state
+hipError_t launch_tombstone(float* rn, const int64_t* labels, int64_t n, int64_t total, unsigned long long* changed,
+                            hipStream_t s);
+// Qpad[q][0..ld) = queries[q][0..dim) zero padded; qaux[q] = 1/(|q|+1e-30) (cosine) or |q| (l2, ip)
+hipError_t launch_query_prep(const float* queries, int32_t nq, int32_t dim, int32_t ld, int32_t space, float* Qpad,
+                             double* qaux, hipStream_t s);
+
+// ---------------------------------------------------------------- exact scan (kernels_exact.hip)
+struct ExactPlan {
+    int qt;        // queries per block tile (1, 2, 4, 8)
+    int nblk;      // blocks along the corpus
+    int nqtiles;   // blocks along the query batch
+    int threads;   // block size
+    size_t lds_bytes;
+};
+ExactPlan plan_exact(int64_t nrows, int32_t ld, int32_t nq_sel, int32_t k);
+
+struct ExactArgs {
+    const float* X;
+    const float* rn;
+    int64_t row_begin;   // first row scanned (multiple of 16)
+    int64_t row_end;     // one past the last row scanned (<= total)
+    int32_t ld;
+    int32_t space;
+    const float* Qpad;   // [nq][ld]
+    const double* qaux;  // [nq]
+    const int32_t* qsel; // [nq_sel] query indices to process, or nullptr for 0..nq_sel-1
+    int32_t nq_sel;
+    int32_t k;
+    const double* cursor_d;   // optional paging cursor per query (nullptr = none):
+    const int32_t* cursor_l;  //   only rows strictly after (cursor_d, cursor_l) in rank order are admitted
+    TopEntry* partial;        // [nq_sel][nblk][k]
+};
+hipError_t launch_exact_scan(const ExactArgs& a, const ExactPlan& p, hipStream_t s);
+// merge partial lists -> final outputs at the original query index
+hipError_t launch_exact_merge(const TopEntry* partial, int32_t nq_sel, const int32_t* qsel, int32_t nblk, int32_t k,
+                              int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_d64,
+                              hipStream_t s);
+
+// ---------------------------------------------------------------- filter path (kernels_filter.hip)
+constexpr int kFilterQueries = 256;   // queries per filter pass
+constexpr int kFilterChunkK = 64;     // columns per Q chunk staged in LDS
+constexpr int kCandCap = 8192;        // candidate slots per query
+constexpr int kFilterTile = 192;      // rows per filter-kernel tile: scan ranges start on multiples of it
+
+struct CandEntry {
+    float u;      // upper bound of the row's score (higher = nearer)
+    int32_t row;
+};
+
+bool filter_supported(int32_t ld);
+size_t filter_qimg_bytes(int32_t ld);   // bf16 query image for one pass of kFilterQueries
+
+struct FilterArgs {
+    const float* X;
+    const float* rn;
+    int64_t total;
+    int32_t ld;
+    int32_t space;
+    const float* Qpad;      // [nq][ld] raw queries of this pass (q0..q0+nq)
+    const double* qaux;
+    int32_t nq;             // <= kFilterQueries
+    // workspace (per pass)
+    void* qimg;             // bf16 image, filter_qimg_bytes
+    float* qscale;          // [256] per-query multiplier of the dot product in score units
+    float* thr;             // [256] admission threshold (lower bound of the k-th best score)
+    uint32_t* cnt;          // [256] candidates appended
+    uint32_t* overflow;     // [256] nonzero = list overflowed, query must be re-run exactly
+    CandEntry* cand;        // [256][kCandCap]
+};
+hipError_t launch_filter_prep(const FilterArgs& a, hipStream_t s);
+// seed thresholds from exact kNN distances of a prefix of the corpus: seed_d64[q][k]
+hipError_t launch_filter_seed_thr(const FilterArgs& a, const double* seed_d64, int32_t k, hipStream_t s);
+hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s);
+hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s);
+hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
+                                 int32_t* out_counts, double* out_d64, unsigned long long* rescored, hipStream_t s);
+// range variant: fixed per-query threshold from the radius, then exact rescoring with emit
+hipError_t launch_filter_range_thr(const FilterArgs& a, float radius, hipStream_t s);
+// exact candidate generator for range queries (any dim): appends every live row with dist <= radius
+hipError_t launch_exact_range_scan(const FilterArgs& a, float radius, hipStream_t s);
+hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, int64_t capacity, int64_t* out_labels,
+                                float* out_dist, int64_t* out_counts, hipStream_t s);
+
+}  // namespace mlvdb

@@ -1,0 +1,697 @@
+// Filter path for large query batches: a bf16-MFMA bound filter over the fp32 corpus followed
+// by exact fp64 rescoring of the few surviving rows.
+//
+// Why: with 256 queries per pass the scan needs 2*N*d*256 flop per 4*N*d corpus bytes; in
+// fp32 (VALU or f32-input MFMA, 157 TF) that is compute-bound at ~15 % of the HBM roof, on
+// bf16 MFMA it fits under the HBM stream.  bf16 scores are not exact, so they are used only
+// as BOUNDS:  for every (query, row) the kernel computes u >= s, an upper bound of the true
+// score s (higher = nearer), from the bf16 dot product a and a rigorous rounding bound
+//       |a - <q^, x>| <= E1 * |x|,  E1 = 2^-7 + 2^-16 + ld*2^-22   (|q^| = 1)
+// (two bf16 roundings of relative size 2^-8 each, Cauchy-Schwarz, fp32 accumulation slack).
+// A row is discarded only if u < thr[q], where thr[q] is a proven LOWER bound of the k-th
+// best true score (k rows with lower bound l = u - 2*eps >= thr exist, or k exactly scored
+// seed rows do).  Everything else is appended to the query's candidate list and rescored in
+// fp64 by the same arithmetic as the exact scan, so the answer is the exact one.  A list
+// that overflows (adversarial near-ties) flags its query for the exact scan instead.
+//
+// Score units per space (q^ = q/(|q|+1e-30)):
+//   cosine  s = <q^,x>/(|x|+1e-30)       = 1 - dist
+//   ip      s = <q^,x>                   = (1 - dist)/|q|
+//   l2      s = 2|q|<q^,x> - |x|^2       = |q|^2 - dist
+#include "internal.h"
+#include "scan_common.h"
+
+namespace mlvdb {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte buffer load: wave-uniform descriptor + scalar byte offset, one VGPR of lane offset.
+// Keeps the streaming loads' address arithmetic on the scalar unit (no 64-bit VGPR adds).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load_f4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ uint4 buf_load_u4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+constexpr int kFilterWaves = 4;
+constexpr int kFilterThreads = kFilterWaves * 64;
+constexpr int kChunkVec = kFilterQueries * kFilterChunkK * 2 / 16;  // uint4 per Q chunk (2048)
+constexpr float kSlack = 1.9073486328125e-06f;                      // 2^-19
+constexpr int kMT = 3;                        // 16-row MFMA tiles (panels) per wave
+constexpr int kFilterTileRows = kFilterWaves * 16 * kMT;  // 192 rows per workgroup tile
+static_assert(kFilterTileRows == kFilterTile, "internal.h kFilterTile out of sync");
+
+bool filter_supported(int32_t ld) { return ld >= kFilterChunkK && (ld % kFilterChunkK) == 0; }
+size_t filter_qimg_bytes(int32_t ld) { return (size_t)kFilterQueries * ld * 2; }
+
+static inline float filter_e1(int32_t ld) { return 0.0078125f + 1.52587890625e-05f + (float)ld * 2.384185791015625e-07f; }
+
+// ------------------------------------------------------------------ query image
+// Qimg[kc][n][ks][lane][j] = bf16(q^[16n + (lane&15)][64kc + 16(2ks + (j>>2)) + 4(lane>>4) + (j&3)])
+// i.e. exactly the B-operand fragments of v_mfma_f32_16x16x32_bf16 for the k-order in which
+// the scan kernel receives its A fragments from the panel layout (layout.h).
+__global__ __launch_bounds__(256) void filter_prep_kernel(const FilterArgs a) {
+    const int nkc = a.ld / kFilterChunkK;
+    __bf16* img = reinterpret_cast<__bf16*>(a.qimg);
+    const int64_t total = (int64_t)nkc * kChunkVec * 8;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int j = idx & 7;
+        const int lane = (idx >> 3) & 63;
+        const int ks = (idx >> 9) & 1;
+        const int n = (idx >> 10) & 15;
+        const int kc = (int)(idx >> 14);
+        const int q = 16 * n + (lane & 15);
+        const int col = 64 * kc + 16 * (2 * ks + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
+        float v = 0.f;
+        if (q < a.nq) {
+            const double aux = a.qaux[q];
+            const double inv = a.space == kSpaceCosine ? aux : 1.0 / (aux + 1e-30);
+            v = a.Qpad[(int64_t)q * a.ld + col] * (float)inv;
+        }
+        img[idx] = (__bf16)v;
+    }
+    if (blockIdx.x == 0) {
+        const int q = threadIdx.x;  // 256 threads = kFilterQueries
+        const double nrm = q < a.nq ? (a.space == kSpaceCosine ? 0.0 : a.qaux[q]) : 0.0;
+        a.qscale[q] = a.space == kSpaceL2 ? (float)(2.0 * nrm) : 1.0f;
+        a.thr[q] = q < a.nq ? -3.0e38f : 3.4e38f;  // padded queries never admit anything
+        a.cnt[q] = 0;
+        a.overflow[q] = 0;
+    }
+}
+
+// round a double down to a float that is <= it
+__device__ __forceinline__ float float_below(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = __uint_as_float(f > 0.f ? __float_as_uint(f) - 1 : (f < 0.f ? __float_as_uint(f) + 1 : 0x80000001u));
+    return f;
+}
+
+// thr[q] from the exact distance of the k-th nearest seed row
+__global__ __launch_bounds__(256) void filter_seed_thr_kernel(const FilterArgs a, const double* seed_d64, int32_t k) {
+    const int q = threadIdx.x;
+    if (q >= a.nq) return;
+    const double dk = seed_d64[(int64_t)q * k + (k - 1)];
+    if (!(dk < 1.0e300)) return;  // fewer than k seeds (inf) or NaN
+    const double aux = a.qaux[q];
+    double s;
+    if (a.space == kSpaceCosine) {
+        s = 1.0 - dk;
+    } else if (a.space == kSpaceIp) {
+        if (!(aux > 0.0)) return;
+        s = (1.0 - dk) / aux;
+    } else {
+        s = aux * aux - dk;
+    }
+    const double mag = a.space == kSpaceL2 ? aux * aux + __builtin_fabs(dk) : __builtin_fabs(s) + 1.0;
+    a.thr[q] = float_below(s - 1e-9 * mag);
+}
+
+// thr[q] for a range query: every row with dist <= radius has s >= s(radius)
+__global__ __launch_bounds__(256) void filter_range_thr_kernel(const FilterArgs a, float radius) {
+    const int q = threadIdx.x;
+    if (q >= a.nq) return;
+    const double aux = a.qaux[q];
+    const double r = (double)radius;
+    double s;
+    if (a.space == kSpaceCosine) {
+        s = 1.0 - r;
+    } else if (a.space == kSpaceIp) {
+        if (!(aux > 0.0)) return;  // |q| = 0: every distance is 1; keep thr = -max (admit all)
+        s = (1.0 - r) / aux;
+    } else {
+        s = aux * aux - r;
+    }
+    const double mag = a.space == kSpaceL2 ? aux * aux + __builtin_fabs(r) : __builtin_fabs(s) + 1.0;
+    a.thr[q] = float_below(s - 1e-9 * mag);
+}
+
+// ------------------------------------------------------------------ the scan
+// One workgroup = 4 waves (one per SIMD, so each wave may use the whole 512-entry register
+// file) = one 192-row tile (12 panels) against all 256 queries; wave w owns panels 3w..3w+2,
+// i.e. a 48 x 256 block of scores in 192 accumulator registers (AGPRs).  (64 rows per wave
+// would fill the 256-entry AGPR file exactly, and hipcc then shuffles and spills.)
+//   X   HBM -> registers: each wave load is one lane-linear 1 KiB burst of one panel
+//       (layout.h) and is already the MFMA A fragment; nobody else needs those rows, so no LDS.
+//       R register buffers of one 32-column half-chunk each (8 KiB per wave) rotate, so
+//       (R-1)..R half-chunks per wave stay in flight under the MFMAs.  The rotation is static
+//       (the step loop is unrolled lcm(R,2) times): a run-time rotation makes hipcc copy
+//       registers that are targets of in-flight loads, which drains the prefetch.
+//   Q   the bf16 query image (L2 resident) goes registers -> LDS in 64-column chunks, double
+//       buffered, one barrier per chunk, and is read back as ready-made B fragments
+//       (ds_read_b128, lane-linear, conflict free).  Each B fragment feeds 4 MFMAs.
+//       Chunk c+1 is loaded right after barrier(c) and written just before barrier(c+1): the
+//       loads are older than the X prefetches issued meanwhile, so waiting for them (in-order
+//       vmcnt) never drains those.
+// All loads are ordinary loads on purpose: hipcc then tracks them with counted s_waitcnt.
+template <int SPACE, int R>
+__global__ __launch_bounds__(kFilterThreads, 1) void filter_scan_kernel(const FilterArgs a, const int64_t tile_begin,
+                                                                        const int64_t tile_end, const float e1) {
+    constexpr int U = (R % 2 == 0) ? R : 2 * R;  // steps per unrolled body
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* qlds = reinterpret_cast<uint4*>(smem);                                  // [2][kChunkVec]
+    float* thr_l = reinterpret_cast<float*>(smem + 2 * kChunkVec * sizeof(uint4));  // [256]
+    float* sq_l = thr_l + kFilterQueries;                                           // [256]
+    float* hit_l = sq_l + kFilterQueries;                                           // [4 waves][16][64]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
+    const int g = lane >> 4;
+    const int c16 = lane & 15;
+    const int ld = a.ld;
+    const int nkc = ld / kFilterChunkK;
+    thr_l[threadIdx.x] = a.thr[threadIdx.x];  // kFilterThreads == kFilterQueries
+    sq_l[threadIdx.x] = a.qscale[threadIdx.x];
+
+    const int64_t ntiles = tile_end - tile_begin;
+    const int64_t my_tiles = ntiles > blockIdx.x ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int64_t total_chunks = my_tiles * nkc;
+    const int64_t total_steps = total_chunks * 2;
+    if (total_steps == 0) return;
+    const int steps_per_tile = 2 * nkc;  // a multiple of U by construction (launcher picks R)
+    const int64_t panel_stride = (int64_t)kPanelRows * ld;  // floats per panel
+
+    f32x4 acc[kMT][16];
+    float4 xr[R][kMT][2];  // raw fp32 X half-chunks in flight; indexed only by unrolled constants
+    uint4 qst[8];        // this thread's share of the next Q chunk
+    float4 rnv[kMT];     // |x| of this lane's kMT x 4 rows of the current tile
+
+    // X prefetch cursor over (tile index, chunk, half)
+    int64_t pre_i = 0;
+    int pre_kc = 0, pre_h = 0;
+    auto tile_of = [&](int64_t i) __attribute__((always_inline)) { return tile_begin + blockIdx.x + i * gridDim.x; };
+    const uint32_t lane_off16 = lane * 16;          // the only per-lane part of every X address
+    const uint32_t wave_bytes = (uint32_t)(kMT * panel_stride * sizeof(float));  // this wave's panels of a tile
+    auto load_x = [&](float4(&xb)[kMT][2]) __attribute__((always_inline)) {
+        const float* base = a.X + (tile_of(pre_i) * (kMT * 4) + kMT * wave) * panel_stride;
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(base, wave_bytes);
+        const uint32_t soff = (uint32_t)(pre_kc * 4 + pre_h * 2) * (kGroupFloats * 4);
+#pragma unroll
+        for (int m = 0; m < kMT; ++m)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+                xb[m][kb] = buf_load_f4(r, lane_off16, soff + (uint32_t)(m * panel_stride * 4) + kb * (kGroupFloats * 4));
+        // advance, saturating at the last half-chunk (the tail re-loads it: harmless, and it keeps
+        // every load unconditional -- a conditional load's phi makes hipcc wait for it at once)
+        const bool at_end = pre_i == my_tiles - 1 && pre_kc == nkc - 1 && pre_h == 1;
+        if (!at_end) {
+            if (++pre_h == 2) {
+                pre_h = 0;
+                if (++pre_kc == nkc) {
+                    pre_kc = 0;
+                    ++pre_i;
+                }
+            }
+        }
+    };
+    const __amdgpu_buffer_rsrc_t q_rsrc = make_rsrc(a.qimg, (uint32_t)(nkc * kChunkVec * sizeof(uint4)));
+    const uint32_t tid_off16 = threadIdx.x * 16;
+    auto load_q = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            qst[i] = buf_load_u4(q_rsrc, tid_off16, (uint32_t)(kc * kChunkVec + i * kFilterThreads) * 16);
+    };
+    auto store_q = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qlds[buf * kChunkVec + threadIdx.x + i * kFilterThreads] = qst[i];
+    };
+
+    // ---- prologue: Q(0) in registers, X(0..R-1) in flight
+    load_q(0);
+    int q_next_kc = nkc > 1 ? 1 : 0;  // chunk of the query image that the next load_q fetches
+#pragma unroll
+    for (int b = 0; b < R; ++b) load_x(xr[b]);
+
+    // Tile finished: bounds, admission test, rare appends.
+    auto epilogue = [&](const int64_t ti) __attribute__((always_inline)) {
+        const int32_t row0 = (int32_t)(tile_of(ti) * kFilterTileRows) + wave * (16 * kMT) + g * 4;
+        float* dump = hit_l + wave * 1024 + lane;  // [16][64] floats per wave
+        // per-row constants: cosine  u = a*p0 + ec      (p0 = 1/(|x|+1e-30))
+        //                    ip      u = a + p0          (p0 = (e1+slack)|x|)
+        //                    l2      u = sq*(a + p0) + p1 (p1 = -|x|^2 (1-slack))
+        float p0[kMT][4], p1[kMT][4];
+        const float ec = e1 + 2.0f * kSlack;
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+            const float nr[4] = {rnv[m].x, rnv[m].y, rnv[m].z, rnv[m].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (SPACE == kSpaceCosine) {
+                    p0[m][i] = 1.0f / (nr[i] + 1e-30f);
+                    p1[m][i] = 0.f;
+                } else {
+                    p0[m][i] = (e1 + kSlack) * nr[i];
+                    p1[m][i] = SPACE == kSpaceL2 ? -(nr[i] * nr[i]) * (1.0f - kSlack) : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            __builtin_amdgcn_sched_barrier(0);  // keep only one query tile's scores live at a time
+            const float thr = thr_l[16 * n + c16];
+            const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
+            float u[4 * kMT];
+            uint32_t mask = 0;
+#pragma unroll
+            for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float av = acc[m][n][i];
+                    float uv;
+                    if (SPACE == kSpaceCosine) uv = __builtin_fmaf(av, p0[m][i], ec);
+                    else if (SPACE == kSpaceIp) uv = av + p0[m][i];
+                    else uv = __builtin_fmaf(sq, av + p0[m][i], p1[m][i]);
+                    u[4 * m + i] = uv;
+                    mask |= uv >= thr ? 1u << (4 * m + i) : 0u;
+                }
+            if (__ballot(mask != 0)) {
+                // rare: park the 16 scores in LDS so the hits can be walked with a dynamic index
+#pragma unroll
+                for (int j = 0; j < 4 * kMT; ++j) dump[j * 64] = u[j];
+                const int q = 16 * n + c16;
+                while (mask) {
+                    const int j = __builtin_ctz(mask);
+                    mask &= mask - 1;
+                    const uint32_t slot = atomicAdd(&a.cnt[q], 1u);
+                    if (slot < (uint32_t)kCandCap) {
+                        CandEntry e;
+                        e.u = dump[j * 64];
+                        e.row = row0 + 16 * (j >> 2) + (j & 3);
+                        a.cand[(int64_t)q * kCandCap + slot] = e;
+                    } else {
+                        a.overflow[q] = 1u;
+                    }
+                }
+            }
+        }
+    };
+
+    for (int64_t ti = 0; ti < my_tiles; ++ti) {
+#pragma unroll
+        for (int m = 0; m < kMT; ++m)
+#pragma unroll
+            for (int n = 0; n < 16; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int st = 0; st < steps_per_tile; st += U) {
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                // one step = one 32-column half-chunk; b, h are compile-time after unrolling
+                const int b = j % R;
+                const int h = j & 1;
+                const int64_t s = ti * steps_per_tile + st + j;
+                const int64_t c = s >> 1;
+                // 1. this half-chunk's A fragments: fp32 -> bf16 in registers
+                bf16x8 xa[kMT];
+#pragma unroll
+                for (int m = 0; m < kMT; ++m) {
+                    const float4 lo = xr[b][m][0], hi = xr[b][m][1];
+                    const f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                    xa[m] = __builtin_convertvector(v, bf16x8);
+                }
+                if (h == 0) {
+                    // 2. new chunk: publish Q(c) (loaded two steps ago), then fetch Q(c+1)
+                    store_q((int)(c & 1));
+                    __syncthreads();
+                    load_q(q_next_kc);
+                    q_next_kc = q_next_kc + 1 == nkc ? 0 : q_next_kc + 1;
+                } else if (j == U - 1) {
+                    // row norms for the epilogue; reloaded every U steps so the load is unconditional
+                    const __amdgpu_buffer_rsrc_t rr =
+                        make_rsrc(a.rn + tile_of(ti) * kFilterTileRows + wave * (16 * kMT), 16 * kMT * 4);
+#pragma unroll
+                    for (int m = 0; m < kMT; ++m) rnv[m] = buf_load_f4(rr, g * 16, m * 64);
+                }
+                // 3. refill the register buffer just consumed with the half-chunk R steps ahead
+                load_x(xr[b]);
+                // 4. 64 MFMAs: 16 query tiles x 4 row tiles, k-step h of the chunk
+                const uint4* qb_base = qlds + (c & 1) * kChunkVec + h * 64 + lane;
+                uint4 qraw[2];
+                qraw[0] = qb_base[0];
+#pragma unroll
+                for (int n = 0; n < 16; ++n) {
+                    if (n + 1 < 16) qraw[(n + 1) & 1] = qb_base[(n + 1) * 128];
+                    const bf16x8 qb = __builtin_bit_cast(bf16x8, qraw[n & 1]);
+#pragma unroll
+                    for (int m = 0; m < kMT; ++m)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[m], qb, acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+        epilogue(ti);
+    }
+}
+
+// ------------------------------------------------------------------ threshold update + compaction
+// eps such that l = u - 2*eps <= s <= u for the entry's (query,row); mirrors the scan epilogue.
+__device__ __forceinline__ float entry_eps(int space, float e1, float sq, float nr) {
+    if (space == kSpaceCosine) return e1 + 2.0f * kSlack;
+    if (space == kSpaceIp) return (e1 + kSlack) * nr;
+    return sq * (e1 + kSlack) * nr + kSlack * nr * nr;
+}
+
+__device__ __forceinline__ uint32_t float_order_key(float f) {  // monotone float -> uint
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+// One block per query.  thr[q] = max(thr[q], k-th largest lower bound); entries with u < thr dropped.
+constexpr int kUpdThreads = 1024;
+constexpr int kUpdWaves = kUpdThreads / 64;
+__global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const FilterArgs a, const int32_t k, const float e1) {
+    __shared__ uint32_t s_count[kUpdWaves];
+    __shared__ uint32_t s_scan[kUpdWaves + 1];
+    const int q = blockIdx.x;
+    if (q >= a.nq || a.overflow[q]) return;
+    const uint32_t cnt = a.cnt[q];
+    if (cnt > (uint32_t)kCandCap) {  // cannot happen without the flag, but never index past the list
+        if (threadIdx.x == 0) a.overflow[q] = 1u;
+        return;
+    }
+    constexpr int kPer = kCandCap / kUpdThreads;  // 8 entries per thread
+    CandEntry* list = a.cand + (int64_t)q * kCandCap;
+    const float sq = a.qscale[q];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float u[kPer];
+    int32_t row[kPer];
+    uint32_t key[kPer];  // order key of the lower bound; 0 = absent
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const uint32_t idx = threadIdx.x + i * kUpdThreads;
+        key[i] = 0;
+        u[i] = 0.f;
+        row[i] = 0;
+        if (idx < cnt) {
+            const CandEntry e = list[idx];
+            u[i] = e.u;
+            row[i] = e.row;
+            const float eps = entry_eps(a.space, e1, sq, a.rn[e.row]);
+            float l = e.u - 2.0f * eps;
+            l -= kSlack * (__builtin_fabsf(e.u) + eps);  // rounding of the line above
+            key[i] = float_order_key(l);
+            if (key[i] == 0) key[i] = 1;
+        }
+    }
+    float thr = a.thr[q];
+    if (cnt >= (uint32_t)k) {
+        // largest key value T such that at least k entries have key >= T (bitwise bisection)
+        uint32_t T = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t trial = T | (1u << bit);
+            uint32_t c = 0;
+#pragma unroll
+            for (int i = 0; i < kPer; ++i) c += key[i] >= trial ? 1u : 0u;
+            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+            __syncthreads();
+            if (lane == 0) s_count[wave] = c;
+            __syncthreads();
+            uint32_t tot = 0;
+#pragma unroll
+            for (int w = 0; w < kUpdWaves; ++w) tot += s_count[w];
+            if (tot >= (uint32_t)k) T = trial;
+        }
+        // invert the order key
+        const uint32_t b = (T & 0x80000000u) ? (T & 0x7fffffffu) : ~T;
+        const float lk = __uint_as_float(b);
+        if (lk > thr) thr = lk;
+    }
+    // compaction: keep u >= thr, stable order not required
+    uint32_t keep = 0;
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) keep += (key[i] != 0 && u[i] >= thr) ? 1u : 0u;
+    uint32_t incl = keep;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    __syncthreads();
+    if (lane == 63) s_scan[wave + 1] = incl;
+    if (threadIdx.x == 0) s_scan[0] = 0;
+    __syncthreads();
+    uint32_t wave_base = 0;
+    for (int w = 0; w < wave; ++w) wave_base += s_scan[w + 1];
+    uint32_t new_cnt = 0;
+    for (int w = 0; w < kUpdWaves; ++w) new_cnt += s_scan[w + 1];
+    uint32_t pos = wave_base + incl - keep;
+    __syncthreads();  // every entry has been read into registers; safe to overwrite the list
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        if (key[i] != 0 && u[i] >= thr) {
+            CandEntry e;
+            e.u = u[i];
+            e.row = row[i];
+            list[pos++] = e;
+        }
+    }
+    if (threadIdx.x == 0) {
+        a.thr[q] = thr;
+        a.cnt[q] = new_cnt;
+    }
+}
+
+// ------------------------------------------------------------------ exact rescoring
+// One block per query: the surviving rows are scored by the exact-scan arithmetic
+// (accumulate_rows, 16 gathered rows per wave step) and ranked (distance, label).
+template <int SPACE>
+__global__ __launch_bounds__(256) void filter_rescore_kernel(const FilterArgs a, const int32_t k, const int32_t q0,
+                                                             int64_t* out_labels, float* out_dist,
+                                                             int32_t* out_counts, double* out_d64,
+                                                             unsigned long long* rescored) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ld = a.ld;
+    double* qs = reinterpret_cast<double*>(smem);                         // [ld]
+    double(*sd)[64] = reinterpret_cast<double(*)[64]>(qs + ld);          // [4][64]
+    int32_t(*sl)[64] = reinterpret_cast<int32_t(*)[64]>(qs + ld + 256);  // [4][64]
+    const int q = blockIdx.x;
+    if (q >= a.nq || a.overflow[q]) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    for (int c = threadIdx.x; c < ld; c += 256) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
+    __syncthreads();
+    const double qinv = a.qaux[q];
+    const uint32_t cnt = min(a.cnt[q], (uint32_t)kCandCap);
+    const CandEntry* list = a.cand + (int64_t)q * kCandCap;
+    WaveTopK top;
+    top.init();
+    for (uint32_t i0 = wave * 16; i0 < cnt; i0 += 64) {
+        const uint32_t idx = i0 + r;
+        const bool have = idx < cnt;
+        const int32_t row = have ? list[idx].row : 0;
+        const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 4 + g * 64};
+        double acc[1][1], nx[1];
+        accumulate_rows<SPACE, 1, 1>(base, qs, ld, g, acc, nx);
+        const double dist = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
+        bool live = have && lane < 16;
+        if (live) {
+            const float nrm = a.rn[row];
+            live = nrm == nrm;
+        }
+        top.offer(live, dist, row, k, lane);
+    }
+    sd[wave][lane] = top.d;
+    sl[wave][lane] = top.l;
+    __syncthreads();
+    if (wave != 0) return;
+    WaveTopK f;
+    f.init();
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) f.offer(lane < k && sl[w2][lane] != kNoLabel, sd[w2][lane], sl[w2][lane], k, lane);
+    const bool valid = lane < k && f.l != kNoLabel;
+    const int64_t o = (int64_t)(q0 + q) * k + lane;
+    if (lane < k) {
+        out_labels[o] = valid ? (int64_t)f.l : -1;
+        out_dist[o] = valid ? (float)f.d : __builtin_inff();
+        if (out_d64) out_d64[o] = valid ? f.d : __builtin_inf();
+    }
+    const int n_valid = __popcll(__ballot(valid));
+    if (lane == 0) {
+        out_counts[q0 + q] = n_valid;
+        if (rescored) atomicAdd(rescored, (unsigned long long)cnt);
+    }
+}
+
+// Range variant: exact distance of every candidate, keep dist <= radius, bitonic sort by
+// (distance, label) in LDS, emit the nearest `capacity`.
+struct RangeHit {
+    double d;
+    int32_t l;
+    int32_t pad;
+};
+
+template <int SPACE>
+__global__ __launch_bounds__(256) void range_rescore_kernel(const FilterArgs a, const float radius, const int32_t q0,
+                                                            const int64_t capacity, int64_t* out_labels,
+                                                            float* out_dist, int64_t* out_counts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    RangeHit* hits = reinterpret_cast<RangeHit*>(smem);                               // [kCandCap]
+    double* qs = reinterpret_cast<double*>(smem + (size_t)kCandCap * sizeof(RangeHit));  // [ld]
+    const int ld = a.ld;
+    uint32_t& s_n = *reinterpret_cast<uint32_t*>(qs + ld);
+    const int q = blockIdx.x;
+    if (q >= a.nq || a.overflow[q]) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    for (int c = threadIdx.x; c < ld; c += 256) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const double qinv = a.qaux[q];
+    const double rad = (double)radius;
+    const uint32_t cnt = min(a.cnt[q], (uint32_t)kCandCap);
+    const CandEntry* list = a.cand + (int64_t)q * kCandCap;
+    for (uint32_t i0 = wave * 16; i0 < cnt; i0 += 64) {
+        const uint32_t idx = i0 + r;
+        const bool have = idx < cnt;
+        const int32_t row = have ? list[idx].row : 0;
+        const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 4 + g * 64};
+        double acc[1][1], nx[1];
+        accumulate_rows<SPACE, 1, 1>(base, qs, ld, g, acc, nx);
+        const double dist = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
+        bool hit = have && lane < 16 && dist <= rad;
+        if (hit) {
+            const float nrm = a.rn[row];
+            hit = nrm == nrm;
+        }
+        if (hit) {
+            const uint32_t slot = atomicAdd(&s_n, 1u);
+            hits[slot].d = dist;
+            hits[slot].l = row;
+        }
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (uint32_t i = n + threadIdx.x; i < np2; i += 256) {
+        hits[i].d = __builtin_inf();
+        hits[i].l = kNoLabel;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= np2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (np2 >> 1); t += 256) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const RangeHit x = hits[lo], y = hits[hi];
+                const bool x_after_y = entry_less(y.d, y.l, x.d, x.l);
+                if (x_after_y == up) {
+                    hits[lo] = y;
+                    hits[hi] = x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t emit = n < (uint64_t)capacity ? n : (uint32_t)capacity;
+    for (uint32_t i = threadIdx.x; i < emit; i += 256) {
+        out_labels[(int64_t)(q0 + q) * capacity + i] = hits[i].l;
+        out_dist[(int64_t)(q0 + q) * capacity + i] = (float)hits[i].d;
+    }
+    if (threadIdx.x == 0) out_counts[q0 + q] = n;
+}
+
+// ------------------------------------------------------------------ launchers
+hipError_t launch_filter_prep(const FilterArgs& a, hipStream_t s) {
+    const int nkc = a.ld / kFilterChunkK;
+    filter_prep_kernel<<<nkc * 16, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_seed_thr(const FilterArgs& a, const double* seed_d64, int32_t k, hipStream_t s) {
+    filter_seed_thr_kernel<<<1, 256, 0, s>>>(a, seed_d64, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_range_thr(const FilterArgs& a, float radius, hipStream_t s) {
+    filter_range_thr_kernel<<<1, 256, 0, s>>>(a, radius);
+    return hipGetLastError();
+}
+
+template <int SPACE, int R>
+static hipError_t launch_scan_one(const FilterArgs& a, int64_t tile_begin, int64_t tile_end, int grid, size_t lds,
+                                  float e1, hipStream_t s) {
+    auto kern = filter_scan_kernel<SPACE, R>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    kern<<<grid, kFilterThreads, lds, s>>>(a, tile_begin, tile_end, e1);
+    return hipGetLastError();
+}
+
+template <int SPACE>
+static hipError_t launch_scan_space(const FilterArgs& a, int64_t tile_begin, int64_t tile_end, int grid, size_t lds,
+                                    float e1, hipStream_t s) {
+    // steps per tile = 2 * (ld / 64) must be a multiple of lcm(R, 2)
+    const int nkc = a.ld / kFilterChunkK;
+    if (nkc % 3 == 0) return launch_scan_one<SPACE, 3>(a, tile_begin, tile_end, grid, lds, e1, s);
+    if (nkc % 2 == 0) return launch_scan_one<SPACE, 4>(a, tile_begin, tile_end, grid, lds, e1, s);
+    return launch_scan_one<SPACE, 2>(a, tile_begin, tile_end, grid, lds, e1, s);
+}
+
+hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
+    const int64_t tile_begin = row_begin / kFilterTileRows;
+    const int64_t tile_end = (row_end + kFilterTileRows - 1) / kFilterTileRows;
+    if (tile_end <= tile_begin) return hipSuccess;
+    const size_t lds = 2 * kChunkVec * sizeof(uint4) + 2 * kFilterQueries * sizeof(float) +
+                       (size_t)kFilterWaves * 16 * 64 * sizeof(float);
+    const int64_t ntiles = tile_end - tile_begin;
+    const int grid = (int)(ntiles < 256 ? ntiles : 256);
+    const float e1 = filter_e1(a.ld);
+    switch (a.space) {
+        case kSpaceL2: return launch_scan_space<kSpaceL2>(a, tile_begin, tile_end, grid, lds, e1, s);
+        case kSpaceCosine: return launch_scan_space<kSpaceCosine>(a, tile_begin, tile_end, grid, lds, e1, s);
+        default: return launch_scan_space<kSpaceIp>(a, tile_begin, tile_end, grid, lds, e1, s);
+    }
+}
+
+hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s) {
+    filter_update_kernel<<<a.nq, kUpdThreads, 0, s>>>(a, k, filter_e1(a.ld));
+    return hipGetLastError();
+}
+
+hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
+                                 int32_t* out_counts, double* out_d64, unsigned long long* rescored, hipStream_t s) {
+    const size_t lds = (size_t)a.ld * sizeof(double) + 256 * sizeof(double) + 256 * sizeof(int32_t);
+    switch (a.space) {
+        case kSpaceL2:
+            filter_rescore_kernel<kSpaceL2><<<a.nq, 256, lds, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored);
+            break;
+        case kSpaceCosine:
+            filter_rescore_kernel<kSpaceCosine><<<a.nq, 256, lds, s>>>(a, k, q0, out_labels, out_dist, out_counts,
+                                                                      out_d64, rescored);
+            break;
+        default:
+            filter_rescore_kernel<kSpaceIp><<<a.nq, 256, lds, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored);
+            break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, int64_t capacity, int64_t* out_labels,
+                                float* out_dist, int64_t* out_counts, hipStream_t s) {
+    const size_t lds = (size_t)kCandCap * sizeof(RangeHit) + (size_t)a.ld * sizeof(double) + 16;
+    hipError_t e = hipSuccess;
+#define MLVDB_LAUNCH_RANGE(SP)                                                                                        \
+    do {                                                                                                              \
+        auto kern = range_rescore_kernel<SP>;                                                                         \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                (int)lds);                                                                            \
+        if (e == hipSuccess) kern<<<a.nq, 256, lds, s>>>(a, radius, q0, capacity, out_labels, out_dist, out_counts);  \
+    } while (0)
+    switch (a.space) {
+        case kSpaceL2: MLVDB_LAUNCH_RANGE(kSpaceL2); break;
+        case kSpaceCosine: MLVDB_LAUNCH_RANGE(kSpaceCosine); break;
+        default: MLVDB_LAUNCH_RANGE(kSpaceIp); break;
+    }
+#undef MLVDB_LAUNCH_RANGE
+    if (e != hipSuccess) return e;
+    return hipGetLastError();
+}
+
+}  // namespace mlvdb

@@ -1,0 +1,145 @@
+// Corpus maintenance kernels: row-major <-> panel layout, row norms, tombstones, query prep.
+// Reference roles: hnswlib add_items / mark_deleted as called from
+// src/mlvectordb/implementations/index.py:65,80,158 (the index copies and owns the rows).
+#include "internal.h"
+
+namespace mlvdb {
+
+// One thread per (row, 4-column group) of the padded row.
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ stage, float* __restrict__ X,
+                                                           int64_t first_row, int64_t n, int32_t dim, int32_t ld) {
+    const int32_t ngrp = ld >> 2;
+    const int64_t total = n * ngrp;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / ngrp;
+        const int32_t col = (int32_t)(idx - r * ngrp) << 2;
+        const float* src = stage + r * dim + col;
+        float4 v;
+        if ((dim & 3) == 0) {
+            v = col < dim ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            v.x = col + 0 < dim ? src[0] : 0.f;
+            v.y = col + 1 < dim ? src[1] : 0.f;
+            v.z = col + 2 < dim ? src[2] : 0.f;
+            v.w = col + 3 < dim ? src[3] : 0.f;
+        }
+        *reinterpret_cast<float4*>(X + layout_offset(first_row + r, col, ld)) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ X, float* __restrict__ out,
+                                                          int64_t first_row, int64_t n, int32_t dim, int32_t ld) {
+    const int64_t total = n * dim;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / dim;
+        const int32_t col = (int32_t)(idx - r * dim);
+        out[idx] = X[layout_offset(first_row + r, col, ld)];
+    }
+}
+
+// One wave per panel; lane 16*g + r sums the squares of row r over its column slices.
+__global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ X, float* __restrict__ rn,
+                                                        int64_t first_row, int64_t n, int32_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t first_panel = first_row >> 4;
+    const int64_t last_panel = (first_row + n - 1) >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int nkb = ld >> 4;
+    for (int64_t panel = first_panel + wave; panel <= last_panel; panel += nwaves) {
+        const float* base = X + panel * (int64_t)(kPanelRows * ld) + lane * 4;
+        double s = 0.0;
+        for (int kb = 0; kb < nkb; ++kb) {
+            const float4 x = *reinterpret_cast<const float4*>(base + (int64_t)kb * kGroupFloats);
+            s = __builtin_fma((double)x.x, (double)x.x, s);
+            s = __builtin_fma((double)x.y, (double)x.y, s);
+            s = __builtin_fma((double)x.z, (double)x.z, s);
+            s = __builtin_fma((double)x.w, (double)x.w, s);
+        }
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        const int64_t row = panel * kPanelRows + (lane & 15);
+        if (lane < 16 && row >= first_row && row < first_row + n) rn[row] = (float)__builtin_sqrt(s);
+    }
+}
+
+__global__ __launch_bounds__(256) void tombstone_kernel(float* __restrict__ rn, const int64_t* __restrict__ labels,
+                                                        int64_t n, int64_t total, unsigned long long* changed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t label = labels[i];
+    if (label < 0 || label >= total) return;
+    // exchange so that a label listed twice in one call is counted once
+    const unsigned int old = atomicExch(reinterpret_cast<unsigned int*>(rn) + label, 0x7fc00000u);
+    const float oldf = __uint_as_float(old);
+    if (oldf == oldf) atomicAdd(changed, 1ull);
+}
+
+// One block per query: zero-padded copy + fp64 norm.
+__global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict__ queries, int32_t dim, int32_t ld,
+                                                         int32_t space, float* __restrict__ Qpad,
+                                                         double* __restrict__ qaux) {
+    __shared__ double red[4];
+    const int q = blockIdx.x;
+    const float* src = queries + (int64_t)q * dim;
+    float* dst = Qpad + (int64_t)q * ld;
+    double s = 0.0;
+    for (int c = threadIdx.x; c < ld; c += blockDim.x) {
+        const float v = c < dim ? src[c] : 0.f;
+        dst[c] = v;
+        s = __builtin_fma((double)v, (double)v, s);
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double nrm = __builtin_sqrt((red[0] + red[1]) + (red[2] + red[3]));
+        qaux[q] = space == kSpaceCosine ? 1.0 / (nrm + 1e-30) : nrm;
+    }
+}
+
+static inline int grid_for(int64_t work, int threads, int cap = 256 * 8) {
+    int64_t g = (work + threads - 1) / threads;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+hipError_t launch_scatter_rows(const float* stage, float* X, int64_t first_row, int64_t n, int32_t dim, int32_t ld,
+                               hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    scatter_rows_kernel<<<grid_for(n * (ld >> 2), 256), 256, 0, s>>>(stage, X, first_row, n, dim, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows(const float* X, float* out, int64_t first_row, int64_t n, int32_t dim, int32_t ld,
+                              hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    gather_rows_kernel<<<grid_for(n * dim, 256), 256, 0, s>>>(X, out, first_row, n, dim, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_norms(const float* X, float* rn, int64_t first_row, int64_t n, int32_t ld, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    const int64_t panels = ((first_row + n - 1) >> 4) - (first_row >> 4) + 1;
+    row_norms_kernel<<<grid_for(panels, 4), 256, 0, s>>>(X, rn, first_row, n, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_tombstone(float* rn, const int64_t* labels, int64_t n, int64_t total, unsigned long long* changed,
+                            hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    tombstone_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(rn, labels, n, total, changed);
+    return hipGetLastError();
+}
+
+hipError_t launch_query_prep(const float* queries, int32_t nq, int32_t dim, int32_t ld, int32_t space, float* Qpad,
+                             double* qaux, hipStream_t s) {
+    if (nq <= 0) return hipSuccess;
+    query_prep_kernel<<<nq, 256, 0, s>>>(queries, dim, ld, space, Qpad, qaux);
+    return hipGetLastError();
+}
+
+}  // namespace mlvdb

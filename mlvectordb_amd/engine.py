@@ -129,11 +129,15 @@ class HipScanEngine:
         return labels, dist, counts
 
     def search_device(self, q_ptr: int, nq: int, k: int, labels_ptr: int, dist_ptr: int, counts_ptr: int,
-                      stream: int = 0) -> None:
-        """Device-pointer search; results are complete when ``stream`` is."""
+                      dist64_ptr: int = 0, stream: int = 0) -> None:
+        """Device-pointer search; results are complete when ``stream`` is.
+
+        ``dist64_ptr`` (optional) receives the unrounded fp64 distances, which is what a
+        multi-shard merge must rank on.
+        """
         self._check(self._lib.mlvdb_search_batch_device(
             self._h, C.c_void_p(q_ptr), int(nq), int(k), C.c_void_p(labels_ptr), C.c_void_p(dist_ptr),
-            C.c_void_p(counts_ptr), C.c_void_p(stream)), "search_batch_device")
+            C.c_void_p(counts_ptr), C.c_void_p(dist64_ptr or None), C.c_void_p(stream or None)), "search_batch_device")
 
     def range(self, queries: np.ndarray, radius: float, capacity: int):
         queries = np.ascontiguousarray(queries, dtype=np.float32)

@@ -1,0 +1,212 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on the same seeded inputs.
+
+Bar (north star): ids bit-exact, scores within 1e-5.  Sizes are chosen so the NumPy oracle
+finishes in seconds; BASELINE-size behaviour is covered by properties in test_gpu_fullsize.py.
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from mlvectordb_amd.engine import HipScanEngine
+from oracle import exact_scan
+from tests.helpers import SCORE_ATOL, assert_knn_matches, deleted_mask, make_case, oracle_knn
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = Path(__file__).parent / "golden"
+
+
+def run_hip(rows, qs, k, space, strategy, deleted=None, append_chunks=1):
+    eng = HipScanEngine(rows.shape[1], space, device=0, strategy=strategy)
+    try:
+        for part in np.array_split(rows, append_chunks):
+            if len(part):
+                eng.append(part)
+        if deleted is not None and deleted.any():
+            changed = eng.tombstone(np.nonzero(deleted)[0])
+            assert changed == int(deleted.sum())
+            assert eng.tombstone(np.nonzero(deleted)[0][:3]) == 0  # already deleted: no state change
+        assert eng.counts() == (rows.shape[0], int(deleted.sum()) if deleted is not None else 0)
+        return eng.search(qs, k), eng.last_stats()
+    finally:
+        eng.close()
+
+
+EXACT_CASES = [
+    # seed, n, d, nq, k, deleted_frac, dup
+    (1, 1, 3, 1, 1, 0.0, False),
+    (2, 15, 3, 2, 5, 0.0, False),
+    (3, 17, 10, 3, 5, 0.2, True),
+    (4, 100, 16, 5, 5, 0.1, True),
+    (5, 1000, 16, 8, 5, 0.1, True),
+    (6, 1037, 100, 9, 7, 0.0, True),
+    (7, 4096, 128, 16, 5, 0.1, True),
+    (8, 5000, 130, 4, 64, 0.3, False),
+    (9, 2048, 768, 8, 10, 0.1, True),
+    (10, 30000, 64, 2, 10, 0.0, False),
+    (11, 20000, 256, 1, 1, 0.5, False),
+]
+
+
+@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+@pytest.mark.parametrize("case", EXACT_CASES, ids=lambda c: f"n{c[1]}d{c[2]}q{c[3]}k{c[4]}")
+def test_exact_scan_matches_oracle(case, space):
+    seed, n, d, nq, k, frac, dup = case
+    rows, qs = make_case(seed, n, d, nq, dup=dup)
+    deleted = deleted_mask(seed, n, frac)
+    got, stats = run_hip(rows, qs, k, space, "exact", deleted, append_chunks=3 if n > 50 else 1)
+    assert stats["strategy_used"] == 1
+    assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"exact/{space}/n{n}d{d}")
+
+
+FILTER_CASES = [
+    # seed, n, d, nq, k, deleted_frac, dup, clustered
+    (21, 500, 64, 3, 5, 0.0, True, False),      # far fewer rows than one tile
+    (22, 3000, 192, 24, 10, 0.05, True, False),  # 3 chunks: the R=3 kernel
+    (23, 4096, 128, 16, 5, 0.1, True, False),    # 2 chunks: the R=4 kernel
+    (24, 2500, 64, 40, 10, 0.1, False, False),   # 1 chunk: the R=2 kernel
+    (25, 10000, 128, 256, 5, 0.1, True, False),  # a full 256-query pass
+    (26, 9000, 768, 64, 10, 0.0, True, False),   # the benchmark dimension
+    (27, 70000, 64, 300, 10, 0.02, False, False),  # two passes (256 + 44), two scan rounds
+    (28, 6000, 256, 32, 64, 0.0, False, False),  # k = MAX_TOPK
+    (29, 5000, 128, 16, 10, 0.0, True, True),    # near-ties everywhere: candidate lists overflow -> fallback
+    (30, 3000, 320, 8, 3, 0.6, False, False),    # 5 chunks (R=2), most rows tombstoned
+]
+
+
+@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+@pytest.mark.parametrize("case", FILTER_CASES, ids=lambda c: f"n{c[1]}d{c[2]}q{c[3]}k{c[4]}")
+def test_filter_path_matches_oracle(case, space):
+    seed, n, d, nq, k, frac, dup, clustered = case
+    rows, qs = make_case(seed, n, d, nq, dup=dup, clustered=clustered)
+    deleted = deleted_mask(seed, n, frac)
+    got, stats = run_hip(rows, qs, k, space, "filter", deleted, append_chunks=2)
+    assert stats["strategy_used"] == 2
+    assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"filter/{space}/n{n}d{d}")
+
+
+def test_filter_bound_prunes_on_random_data():
+    """On random-normal data the bf16 bounds must discard almost everything (else the path is pointless)."""
+    rows, qs = make_case(31, 60000, 128, 64)
+    got, stats = run_hip(rows, qs, 10, "cosine", "filter")
+    assert_knn_matches(got, oracle_knn(qs, rows, 10, "cosine"), "filter/prune")
+    assert stats["fallback_queries"] == 0
+    assert stats["candidates_rescored"] < 64 * 60000 * 0.02
+
+
+def test_zero_rows_zero_queries_and_scale_extremes():
+    rng = np.random.default_rng(41)
+    rows = rng.standard_normal((3000, 64)).astype(np.float32)
+    rows[5] = 0.0          # hnswlib: zero row normalises to zero -> cosine distance 1
+    rows[6] *= 1e-18       # tiny but non-zero norm
+    rows[7] *= 1e12        # huge norm
+    qs = rng.standard_normal((12, 64)).astype(np.float32)
+    qs[1] = 0.0
+    qs[2] *= 1e-15
+    for space in ("cosine", "l2", "ip"):
+        for strategy in ("exact", "filter"):
+            got, _ = run_hip(rows, qs, 8, space, strategy)
+            assert_knn_matches(got, oracle_knn(qs, rows, 8, space), f"{strategy}/{space}/extremes")
+
+
+@pytest.mark.parametrize("name", sorted(p.stem for p in GOLDEN.glob("knn_*.npz")))
+@pytest.mark.parametrize("strategy", ["exact", "filter"])
+def test_committed_golden_vectors(name, strategy):
+    from tests.golden.make_golden import regenerate_inputs
+
+    g = np.load(GOLDEN / f"{name}.npz")
+    meta = json.loads(str(g["meta"]))
+    if strategy == "filter" and meta["d"] % 64:
+        pytest.skip("filter path needs dim % 64 == 0; AUTO routes such corpora to the exact scan")
+    rows, qs, deleted = regenerate_inputs(meta)
+    (labels, dist, counts), _ = run_hip(rows, qs, meta["k"], meta["space"], strategy, deleted)
+    assert np.array_equal(labels, g["labels"]) and np.array_equal(counts, g["counts"])
+    assert np.abs(dist - g["dist"]).max() <= SCORE_ATOL
+
+
+def test_k_larger_than_live_rows_pads():
+    rows, qs = make_case(51, 6, 64, 2)
+    got, _ = run_hip(rows, qs, 10, "l2", "exact", deleted_mask(51, 6, 0.4))
+    assert_knn_matches(got, oracle_knn(qs, rows, 10, "l2", deleted_mask(51, 6, 0.4)), "pad")
+
+
+def test_get_rows_roundtrip_and_reset():
+    rng = np.random.default_rng(61)
+    rows = rng.standard_normal((777, 50)).astype(np.float32)
+    eng = HipScanEngine(50, "l2", device=0)
+    try:
+        eng.append(rows[:300])
+        eng.append(rows[300:])
+        assert np.array_equal(eng.get_rows(0, 777), rows)
+        assert np.array_equal(eng.get_rows(290, 30), rows[290:320])
+        eng.reset("cosine")
+        assert eng.counts() == (0, 0)
+        labels, dist, counts = eng.search(rows[:2], 3)
+        assert counts.tolist() == [0, 0] and (labels == -1).all()
+        eng.append(rows[:10])
+        got = eng.search(rows[:2], 3)
+        assert_knn_matches(got, oracle_knn(rows[:2], rows[:10], 3, "cosine"), "after-reset")
+    finally:
+        eng.close()
+
+
+def test_device_pointer_entry_and_fp64_distances():
+    import torch
+
+    rows, qs = make_case(71, 5000, 128, 32)
+    eng = HipScanEngine(128, "cosine", device=0, strategy="filter")
+    try:
+        t_rows = torch.from_numpy(rows).cuda()
+        eng.append_device(t_rows.data_ptr(), rows.shape[0])
+        t_q = torch.from_numpy(qs).cuda()
+        k = 10
+        lab = torch.empty((32, k), dtype=torch.int64, device="cuda")
+        dist = torch.empty((32, k), dtype=torch.float32, device="cuda")
+        cnt = torch.empty(32, dtype=torch.int32, device="cuda")
+        d64 = torch.empty((32, k), dtype=torch.float64, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        eng.search_device(t_q.data_ptr(), 32, k, lab.data_ptr(), dist.data_ptr(), cnt.data_ptr(), d64.data_ptr(), stream)
+        torch.cuda.synchronize()
+        want = oracle_knn(qs, rows, k, "cosine")
+        assert_knn_matches((lab.cpu().numpy(), dist.cpu().numpy(), cnt.cpu().numpy()), want, "device-entry")
+        want64 = np.take_along_axis(exact_scan.exact_distances(qs, rows, "cosine"), want[0], axis=1)
+        assert np.abs(d64.cpu().numpy() - want64).max() < 1e-12
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+@pytest.mark.parametrize("strategy,n,d", [("exact", 2000, 20), ("exact", 3000, 128), ("filter", 40000, 128), ("filter", 5000, 192)])
+def test_range_query_matches_oracle(space, strategy, n, d):
+    rows, qs = make_case(81, n, d, 20, dup=True)
+    deleted = deleted_mask(81, n, 0.1)
+    dmat = exact_scan.exact_distances(qs, rows[~deleted], space)
+    radius = float(np.float32(np.sort(dmat, axis=1)[:, 9].mean()))  # ~10 hits per query
+    eng = HipScanEngine(d, space, device=0, strategy=strategy)
+    try:
+        eng.append(rows)
+        eng.tombstone(np.nonzero(deleted)[0])
+        got = eng.range(qs, radius, 64)
+    finally:
+        eng.close()
+    want = exact_scan.range_query(qs, rows, radius, space, deleted=deleted)
+    assert sum(len(w[0]) for w in want) > 0
+    for i, ((gl, gd), (wl, wd)) in enumerate(zip(got, want)):
+        assert np.array_equal(gl, wl), f"range {space}/{strategy} query {i}: {gl} vs {wl}"
+        assert np.abs(gd - wd).max(initial=0.0) <= SCORE_ATOL
+
+
+def test_range_capacity_overflow_is_reported_then_resolved():
+    rows, qs = make_case(91, 3000, 64, 4)
+    eng = HipScanEngine(64, "l2", device=0)
+    try:
+        eng.append(rows)
+        radius = float(np.sort(exact_scan.exact_distances(qs, rows, "l2"), axis=1)[:, 49].max())
+        got = eng.range(qs, radius, 8)  # capacity 8 < hits: the engine retries with the reported counts
+        want = exact_scan.range_query(qs, rows, radius, "l2")
+        for (gl, _), (wl, _) in zip(got, want):
+            assert np.array_equal(gl, wl) and len(gl) >= 50
+    finally:
+        eng.close()

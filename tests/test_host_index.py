@@ -1,0 +1,150 @@
+"""Host-side logic of Index / QueryProcessor with the oracle engine injected (CPU only).
+
+Covers what the reference's Python owns (index.py:50-165, query_processor.py:26-62) and the quirks
+recorded in SURVEY.md section 3.5.
+"""
+import numpy as np
+import pytest
+
+from mlvectordb_amd import Index, InMemoryStorage, QueryProcessor, Vector, VectorDTO
+from mlvectordb_amd.index import SearchResult
+from oracle.engine import OracleScanEngine
+
+
+def idx(space="l2", **kw):
+    return Index(space=space, engine_factory=OracleScanEngine, **kw)
+
+
+def vecs(n, d=8, seed=0):
+    rng = np.random.default_rng(seed)
+    return [Vector(values=rng.standard_normal(d).tolist(), metadata={"i": i}) for i in range(n)]
+
+
+def test_constructor_signature_matches_reference():
+    i = Index.__new__(Index)
+    Index.__init__(i, "cosine", 200, 16, 0.2, engine_factory=OracleScanEngine)  # positional, as index.py:18
+    assert i._space == "cosine" and i._M == 16 and i._ef_construction == 200
+
+
+def test_empty_and_unknown_namespace_return_empty_lists():
+    i = idx()
+    q = VectorDTO(values=[0.0] * 8, metadata={})
+    assert i.search(q, 3, "nope", "l2") == []
+    i.add([], "ns")  # no-op, does not create the namespace (index.py:52-53)
+    assert i.search(q, 3, "ns", "l2") == []
+    v = vecs(2)
+    i.add(v, "ns")
+    i.remove([x.id for x in v], "ns")
+    assert i.search(q, 3, "ns", "l2") == []  # active count 0 (index.py:103-105)
+
+
+def test_metric_argument_only_flips_the_score_q1_q2():
+    v = vecs(20)
+    i = idx("l2")
+    i.add(v, "ns")
+    q = VectorDTO(values=v[3].values, metadata={})
+    as_l2 = i.search(q, 5, "ns", "l2")
+    as_cos = i.search(q, 5, "ns", "cosine")
+    assert [r.vector_id for r in as_l2] == [r.vector_id for r in as_cos]  # same space searched
+    assert [r.score for r in as_cos] == [1 - r.score for r in as_l2]  # only the flip differs
+
+
+def test_query_coercion_and_wrong_dim_query_returns_empty():
+    v = vecs(10)
+    i = idx()
+    i.add(v, "ns")
+    as_list = i.search(VectorDTO(values=list(map(float, v[0].values)), metadata={}), 1, "ns", "l2")
+    as_f64 = i.search(VectorDTO(values=v[0].values.astype(np.float64), metadata={}), 1, "ns", "l2")
+    assert as_list[0].vector_id == as_f64[0].vector_id == v[0].id
+    assert i.search(VectorDTO(values=[1.0, 2.0], metadata={}), 1, "ns", "l2") == []  # swallowed RuntimeError
+
+
+def test_wrong_dim_rows_raise_runtime_error():
+    i = idx()
+    i.add(vecs(3, d=8), "ns")
+    with pytest.raises(RuntimeError):
+        i.add(vecs(1, d=5), "ns")
+
+
+def test_labels_continue_and_are_never_reused_until_rebuild():
+    i = idx()
+    a, b = vecs(5, seed=1), vecs(5, seed=2)
+    i.add(a, "ns")
+    i.remove([a[0].id], "ns")
+    i.add(b, "ns")
+    ns = i._ns["ns"]
+    assert ns.uuid_to_label[b[0].id] == 5 and ns.total == 10 and ns.deleted == 1
+
+
+def test_rebuild_threshold_and_flag():
+    i = idx(rebuild_threshold=0.2)
+    v = vecs(10)
+    i.add(v, "ns")
+    i.remove([v[0].id], "ns")
+    assert not i.is_rebuild_required("ns")  # 1/10 < 0.2
+    i.remove([v[1].id, v[1].id, v[2].id], "ns")  # duplicates / repeats are ignored after the first
+    assert i.namespace_counts("ns") == (10, 3)
+    assert i.is_rebuild_required("ns")
+    assert not i.is_rebuild_required("other")
+
+
+def test_rebuild_replaces_everything_and_uses_metric_as_space():
+    i = idx("l2")
+    a, b = vecs(4, seed=1), vecs(4, seed=2)
+    i.add(a, "A")
+    i.add(b, "B")
+    i.rebuild({"A": a[:2]}, metric="cosine")
+    assert i.search(VectorDTO(values=b[0].values, metadata={}), 1, "B", "l2") == []  # B wiped (index.py:136-143)
+    assert i._ns["A"].engine.space == "cosine" and i._space == "l2"  # _space itself is untouched
+    assert i._ns["A"].uuid_to_label[a[1].id] == 1
+
+
+def test_query_processor_delete_rebuilds_all_namespaces_by_default_q4():
+    qp = QueryProcessor(InMemoryStorage(), idx("cosine"))
+    qp.upsert_many([VectorDTO([1, 0], {"l": "a1"}), VectorDTO([0, 1], {"l": "a2"})], namespace="A")
+    qp.upsert_many([VectorDTO([1, 1], {"l": "b1"})], namespace="B")
+    victim = qp.find_similar(VectorDTO([1, 0], {}), 1, namespace="A")[0]["id"]
+    qp.delete([victim], namespace="A")
+    assert len(qp.find_similar(VectorDTO([1, 1], {}), 1, namespace="B")) == 1  # divergence from the reference
+    qp2 = QueryProcessor(InMemoryStorage(), idx("cosine"), rebuild_scope="namespace")
+    qp2.upsert_many([VectorDTO([1, 0], {}), VectorDTO([0, 1], {})], namespace="A")
+    qp2.upsert_many([VectorDTO([1, 1], {})], namespace="B")
+    victim = qp2.find_similar(VectorDTO([1, 0], {}), 1, namespace="A")[0]["id"]
+    qp2.delete([victim], namespace="A")
+    assert qp2.find_similar(VectorDTO([1, 1], {}), 1, namespace="B") == []  # reference behaviour reproduced
+
+
+def test_search_many_equals_repeated_search_and_find_similar_many():
+    v = vecs(50, d=12)
+    i = idx("cosine")
+    i.add(v, "ns")
+    rng = np.random.default_rng(5)
+    qs = rng.standard_normal((7, 12)).astype(np.float32)
+    batched = i.search_many(qs, 4, "ns", "cosine")
+    single = [i.search(VectorDTO(values=q, metadata={}), 4, "ns", "cosine") for q in qs]
+    assert batched == single
+    assert all(isinstance(r, SearchResult) for hits in batched for r in hits)
+    qp = QueryProcessor(InMemoryStorage(), idx("cosine"))
+    qp.upsert_many([VectorDTO(values=x.values, metadata={"i": n}) for n, x in enumerate(v)])
+    many = qp.find_similar_many(qs, top_k=3)
+    one = [qp.find_similar(VectorDTO(values=q, metadata={}), top_k=3) for q in qs]
+    assert [[h["id"] for h in hits] for hits in many] == [[h["id"] for h in hits] for hits in one]
+
+
+def test_find_similar_drops_ids_missing_from_storage():
+    qp = QueryProcessor(InMemoryStorage(), idx("cosine"))
+    qp.upsert_many([VectorDTO([1, 0], {"l": "a"}), VectorDTO([0.9, 0.1], {"l": "b"})])
+    top = qp.find_similar(VectorDTO([1, 0], {}), 2)
+    qp._storage.delete(top[0]["id"], "default")  # storage and index now disagree
+    assert [h["metadata"]["l"] for h in qp.find_similar(VectorDTO([1, 0], {}), 2)] == ["b"]
+
+
+def test_range_search_and_euclidean_alias():
+    i = idx("euclidean")
+    v = [Vector(values=[0, 0]), Vector(values=[3, 4]), Vector(values=[6, 8])]
+    i.add(v, "ns")
+    hits = i.range_search(VectorDTO([0, 0], {}), 5.0, "ns", "euclidean")
+    assert [h.vector_id for h in hits] == [v[0].id, v[1].id]
+    assert [h.score for h in hits] == [0.0, 5.0]
+    assert [h.score for h in i.search(VectorDTO([0, 0], {}), 3, "ns", "euclidean")] == [0.0, 5.0, 10.0]
+    assert [h.score for h in i.search(VectorDTO([0, 0], {}), 3, "ns", "l2")] == [0.0, 25.0, 100.0]
