@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/sec of exact cosine kNN (k=10) over a row-sharded 768-d corpus.
+
+  python bench.py --gpus N --steps K --warmup W
+
+N=1 runs BASELINE.json configs[2] (10M x 768, batch 256, 1 x MI355X).  N>1 is launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: one process per
+GPU, every rank holds 10M rows (weak scaling; N=8 is configs[4], 80M rows, batch 1024), scans
+its shard for the whole query wave, and rank 0 merges the per-shard top-k on the host.
+
+A step = one query wave through the hot path with queries and corpus resident in HBM:
+query prep -> bf16-MFMA filter scan of the shard -> threshold updates -> exact fp64 rescoring
+(-> gather + host merge when N>1).  Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def log(msg: str) -> None:
+    print(f"[bench r{os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=0, help="queries per wave (default 256 at 1 GPU, 1024 beyond)")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--space", default="cosine")
+    ap.add_argument("--strategy", default="auto")
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config-2 (1M x 768, batch 1) side measurement")
+    ap.add_argument("--gen-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def main() -> None:
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from mlvectordb_amd import synth
+    from mlvectordb_amd.engine import HipScanEngine
+    from mlvectordb_amd.sharded import merge_topk
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    host_group = None
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        host_group = dist.new_group(backend="gloo")  # the per-shard candidates are merged on the host
+    dev = torch.device("cuda", local_rank)
+
+    n_local, d, k = args.rows_per_gpu, args.dim, args.k
+    batch = args.batch or (256 if world == 1 else 1024)
+    row0 = rank * n_local
+    threads = args.gen_threads or max(2, min(16, (os.cpu_count() or 8) // max(1, min(world, 8))))
+
+    # ---- shard: seeded N(0,1) rows, generated on the host in 1M-row chunks, appended to HBM
+    t0 = time.perf_counter()
+    eng = HipScanEngine(d, args.space, device=local_rank, capacity_hint=n_local, strategy=args.strategy)
+    sample_rows = None
+    for off, rows in synth.iter_corpus(row0, n_local, d, threads=threads):
+        eng.append(rows)
+        if rank == 0 and off == 0:
+            sample_rows = rows.copy()  # first 250k rows, reused for the parity gate
+    load_s = time.perf_counter() - t0
+    log(f"shard rows [{row0}, {row0 + n_local}) resident after {load_s:.1f} s ({threads} generator threads)")
+
+    q_host = synth.queries(batch, d)
+    q_dev = torch.from_numpy(q_host).to(dev)
+    lab = torch.empty((batch, k), dtype=torch.int64, device=dev)
+    dst = torch.empty((batch, k), dtype=torch.float32, device=dev)
+    cnt = torch.empty(batch, dtype=torch.int32, device=dev)
+    d64 = torch.empty((batch, k), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def local_wave():
+        eng.search_device(q_dev.data_ptr(), batch, k, lab.data_ptr(), dst.data_ptr(), cnt.data_ptr(),
+                          d64.data_ptr(), stream)
+
+    def step():
+        local_wave()
+        if world == 1:
+            return None
+        torch.cuda.current_stream().synchronize()
+        l_host = lab.cpu()
+        l_host = torch.where(l_host >= 0, l_host + row0, l_host)
+        d_host = d64.cpu()
+        if rank == 0:
+            gl = [torch.empty_like(l_host) for _ in range(world)]
+            gd = [torch.empty_like(d_host) for _ in range(world)]
+        else:
+            gl = gd = None
+        dist.gather(l_host, gl, dst=0, group=host_group)
+        dist.gather(d_host, gd, dst=0, group=host_group)
+        if rank == 0:
+            return merge_topk([t.numpy() for t in gl], [t.numpy() for t in gd], k)
+        return None
+
+    # ---- parity gate (untimed): ids must equal the exact fp64 GPU scan, and the oracle on a sample
+    verify = {}
+    local_wave()
+    torch.cuda.synchronize()
+    stats0 = eng.last_stats()
+    fast_ids = lab[:8].cpu().numpy().copy()
+    fast_dist = dst[:8].cpu().numpy().copy()
+    eng.set_strategy("exact")
+    ex_l, ex_d, _ = eng.search(q_host[:8], k)
+    eng.set_strategy(args.strategy)
+    verify["filter_equals_exact_scan_ids"] = bool(np.array_equal(fast_ids, ex_l))
+    verify["filter_equals_exact_scan_max_abs_err"] = float(np.abs(fast_dist - ex_d).max())
+    if rank == 0 and sample_rows is not None:
+        from oracle import exact_scan
+
+        small = HipScanEngine(d, args.space, device=local_rank, strategy="filter" if d % 64 == 0 else "exact")
+        small.append(sample_rows)
+        sl, sd, _ = small.search(q_host[:64], k)
+        small.close()
+        ol, od, _ = exact_scan.knn(q_host[:64], sample_rows, k, args.space)
+        verify["oracle_sample"] = f"{sample_rows.shape[0]} rows x 64 queries"
+        verify["oracle_ids_equal"] = bool(np.array_equal(sl, ol))
+        verify["oracle_max_abs_err"] = float(np.abs(sd - od).max())
+    if not verify["filter_equals_exact_scan_ids"] or verify.get("oracle_ids_equal") is False:
+        log(f"PARITY GATE FAILED: {verify}")
+
+    # ---- timed region
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    eng.set_profiling(True)  # HIP events on the launch stream around every scan-kernel launch
+    scan_ms, scan_launches, rows_scanned, rescored, fallbacks = 0.0, 0, 0, 0, 0
+    per_step = []
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        step()
+        torch.cuda.current_stream().synchronize()
+        per_step.append(time.perf_counter() - ts)
+        st = eng.last_stats()  # the call has already drained its stream; this only reads the events
+        scan_ms += st["scan_ms"]
+        scan_launches += st["scan_launches"]
+        rows_scanned += st["rows_scanned"]
+        rescored += st["candidates_rescored"]
+        fallbacks += st["fallback_queries"]
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    eng.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    shard_queries_per_s = world * batch * args.steps / elapsed  # one unit = one query against one 10M-row shard
+    # algorithmic bytes of one wave over one shard: corpus once + queries + results + row norms
+    passes = (batch + 255) // 256
+    alg_bytes_wave = n_local * d * 4 + batch * d * 4 + batch * k * 12 + n_local * 4
+    alg_bytes_scan = float(rows_scanned) * (d * 4 + 4) + args.steps * passes * (256 * d * 2)
+    roofline = None
+    if scan_ms > 0:
+        achieved = alg_bytes_scan / (scan_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": "filter_scan_kernel" if stats0["strategy_used"] == 2 else "exact_scan_kernel",
+                    "avg_launch_ms": round(scan_ms / max(1, scan_launches), 4), "launches": scan_launches,
+                    "alg_bytes_per_launch": round(alg_bytes_scan / max(1, scan_launches)),
+                    "whole_wave_frac": round(alg_bytes_wave * passes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    if world == 1 else None}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    out = {
+        "metric": "queries/sec, exact cosine kNN k=10 over a row-sharded Nx768 fp32 corpus (10M rows per GPU)",
+        "value": round(shard_queries_per_s, 1),
+        "unit": "queries/s (each query scanned against one 10M-row shard; whole-corpus QPS = value / n_gpus)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{2 if world == 1 else 4}]: {world * n_local} x {d} fp32 N(0,1) "
+                               f"rows ({n_local}/GPU), {args.space} kNN k={k}, batch={batch}, exact ids "
+                               f"(bf16-MFMA bound filter + fp64 rescoring)",
+                   "rows_per_gpu": n_local, "dim": d, "k": k, "batch": batch, "space": args.space,
+                   "strategy": {1: "exact", 2: "filter"}.get(stats0["strategy_used"], "?"),
+                   "sharding": f"row-wise over {world} ranks, host merge of per-shard top-k"},
+        "whole_corpus_qps": round(batch * args.steps / elapsed, 1),
+        "p50_ms_per_wave": round(float(np.median(per_step)) * 1e3, 3),
+        "roofline": roofline,
+        "candidates_rescored_per_query": round(rescored / max(1, args.steps * batch), 1),
+        "fallback_queries": int(fallbacks),
+        "parity_gate": verify,
+        "load_s": round(load_s, 1),
+    }
+
+    # ---- CPU exact-scan baseline (rank 0, N=1): this repo's NumPy/OpenBLAS scan on a bounded sample
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.blas_scan import BlasScanIndex
+
+        s_rows = min(args.cpu_sample_rows, n_local)
+        sample = synth.corpus_rows(0, s_rows, d)
+        cpu = BlasScanIndex(sample, args.space)
+        cpu.search(q_host[:8], k)
+        reps, t_cpu = 0, 0.0
+        while t_cpu < 10.0 and reps < 8:
+            tc = time.perf_counter()
+            cl, _ = cpu.search(q_host, k)
+            t_cpu += time.perf_counter() - tc
+            reps += 1
+        per_wave_sample = t_cpu / reps
+        try:
+            from threadpoolctl import threadpool_info
+
+            blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        except Exception:
+            blas_threads = os.cpu_count() or 1
+        out["cpu_baseline"] = {
+            "value": round(batch / (per_wave_sample * n_local / s_rows), 2),
+            "unit": "queries/s (extrapolated linearly in rows to the 10M-row corpus)",
+            "cores": int(blas_threads), "kind": "port",
+            "sample": f"{reps} waves of {batch} queries over the first {s_rows} rows, fp32 sgemm + argpartition "
+                      f"(oracle/blas_scan.py), {per_wave_sample * 1e3:.0f} ms per wave on the sample",
+        }
+        del cpu
+        # ---- side measurement, BASELINE configs[1]: 1M x 768, batch 1 (latency path, exact fp64 scan)
+        if not args.no_extras and s_rows >= 1_000_000:
+            e2 = HipScanEngine(d, args.space, device=local_rank, capacity_hint=1_000_000)
+            e2.append(sample[:1_000_000])
+            q1 = q_dev[:1].contiguous()
+            e2.set_profiling(True)
+            lat, scan2 = [], 0.0
+            for i in range(60):
+                ts = time.perf_counter()
+                e2.search_device(q1.data_ptr(), 1, k, lab.data_ptr(), dst.data_ptr(), cnt.data_ptr(), 0, stream)
+                torch.cuda.current_stream().synchronize()
+                if i >= 10:
+                    lat.append(time.perf_counter() - ts)
+                    scan2 += e2.last_stats()["scan_ms"]
+            e2.close()
+            p50 = float(np.median(lat))
+            out["config2_1Mx768_batch1"] = {
+                "qps": round(1.0 / p50, 1), "p50_ms": round(p50 * 1e3, 4),
+                "scan_kernel_ms": round(scan2 / len(lat), 4),
+                "hbm_frac_scan_kernel": round((1_000_000 * (d * 4 + 4)) / (scan2 / len(lat) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,15 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64 / libhsa-runtime64
+    # (SONAME libamdhip64.so.7, the name this library links).  If torch is importable, load it first
+    # so that the dynamic linker resolves our dependency to the runtime torch already initialised --
+    # two runtimes in one process leave the second without a GPU, and device pointers / streams
+    # handed over from torch must belong to the runtime that launches our kernels.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not path.exists():
         raise RuntimeError(

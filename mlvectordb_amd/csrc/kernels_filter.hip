@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void range_rescore_kernel(const FilterArgs a, 
 // ------------------------------------------------------------------ launchers
 hipError_t launch_filter_prep(const FilterArgs& a, hipStream_t s) {
     const int nkc = a.ld / kFilterChunkK;
-    filter_prep_kernel<<<nkc * 16, 256, 0, s>>>(a);
+    filter_prep_kernel<<<nkc > 0 ? nkc * 16 : 1, 256, 0, s>>>(a);  // nkc == 0: only the per-query state
     return hipGetLastError();
 }
 

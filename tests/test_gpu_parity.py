@@ -203,7 +203,7 @@ def test_range_capacity_overflow_is_reported_then_resolved():
     eng = HipScanEngine(64, "l2", device=0)
     try:
         eng.append(rows)
-        radius = float(np.sort(exact_scan.exact_distances(qs, rows, "l2"), axis=1)[:, 49].max())
+        radius = float(np.sort(exact_scan.exact_distances(qs, rows, "l2"), axis=1)[:, 49].max()) * 1.001
         got = eng.range(qs, radius, 8)  # capacity 8 < hits: the engine retries with the reported counts
         want = exact_scan.range_query(qs, rows, radius, "l2")
         for (gl, _), (wl, _) in zip(got, want):
