@@ -58,7 +58,7 @@ extern "C" {
 
 typedef struct mlvdb_index mlvdb_index;
 
-/* Per-call statistics of the most recent search/range call on a handle. */
+/* Statistics of the search/range calls made since the previous mlvdb_index_last_stats on the handle. */
 typedef struct mlvdb_stats {
     int32_t strategy_used;        /* MLVDB_STRATEGY_EXACT or MLVDB_STRATEGY_FILTER */
     int32_t scan_launches;        /* launches of the dominant scan kernel in the call */
@@ -125,8 +125,9 @@ int mlvdb_index_get_rows(mlvdb_index* h, int64_t first, int64_t n, float* out_ro
 int mlvdb_search_batch(mlvdb_index* h, const float* queries, int64_t nq, int32_t k,
                        int64_t* out_labels, float* out_dist, int32_t* out_counts);
 /* Same with every buffer on the index's device; work is enqueued on `stream`
- * (a hipStream_t passed as void*, NULL = default stream) and is complete when the
+ * (a hipStream_t passed as void*, NULL = the null stream) and is complete when the
  * stream is: the call itself only synchronises when a fallback decision needs it.
+ * The handle's workspaces are reused by every call: use one stream at a time per handle.
  * out_dist64_device (optional, may be NULL) receives the unrounded fp64 distances [nq, k]:
  * a caller that merges per-shard results must rank on these, not on the fp32 roundings. */
 int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64_t nq, int32_t k,
@@ -151,7 +152,8 @@ int mlvdb_index_set_strategy(mlvdb_index* h, int32_t strategy);
 /* Turn HIP-event timing of the scan kernels on/off (off by default: events add launch overhead). */
 int mlvdb_index_set_profiling(mlvdb_index* h, int32_t enabled);
 
-/* Statistics of the most recent search/range call (waits for that call's events if profiling). */
+/* Statistics accumulated since the previous call of this function (waits for the pending events /
+ * device counters of those calls), then starts a new accumulation window. */
 int mlvdb_index_last_stats(mlvdb_index* h, mlvdb_stats* out);
 
 /*

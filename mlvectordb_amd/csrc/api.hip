@@ -3,6 +3,7 @@
 // if no HIP device is usable every entry point fails with MLVDB_ERR_NO_DEVICE.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -50,6 +51,8 @@ struct mlvdb_index {
     int32_t strategy = MLVDB_STRATEGY_AUTO;
     bool profiling = false;
     float* X = nullptr;   // panels, capacity * ld floats
+    void* Xb = nullptr;   // bf16 shadow of X for the filter scan (capacity * ld bf16), or nullptr
+    bool shadow = false;  // keep the shadow (decided at creation: dim % 64 == 0 and not disabled)
     float* rn = nullptr;  // row norms, NaN = tombstoned / not a row
     int64_t capacity = 0, total = 0, deleted = 0;
     hipStream_t stream = nullptr;
@@ -64,6 +67,8 @@ struct mlvdb_index {
     size_t scan_events_used = 0;
     hipEvent_t total_events[2] = {nullptr, nullptr};
     bool stats_pending = false;
+    hipStream_t counters_stream = nullptr;  // stream of the last call that wrote the device counters
+    bool counters_pending = false;
 };
 
 namespace {
@@ -95,15 +100,24 @@ int reserve_rows(mlvdb_index* h, int64_t rows) {
     const int64_t cap = round_up_rows(want);
     float* nX = nullptr;
     float* nrn = nullptr;
+    void* nXb = nullptr;
     HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&nX), (size_t)cap * h->ld * sizeof(float)));
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&nrn), (size_t)cap * sizeof(float));
+    if (e == hipSuccess && h->shadow) e = hipMalloc(&nXb, (size_t)cap * h->ld * 2);
     if (e != hipSuccess) {
         (void)hipFree(nX);
-        return fail(h, MLVDB_ERR_OUT_OF_MEMORY, "hipMalloc(row norms)", e);
+        if (nrn) (void)hipFree(nrn);
+        return fail(h, MLVDB_ERR_OUT_OF_MEMORY, "hipMalloc(row norms / bf16 shadow)", e);
     }
     const size_t used_floats = (size_t)((h->total + 15) / 16) * 16 * h->ld;
     HIP_TRY(h, hipMemsetAsync(nX + used_floats, 0, ((size_t)cap * h->ld - used_floats) * sizeof(float), h->stream));
     HIP_TRY(h, hipMemsetAsync(nrn, 0xFF, (size_t)cap * sizeof(float), h->stream));  // 0xFFFFFFFF = NaN
+    if (nXb) {
+        HIP_TRY(h, hipMemsetAsync(static_cast<char*>(nXb) + used_floats * 2, 0, ((size_t)cap * h->ld - used_floats) * 2,
+                                  h->stream));
+        if (h->total > 0)
+            HIP_TRY(h, hipMemcpyAsync(nXb, h->Xb, used_floats * 2, hipMemcpyDeviceToDevice, h->stream));
+    }
     if (h->total > 0) {
         HIP_TRY(h, hipMemcpyAsync(nX, h->X, used_floats * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
         HIP_TRY(h, hipMemcpyAsync(nrn, h->rn, (size_t)h->total * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
@@ -111,18 +125,24 @@ int reserve_rows(mlvdb_index* h, int64_t rows) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->X) (void)hipFree(h->X);
     if (h->rn) (void)hipFree(h->rn);
+    if (h->Xb) (void)hipFree(h->Xb);
     h->X = nX;
     h->rn = nrn;
+    h->Xb = nXb;
     h->capacity = cap;
     return MLVDB_OK;
 }
 
 // ---- profiling helpers
+// Statistics accumulate over calls until mlvdb_index_last_stats reads (and resets) them, so a
+// caller can enqueue many query waves without synchronising and still get per-kernel times.
 int begin_call(mlvdb_index* h, hipStream_t s) {
-    h->stats = mlvdb_stats{};
-    h->scan_events_used = 0;
-    h->stats_pending = false;
-    if (h->profiling) {
+    if (h->scan_events_used > 8192) {  // nobody is reading them: start over rather than grow forever
+        h->scan_events_used = 0;
+        h->stats = mlvdb_stats{};
+        h->stats_pending = false;
+    }
+    if (h->profiling && !h->stats_pending) {
         for (auto& ev : h->total_events)
             if (!ev) HIP_TRY(h, hipEventCreate(&ev));
         HIP_TRY(h, hipEventRecord(h->total_events[0], s));
@@ -159,9 +179,16 @@ int scan_event(mlvdb_index* h, hipStream_t s, bool start) {
 // Qpad/qaux point at query 0 of the set's index space; qsel (device) lists the members or is null.
 int run_exact(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qaux, int32_t nq_sel,
               const int32_t* qsel, int64_t row_begin, int64_t row_end, int32_t k, int64_t* out_labels,
-              float* out_dist, int32_t* out_counts, double* out_d64, bool is_main_scan) {
+              float* out_dist, int32_t* out_counts, double* out_d64, bool is_main_scan,
+              const int32_t* nq_sel_dev = nullptr) {
     if (nq_sel <= 0) return MLVDB_OK;
-    const ExactPlan plan = plan_exact(row_end - row_begin, h->ld, nq_sel, k);
+    ExactPlan plan = plan_exact(row_end - row_begin, h->ld, nq_sel, k);
+    if (nq_sel_dev) {
+        // device-decided fallback: usually zero or a few queries are selected, so spread each query
+        // tile over many blocks; blocks of unselected tiles exit at once
+        const int64_t by_mem = (int64_t)(64u << 20) / ((int64_t)nq_sel * k * (int64_t)sizeof(TopEntry));
+        plan.nblk = (int)std::max<int64_t>(8, std::min<int64_t>(256, by_mem));
+    }
     HIP_TRY(h, h->partial.ensure((size_t)nq_sel * plan.nblk * k * sizeof(TopEntry)));
     ExactArgs a{};
     a.X = h->X;
@@ -174,6 +201,7 @@ int run_exact(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qa
     a.qaux = qaux;
     a.qsel = qsel;
     a.nq_sel = nq_sel;
+    a.nq_sel_dev = nq_sel_dev;
     a.k = k;
     a.cursor_d = nullptr;
     a.cursor_l = nullptr;
@@ -189,7 +217,8 @@ int run_exact(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qa
         h->stats.scan_launches += 1;
         h->stats.rows_scanned += (row_end - row_begin) * plan.nqtiles;
     }
-    HIP_TRY(h, launch_exact_merge(a.partial, nq_sel, qsel, plan.nblk, k, out_labels, out_dist, out_counts, out_d64, s));
+    HIP_TRY(h, launch_exact_merge(a.partial, nq_sel, nq_sel_dev, qsel, plan.nblk, k, out_labels, out_dist, out_counts,
+                                  out_d64, s));
     return MLVDB_OK;
 }
 
@@ -214,6 +243,7 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     if (!h->host_flags)
         HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->host_flags), kFilterQueries * sizeof(uint32_t), 0));
     fa.X = h->X;
+    fa.Xb = h->Xb;
     fa.rn = h->rn;
     fa.total = h->total;
     fa.ld = h->ld;
@@ -255,7 +285,7 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
     if (rc) return rc;
     HIP_TRY(h, launch_filter_prep(fa, s));
     // seed thresholds with the exact k-th best of a prefix (those rows are scanned again below)
-    const int64_t n_seed = std::min<int64_t>(h->total, 1024);
+    const int64_t n_seed = std::min<int64_t>(h->total, 4096);
     HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * k * sizeof(int64_t)));
     HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * k * sizeof(float)));
     HIP_TRY(h, h->seed_cnt.ensure(kFilterQueries * sizeof(int32_t)));
@@ -265,7 +295,7 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
     if (rc) return rc;
     HIP_TRY(h, launch_filter_seed_thr(fa, h->seed_d64.as<double>(), k, s));
     // scan in rounds of growing size; thresholds tighten between rounds
-    const int64_t bounds[] = {0, (int64_t)kFilterTile * 341, (int64_t)kFilterTile * 10923, h->total};
+    const int64_t bounds[] = {0, (int64_t)kFilterTile * 64, (int64_t)kFilterTile * 2048, h->total};
     for (int r = 0; r < 3; ++r) {
         const int64_t b = std::min(bounds[r], h->total), e = std::min(bounds[r + 1], h->total);
         if (e <= b) continue;
@@ -278,23 +308,19 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
         h->stats.rows_scanned += e - b;
         HIP_TRY(h, launch_filter_update(fa, k, s));
     }
-    HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(h, launch_filter_rescore(fa, k, q0, out_labels, out_dist, out_counts, out_d64,
-                                     h->counters.as<unsigned long long>(), s));
-    int32_t n_flagged = 0;
-    rc = collect_overflow(h, s, fa, &n_flagged);
+    // counters: [0] rescored pairs, [1] fallback queries (accumulated over the passes of a call), [2] flag count
+    unsigned long long* stats = h->counters.as<unsigned long long>();
+    HIP_TRY(h, launch_filter_rescore(fa, k, q0, out_labels, out_dist, out_counts, out_d64, stats, s));
+    // overflowed queries (adversarial near-ties) are re-run on the exact scan.  The decision stays on
+    // the device: the list is compacted there and the scan's blocks exit at once when it is empty,
+    // so the call never waits for the host.
+    HIP_TRY(h, h->qsel.ensure(kFilterQueries * sizeof(int32_t)));
+    int32_t* nflag = reinterpret_cast<int32_t*>(stats + 2);
+    HIP_TRY(h, launch_filter_collect(fa, h->qsel.as<int32_t>(), nflag, stats, s));
+    rc = run_exact(h, s, fa.Qpad, fa.qaux, nq, h->qsel.as<int32_t>(), 0, h->total, k, out_labels + (size_t)q0 * k,
+                   out_dist + (size_t)q0 * k, out_counts + q0, out_d64 ? out_d64 + (size_t)q0 * k : nullptr, false,
+                   nflag);
     if (rc) return rc;
-    unsigned long long rescored = 0;
-    HIP_TRY(h, hipMemcpy(&rescored, h->counters.p, sizeof rescored, hipMemcpyDeviceToHost));
-    h->stats.candidates_rescored += (int64_t)rescored;
-    if (n_flagged) {
-        h->stats.fallback_queries += n_flagged;
-        // outputs are indexed by batch position: shift the output base so query i lands at q0 + i
-        rc = run_exact(h, s, fa.Qpad, fa.qaux, n_flagged, h->qsel.as<int32_t>(), 0, h->total, k,
-                       out_labels + (size_t)q0 * k, out_dist + (size_t)q0 * k, out_counts + q0,
-                       out_d64 ? out_d64 + (size_t)q0 * k : nullptr, true);
-        if (rc) return rc;
-    }
     return MLVDB_OK;
 }
 
@@ -355,6 +381,10 @@ int mlvdb_index_create(int device, int32_t dim, int32_t space, int64_t capacity_
     h->dim = dim;
     h->ld = layout_ld(dim);
     h->space = space;
+    {
+        const char* ns = getenv("MLVDB_NO_SHADOW");
+        h->shadow = filter_supported(h->ld) && !(ns && ns[0] == '1');
+    }
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete h;
@@ -384,6 +414,7 @@ int mlvdb_index_destroy(mlvdb_index* h) {
     (void)hipDeviceSynchronize();
     if (h->X) (void)hipFree(h->X);
     if (h->rn) (void)hipFree(h->rn);
+    if (h->Xb) (void)hipFree(h->Xb);
     for (DevBuf* b : {&h->stage, &h->qpad, &h->qaux, &h->partial, &h->qsel, &h->seed_lab, &h->seed_dist, &h->seed_cnt,
                       &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt,
                       &h->counters, &h->labels_in})
@@ -411,6 +442,7 @@ int mlvdb_index_append_device(mlvdb_index* h, const float* rows_device, int64_t 
     if (rc) return rc;
     HIP_TRY(h, launch_scatter_rows(rows_device, h->X, h->total, n, h->dim, h->ld, h->stream));
     HIP_TRY(h, launch_row_norms(h->X, h->rn, h->total, n, h->ld, h->stream));
+    if (h->Xb) HIP_TRY(h, launch_shadow_rows(h->X, h->Xb, h->total, n, h->ld, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->total += n;
     return MLVDB_OK;
@@ -433,6 +465,7 @@ int mlvdb_index_append(mlvdb_index* h, const float* rows, int64_t n, int64_t* fi
                                   hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, launch_scatter_rows(h->stage.as<float>(), h->X, h->total + done, m, h->dim, h->ld, h->stream));
         HIP_TRY(h, launch_row_norms(h->X, h->rn, h->total + done, m, h->ld, h->stream));
+        if (h->Xb) HIP_TRY(h, launch_shadow_rows(h->X, h->Xb, h->total + done, m, h->ld, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     h->total += n;
@@ -472,6 +505,7 @@ int mlvdb_index_reset(mlvdb_index* h, int32_t space) {
     if (h->capacity > 0) {
         HIP_TRY(h, hipMemsetAsync(h->X, 0, (size_t)h->capacity * h->ld * sizeof(float), h->stream));
         HIP_TRY(h, hipMemsetAsync(h->rn, 0xFF, (size_t)h->capacity * sizeof(float), h->stream));
+        if (h->Xb) HIP_TRY(h, hipMemsetAsync(h->Xb, 0, (size_t)h->capacity * h->ld * 2, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     h->total = 0;
@@ -508,7 +542,7 @@ int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64
     if (nq == 0) return MLVDB_OK;
     if (!queries_device || !out_labels_device || !out_dist_device || !out_counts_device)
         return fail(h, MLVDB_ERR_INVALID_ARG, "null buffer");
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    hipStream_t s = static_cast<hipStream_t>(stream);  // NULL = the caller's default (null) stream
     rc = begin_call(h, s);
     if (rc) return rc;
     if (h->total == 0 || h->total == h->deleted) {
@@ -519,10 +553,13 @@ int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64
     }
     HIP_TRY(h, h->qpad.ensure((size_t)nq * h->ld * sizeof(float)));
     HIP_TRY(h, h->qaux.ensure((size_t)nq * sizeof(double)));
+    if (!h->counters_pending) HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 32, s));
+    h->counters_stream = s;
     HIP_TRY(h, launch_query_prep(queries_device, (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
                                  h->qaux.as<double>(), s));
     if (use_filter(h, nq)) {
         h->stats.strategy_used = MLVDB_STRATEGY_FILTER;
+        h->counters_pending = true;
         for (int64_t q0 = 0; q0 < nq; q0 += kFilterQueries) {
             const int32_t n = (int32_t)std::min<int64_t>(kFilterQueries, nq - q0);
             rc = run_filter_pass(h, s, h->qpad.as<float>(), h->qaux.as<double>(), (int32_t)q0, n, k, out_labels_device,
@@ -655,6 +692,14 @@ int mlvdb_index_last_stats(mlvdb_index* h, mlvdb_stats* out) {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!out) return fail(h, MLVDB_ERR_INVALID_ARG, "out is null");
+    if (h->counters_pending) {
+        unsigned long long c[2] = {0, 0};
+        HIP_TRY(h, hipMemcpyAsync(c, h->counters.p, sizeof c, hipMemcpyDeviceToHost, h->counters_stream));
+        HIP_TRY(h, hipStreamSynchronize(h->counters_stream));
+        h->stats.candidates_rescored = (int64_t)c[0];
+        h->stats.fallback_queries = (int64_t)c[1];
+        h->counters_pending = false;
+    }
     if (h->stats_pending) {
         HIP_TRY(h, hipEventSynchronize(h->total_events[1]));
         float ms = 0.f;
@@ -669,6 +714,11 @@ int mlvdb_index_last_stats(mlvdb_index* h, mlvdb_stats* out) {
         h->stats_pending = false;
     }
     *out = h->stats;
+    // reset: the next call starts a new accumulation window
+    const int32_t strategy = h->stats.strategy_used;
+    h->stats = mlvdb_stats{};
+    h->stats.strategy_used = strategy;
+    h->scan_events_used = 0;
     return MLVDB_OK;
 }
 

@@ -16,6 +16,8 @@ namespace mlvdb {
 // stage: row-major [n, dim] on the device -> panels; rows first_row..first_row+n-1
 hipError_t launch_scatter_rows(const float* stage, float* X, int64_t first_row, int64_t n, int32_t dim, int32_t ld,
                                hipStream_t s);
+// Xb (bf16 shadow, layout_offset_b) for the same rows, from the fp32 panels
+hipError_t launch_shadow_rows(const float* X, void* Xb, int64_t first_row, int64_t n, int32_t ld, hipStream_t s);
 // rn[row] = (float)|x_row| for the same rows (fp64 sum of squares)
 hipError_t launch_row_norms(const float* X, float* rn, int64_t first_row, int64_t n, int32_t ld, hipStream_t s);
 // panels -> row-major [n, dim]
@@ -49,6 +51,7 @@ struct ExactArgs {
     const double* qaux;  // [nq]
     const int32_t* qsel; // [nq_sel] query indices to process, or nullptr for 0..nq_sel-1
     int32_t nq_sel;
+    const int32_t* nq_sel_dev;  // optional: the actual count lives on the device (<= nq_sel); blocks beyond it exit
     int32_t k;
     const double* cursor_d;   // optional paging cursor per query (nullptr = none):
     const int32_t* cursor_l;  //   only rows strictly after (cursor_d, cursor_l) in rank order are admitted
@@ -56,7 +59,8 @@ struct ExactArgs {
 };
 hipError_t launch_exact_scan(const ExactArgs& a, const ExactPlan& p, hipStream_t s);
 // merge partial lists -> final outputs at the original query index
-hipError_t launch_exact_merge(const TopEntry* partial, int32_t nq_sel, const int32_t* qsel, int32_t nblk, int32_t k,
+hipError_t launch_exact_merge(const TopEntry* partial, int32_t nq_sel, const int32_t* nq_sel_dev, const int32_t* qsel,
+                              int32_t nblk, int32_t k,
                               int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_d64,
                               hipStream_t s);
 
@@ -64,7 +68,7 @@ hipError_t launch_exact_merge(const TopEntry* partial, int32_t nq_sel, const int
 constexpr int kFilterQueries = 256;   // queries per filter pass
 constexpr int kFilterChunkK = 64;     // columns per Q chunk staged in LDS
 constexpr int kCandCap = 8192;        // candidate slots per query
-constexpr int kFilterTile = 192;      // rows per filter-kernel tile: scan ranges start on multiples of it
+constexpr int kFilterTile = 768;      // scan ranges start on multiples of it (common multiple of the kernels' 192/128-row tiles)
 
 struct CandEntry {
     float u;      // upper bound of the row's score (higher = nearer)
@@ -76,6 +80,7 @@ size_t filter_qimg_bytes(int32_t ld);   // bf16 query image for one pass of kFil
 
 struct FilterArgs {
     const float* X;
+    const void* Xb;         // bf16 shadow of X (layout_offset_b) or nullptr: the scan then converts fp32 in registers
     const float* rn;
     int64_t total;
     int32_t ld;
@@ -98,6 +103,9 @@ hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t ro
 hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s);
 hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
                                  int32_t* out_counts, double* out_d64, unsigned long long* rescored, hipStream_t s);
+// compact the overflowed queries of a pass: qsel[0..*nflag) = their indices; stats[0] += rescored, stats[1] += *nflag
+hipError_t launch_filter_collect(const FilterArgs& a, int32_t* qsel, int32_t* nflag, unsigned long long* stats,
+                                 hipStream_t s);
 // range variant: fixed per-query threshold from the radius, then exact rescoring with emit
 hipError_t launch_filter_range_thr(const FilterArgs& a, float radius, hipStream_t s);
 // exact candidate generator for range queries (any dim): appends every live row with dist <= radius

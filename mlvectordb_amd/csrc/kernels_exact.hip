@@ -22,12 +22,14 @@ __global__ __launch_bounds__(NW * 64) void exact_scan_kernel(const ExactArgs a, 
     const int g = lane >> 4;
     const int r = lane & 15;
     const int ld = a.ld;
+    const int nq_sel = a.nq_sel_dev ? min(*a.nq_sel_dev, a.nq_sel) : a.nq_sel;
+    if ((int)blockIdx.y * QT >= nq_sel) return;  // block-uniform: nothing selected for this query tile
 
     int qid[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int sel = blockIdx.y * QT + t;
-        qid[t] = sel < a.nq_sel ? (a.qsel ? a.qsel[sel] : sel) : -1;
+        qid[t] = sel < nq_sel ? (a.qsel ? a.qsel[sel] : sel) : -1;
     }
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(NW * 64) void exact_scan_kernel(const ExactArgs a, 
         }
         double acc[PW][QT];
         double nx[PW];
-        accumulate_rows<SPACE, QT, PW>(base, qs, ld, g, acc, nx);
+        accumulate_rows<SPACE, QT, PW, (QT == 8 ? 4 : 0)>(base, qs, ld, g, acc, nx);
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int64_t row = panel[p] * kPanelRows + r;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(NW * 64) void exact_scan_kernel(const ExactArgs a, 
             m.offer(lane < a.k && cl != kNoLabel, cd, cl, a.k, lane);
         }
         const int sel = blockIdx.y * QT + t;
-        if (sel < a.nq_sel && lane < a.k) {
+        if (sel < nq_sel && lane < a.k) {
             TopEntry e;
             e.d = m.d;
             e.l = m.l;
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(NW * 64) void exact_scan_kernel(const ExactArgs a, 
 
 // One block (4 waves) per selected query: each wave folds a quarter of the partial entries,
 // wave 0 folds the four lists and writes the final answer.
-__global__ __launch_bounds__(256) void exact_merge_kernel(const TopEntry* __restrict__ partial, const int32_t* qsel,
+__global__ __launch_bounds__(256) void exact_merge_kernel(const TopEntry* __restrict__ partial,
+                                                          const int32_t* nq_sel_dev, const int32_t* qsel,
                                                           int32_t nblk, int32_t k, int64_t* out_labels,
                                                           float* out_dist, int32_t* out_counts, double* out_d64) {
     __shared__ double sd[4][64];
@@ -120,6 +123,7 @@ __global__ __launch_bounds__(256) void exact_merge_kernel(const TopEntry* __rest
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int sel = blockIdx.x;
+    if (nq_sel_dev && sel >= *nq_sel_dev) return;
     const int q = qsel ? qsel[sel] : sel;
     const TopEntry* src = partial + (int64_t)sel * nblk * k;
     const int64_t n = (int64_t)nblk * k;
@@ -302,11 +306,12 @@ hipError_t launch_exact_scan(const ExactArgs& a, const ExactPlan& p, hipStream_t
     }
 }
 
-hipError_t launch_exact_merge(const TopEntry* partial, int32_t nq_sel, const int32_t* qsel, int32_t nblk, int32_t k,
-                              int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_d64,
-                              hipStream_t s) {
+hipError_t launch_exact_merge(const TopEntry* partial, int32_t nq_sel, const int32_t* nq_sel_dev, const int32_t* qsel,
+                              int32_t nblk, int32_t k, int64_t* out_labels, float* out_dist, int32_t* out_counts,
+                              double* out_d64, hipStream_t s) {
     if (nq_sel <= 0) return hipSuccess;
-    exact_merge_kernel<<<nq_sel, 256, 0, s>>>(partial, qsel, nblk, k, out_labels, out_dist, out_counts, out_d64);
+    exact_merge_kernel<<<nq_sel, 256, 0, s>>>(partial, nq_sel_dev, qsel, nblk, k, out_labels, out_dist, out_counts,
+                                              out_d64);
     return hipGetLastError();
 }
 

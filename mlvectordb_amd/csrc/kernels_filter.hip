@@ -18,6 +18,8 @@
 //   cosine  s = <q^,x>/(|x|+1e-30)       = 1 - dist
 //   ip      s = <q^,x>                   = (1 - dist)/|q|
 //   l2      s = 2|q|<q^,x> - |x|^2       = |q|^2 - dist
+#include <cstdlib>
+
 #include "internal.h"
 #include "scan_common.h"
 
@@ -27,6 +29,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// In-place accumulate with the accumulator tied to the destination.  Used in the 2-waves-per-SIMD
+// geometry, where hipcc keeps the accumulators in plain VGPRs, is free to pick dst != srcC for
+// the builtin, and then rotates (and spills) them.  The s_nop covers the VALU-write -> MFMA-read
+// wait states for A fragments that were converted just before (hipcc pads nothing inside asm).
+template <bool PAD>
+__device__ __forceinline__ void mfma_tied(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+    if (PAD) asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+    else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
 
 // 16-byte buffer load: wave-uniform descriptor + scalar byte offset, one VGPR of lane offset.
 // Keeps the streaming loads' address arithmetic on the scalar unit (no 64-bit VGPR adds).
@@ -40,13 +52,9 @@ __device__ __forceinline__ uint4 buf_load_u4(__amdgpu_buffer_rsrc_t r, uint32_t 
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-constexpr int kFilterWaves = 4;
-constexpr int kFilterThreads = kFilterWaves * 64;
 constexpr int kChunkVec = kFilterQueries * kFilterChunkK * 2 / 16;  // uint4 per Q chunk (2048)
 constexpr float kSlack = 1.9073486328125e-06f;                      // 2^-19
-constexpr int kMT = 3;                        // 16-row MFMA tiles (panels) per wave
-constexpr int kFilterTileRows = kFilterWaves * 16 * kMT;  // 192 rows per workgroup tile
-static_assert(kFilterTileRows == kFilterTile, "internal.h kFilterTile out of sync");
+static_assert(kFilterTile % 192 == 0 && kFilterTile % 128 == 0, "kFilterTile");
 
 bool filter_supported(int32_t ld) { return ld >= kFilterChunkK && (ld % kFilterChunkK) == 0; }
 size_t filter_qimg_bytes(int32_t ld) { return (size_t)kFilterQueries * ld * 2; }
@@ -69,7 +77,10 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const FilterArgs a) {
         const int n = (idx >> 10) & 15;
         const int kc = (int)(idx >> 14);
         const int q = 16 * n + (lane & 15);
-        const int col = 64 * kc + 16 * (2 * ks + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
+        // k order of the A fragments: fp32 panels give lane g the columns {4g..4g+3} of two 16-col groups,
+        // the bf16 shadow gives it 8 consecutive columns
+        const int col = a.Xb ? 64 * kc + 32 * ks + 8 * (lane >> 4) + j
+                             : 64 * kc + 16 * (2 * ks + (j >> 2)) + 4 * (lane >> 4) + (j & 3);
         float v = 0.f;
         if (q < a.nq) {
             const double aux = a.qaux[q];
@@ -152,15 +163,18 @@ __global__ __launch_bounds__(256) void filter_range_thr_kernel(const FilterArgs 
 //       loads are older than the X prefetches issued meanwhile, so waiting for them (in-order
 //       vmcnt) never drains those.
 // All loads are ordinary loads on purpose: hipcc then tracks them with counted s_waitcnt.
-template <int SPACE, int R>
-__global__ __launch_bounds__(kFilterThreads, 1) void filter_scan_kernel(const FilterArgs a, const int64_t tile_begin,
+template <int SPACE, int R, int QD, bool PIN, int kMT, int NW, bool XB>
+__global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(const FilterArgs a, const int64_t tile_begin,
                                                                         const int64_t tile_end, const float e1) {
     constexpr int U = (R % 2 == 0) ? R : 2 * R;  // steps per unrolled body
+    constexpr int kThreads = NW * 64;
+    constexpr int kQPer = 1024 / kThreads;                 // uint4 of a Q half-chunk moved per thread
+    constexpr int kFilterTileRows = NW * 16 * kMT;  // rows per workgroup tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4* qlds = reinterpret_cast<uint4*>(smem);                                  // [2][kChunkVec]
     float* thr_l = reinterpret_cast<float*>(smem + 2 * kChunkVec * sizeof(uint4));  // [256]
     float* sq_l = thr_l + kFilterQueries;                                           // [256]
-    float* hit_l = sq_l + kFilterQueries;                                           // [4 waves][16][64]
+    float* hit_l = sq_l + kFilterQueries;                                           // [NW waves][4*kMT][64]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
@@ -168,8 +182,10 @@ __global__ __launch_bounds__(kFilterThreads, 1) void filter_scan_kernel(const Fi
     const int c16 = lane & 15;
     const int ld = a.ld;
     const int nkc = ld / kFilterChunkK;
-    thr_l[threadIdx.x] = a.thr[threadIdx.x];  // kFilterThreads == kFilterQueries
-    sq_l[threadIdx.x] = a.qscale[threadIdx.x];
+    if (threadIdx.x < kFilterQueries) {
+        thr_l[threadIdx.x] = a.thr[threadIdx.x];
+        sq_l[threadIdx.x] = a.qscale[threadIdx.x];
+    }
 
     const int64_t ntiles = tile_end - tile_begin;
     const int64_t my_tiles = ntiles > blockIdx.x ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
@@ -180,60 +196,74 @@ __global__ __launch_bounds__(kFilterThreads, 1) void filter_scan_kernel(const Fi
     const int64_t panel_stride = (int64_t)kPanelRows * ld;  // floats per panel
 
     f32x4 acc[kMT][16];
-    float4 xr[R][kMT][2];  // raw fp32 X half-chunks in flight; indexed only by unrolled constants
-    uint4 qst[8];        // this thread's share of the next Q chunk
+    constexpr int kLoads = XB ? 1 : 2;  // 16-byte loads per panel and 32-column step
+    float4 xr[R][kMT][kLoads];  // X k-steps in flight (fp32, or bf16 bits); indexed only by unrolled constants
+    uint4 qst[kQPer];    // this thread's share of the next Q half-chunk
     float4 rnv[kMT];     // |x| of this lane's kMT x 4 rows of the current tile
 
-    // X prefetch cursor over (tile index, chunk, half)
-    int64_t pre_i = 0;
-    int pre_kc = 0, pre_h = 0;
+    // X prefetch cursor: a 64-bit wave-uniform base (this wave's 3 panels of the tile being
+    // prefetched) plus a 32-bit byte offset of the half-chunk inside the panels.  Everything is
+    // advanced incrementally on the scalar unit; no multiplies on the per-step path.
     auto tile_of = [&](int64_t i) __attribute__((always_inline)) { return tile_begin + blockIdx.x + i * gridDim.x; };
-    const uint32_t lane_off16 = lane * 16;          // the only per-lane part of every X address
-    const uint32_t wave_bytes = (uint32_t)(kMT * panel_stride * sizeof(float));  // this wave's panels of a tile
-    auto load_x = [&](float4(&xb)[kMT][2]) __attribute__((always_inline)) {
-        const float* base = a.X + (tile_of(pre_i) * (kMT * 4) + kMT * wave) * panel_stride;
-        const __amdgpu_buffer_rsrc_t r = make_rsrc(base, wave_bytes);
-        const uint32_t soff = (uint32_t)(pre_kc * 4 + pre_h * 2) * (kGroupFloats * 4);
+    const uint32_t lane_off16 = lane * 16;  // the only per-lane part of every X address
+    const uint32_t panel_bytes = (uint32_t)(panel_stride * (XB ? 2 : 4));
+    const uint32_t wave_bytes = kMT * panel_bytes;         // this wave's panels of one tile
+    const uint32_t row_bytes_in_panel = (uint32_t)ld * (XB ? 32 : 64);  // bytes of one panel (groups of 1 KiB)
+    const uint64_t tile_stride_bytes = (uint64_t)gridDim.x * (NW * wave_bytes);
+    const char* pre_base = reinterpret_cast<const char*>(XB ? a.Xb : (const void*)a.X) +
+                           (uint64_t)(tile_begin + blockIdx.x) * (NW * wave_bytes) +
+                           (uint64_t)wave * wave_bytes;
+    uint32_t pre_soff = 0;
+    int64_t pre_tiles_left = my_tiles - 1;
+    auto load_x = [&](float4(&xb)[kMT][kLoads]) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(pre_base, wave_bytes);
 #pragma unroll
         for (int m = 0; m < kMT; ++m)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-                xb[m][kb] = buf_load_f4(r, lane_off16, soff + (uint32_t)(m * panel_stride * 4) + kb * (kGroupFloats * 4));
+            for (int kb = 0; kb < kLoads; ++kb)
+                xb[m][kb] = buf_load_f4(r, lane_off16 + kb * 1024, pre_soff + m * panel_bytes);
         // advance, saturating at the last half-chunk (the tail re-loads it: harmless, and it keeps
         // every load unconditional -- a conditional load's phi makes hipcc wait for it at once)
-        const bool at_end = pre_i == my_tiles - 1 && pre_kc == nkc - 1 && pre_h == 1;
-        if (!at_end) {
-            if (++pre_h == 2) {
-                pre_h = 0;
-                if (++pre_kc == nkc) {
-                    pre_kc = 0;
-                    ++pre_i;
-                }
+        pre_soff += kLoads * 1024;
+        if (pre_soff == row_bytes_in_panel) {
+            if (pre_tiles_left > 0) {
+                --pre_tiles_left;
+                pre_soff = 0;
+                pre_base += tile_stride_bytes;
+            } else {
+                pre_soff -= kLoads * 1024;
             }
         }
     };
     const __amdgpu_buffer_rsrc_t q_rsrc = make_rsrc(a.qimg, (uint32_t)(nkc * kChunkVec * sizeof(uint4)));
-    const uint32_t tid_off16 = threadIdx.x * 16;
-    auto load_q = [&](int kc) __attribute__((always_inline)) {
+    const uint32_t tid_off16 = (((threadIdx.x >> 6) * 2) * 64 + (threadIdx.x & 63)) * 16;
+    // half `h` of a chunk = its 16 B-fragment pieces with k-step == h; thread t moves uint4 t + kThreads*i
+    auto load_q = [&](int kc, int h) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            qst[i] = buf_load_u4(q_rsrc, tid_off16, (uint32_t)(kc * kChunkVec + i * kFilterThreads) * 16);
+        for (int i = 0; i < kQPer; ++i)
+            qst[i] = buf_load_u4(q_rsrc, tid_off16, (uint32_t)(kc * kChunkVec + ((i * NW) * 2 + h) * 64) * 16);
     };
-    auto store_q = [&](int buf) __attribute__((always_inline)) {
+    auto store_q = [&](int buf, int h) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) qlds[buf * kChunkVec + threadIdx.x + i * kFilterThreads] = qst[i];
+        for (int i = 0; i < kQPer; ++i) {
+            const int v = threadIdx.x + i * kThreads;
+            qlds[buf * kChunkVec + ((v >> 6) * 2 + h) * 64 + (v & 63)] = qst[i];
+        }
     };
 
-    // ---- prologue: Q(0) in registers, X(0..R-1) in flight
-    load_q(0);
-    int q_next_kc = nkc > 1 ? 1 : 0;  // chunk of the query image that the next load_q fetches
+    // ---- prologue: first half of Q(0) in LDS, second half in registers, X(0..R-1) in flight
+    load_q(0, 0);
+    store_q(0, 0);
+    load_q(0, 1);
+    int q_next_kc = nkc > 1 ? 1 : 0;  // chunk whose halves the next two load_q calls fetch
 #pragma unroll
     for (int b = 0; b < R; ++b) load_x(xr[b]);
 
     // Tile finished: bounds, admission test, rare appends.
     auto epilogue = [&](const int64_t ti) __attribute__((always_inline)) {
+        if (kMT == 2 && R > 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // XDL write -> VALU read wait states
         const int32_t row0 = (int32_t)(tile_of(ti) * kFilterTileRows) + wave * (16 * kMT) + g * 4;
-        float* dump = hit_l + wave * 1024 + lane;  // [16][64] floats per wave
+        float* dump = hit_l + wave * (4 * kMT * 64) + lane;  // [4*kMT][64] floats per wave
         // per-row constants: cosine  u = a*p0 + ec      (p0 = 1/(|x|+1e-30))
         //                    ip      u = a + p0          (p0 = (e1+slack)|x|)
         //                    l2      u = sq*(a + p0) + p1 (p1 = -|x|^2 (1-slack))
@@ -253,34 +283,46 @@ __global__ __launch_bounds__(kFilterThreads, 1) void filter_scan_kernel(const Fi
                 }
             }
         }
+        auto bound = [&](int m, int i, int n, float sq) __attribute__((always_inline)) {
+            const float av = acc[m][n][i];
+            if (SPACE == kSpaceCosine) return __builtin_fmaf(av, p0[m][i], ec);
+            if (SPACE == kSpaceIp) return av + p0[m][i];
+            return __builtin_fmaf(sq, av + p0[m][i], p1[m][i]);
+        };
+        // pass 1: admission masks; one slot reservation (atomic) per lane and query tile with hits.
+        // The atomics' results are not touched before pass 2, so all of them are in flight together.
+        uint32_t packed[16];  // bits 0..11 hit mask, bits 12.. first reserved slot (clamped)
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
             __builtin_amdgcn_sched_barrier(0);  // keep only one query tile's scores live at a time
             const float thr = thr_l[16 * n + c16];
             const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
-            float u[4 * kMT];
             uint32_t mask = 0;
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float av = acc[m][n][i];
-                    float uv;
-                    if (SPACE == kSpaceCosine) uv = __builtin_fmaf(av, p0[m][i], ec);
-                    else if (SPACE == kSpaceIp) uv = av + p0[m][i];
-                    else uv = __builtin_fmaf(sq, av + p0[m][i], p1[m][i]);
-                    u[4 * m + i] = uv;
-                    mask |= uv >= thr ? 1u << (4 * m + i) : 0u;
-                }
+                for (int i = 0; i < 4; ++i) mask |= bound(m, i, n, sq) >= thr ? 1u << (4 * m + i) : 0u;
+            uint32_t slot = 0;
             if (__ballot(mask != 0)) {
-                // rare: park the 16 scores in LDS so the hits can be walked with a dynamic index
+                if (mask) slot = atomicAdd(&a.cnt[16 * n + c16], (uint32_t)__popc(mask));
+            }
+            packed[n] = mask | (min(slot, (uint32_t)kCandCap) << 12);
+        }
+        // pass 2 (rare): write the admitted (bound, row) pairs into the reserved slots
 #pragma unroll
-                for (int j = 0; j < 4 * kMT; ++j) dump[j * 64] = u[j];
+        for (int n = 0; n < 16; ++n) {
+            if (__ballot((packed[n] & 0xfffu) != 0)) {
+                const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
+#pragma unroll
+                for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dump[(4 * m + i) * 64] = bound(m, i, n, sq);
                 const int q = 16 * n + c16;
+                uint32_t mask = packed[n] & 0xfffu;
+                uint32_t slot = packed[n] >> 12;
                 while (mask) {
                     const int j = __builtin_ctz(mask);
                     mask &= mask - 1;
-                    const uint32_t slot = atomicAdd(&a.cnt[q], 1u);
                     if (slot < (uint32_t)kCandCap) {
                         CandEntry e;
                         e.u = dump[j * 64];
@@ -289,12 +331,15 @@ __global__ __launch_bounds__(kFilterThreads, 1) void filter_scan_kernel(const Fi
                     } else {
                         a.overflow[q] = 1u;
                     }
+                    ++slot;
                 }
             }
         }
     };
 
     for (int64_t ti = 0; ti < my_tiles; ++ti) {
+        const __amdgpu_buffer_rsrc_t rn_rsrc =
+            make_rsrc(a.rn + tile_of(ti) * kFilterTileRows + wave * (16 * kMT), 16 * kMT * 4);
 #pragma unroll
         for (int m = 0; m < kMT; ++m)
 #pragma unroll
@@ -307,40 +352,60 @@ __global__ __launch_bounds__(kFilterThreads, 1) void filter_scan_kernel(const Fi
                 const int h = j & 1;
                 const int64_t s = ti * steps_per_tile + st + j;
                 const int64_t c = s >> 1;
-                // 1. this half-chunk's A fragments: fp32 -> bf16 in registers
+                // 1. this k-step's A fragments: bf16 bits as loaded, or fp32 -> bf16 in registers
                 bf16x8 xa[kMT];
 #pragma unroll
                 for (int m = 0; m < kMT; ++m) {
-                    const float4 lo = xr[b][m][0], hi = xr[b][m][1];
-                    const f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                    xa[m] = __builtin_convertvector(v, bf16x8);
+                    if (XB) {
+                        xa[m] = __builtin_bit_cast(bf16x8, xr[b][m][0]);
+                    } else {
+                        const float4 lo = xr[b][m][0], hi = xr[b][m][kLoads - 1];
+                        const f32x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                        xa[m] = __builtin_convertvector(v, bf16x8);
+                    }
                 }
+                // 2. Q staging, one half-chunk per step: write the half fetched one step ago, then
+                //    (new chunk) barrier, then fetch the next half.  Step 2c completes chunk c.
                 if (h == 0) {
-                    // 2. new chunk: publish Q(c) (loaded two steps ago), then fetch Q(c+1)
-                    store_q((int)(c & 1));
-                    __syncthreads();
-                    load_q(q_next_kc);
+                    store_q((int)(c & 1), 1);
+                    __syncthreads();  // everyone is done with chunk c-1; chunk c is complete and visible
+                    load_q(q_next_kc, 0);
+                } else {
+                    store_q((int)((c + 1) & 1), 0);
+                    load_q(q_next_kc, 1);
                     q_next_kc = q_next_kc + 1 == nkc ? 0 : q_next_kc + 1;
-                } else if (j == U - 1) {
-                    // row norms for the epilogue; reloaded every U steps so the load is unconditional
-                    const __amdgpu_buffer_rsrc_t rr =
-                        make_rsrc(a.rn + tile_of(ti) * kFilterTileRows + wave * (16 * kMT), 16 * kMT * 4);
+                    if (j == U - 1) {
+                        // row norms for the epilogue; reloaded every U steps so the load is unconditional
 #pragma unroll
-                    for (int m = 0; m < kMT; ++m) rnv[m] = buf_load_f4(rr, g * 16, m * 64);
+                        for (int m = 0; m < kMT; ++m) rnv[m] = buf_load_f4(rn_rsrc, g * 16, m * 64);
+                    }
                 }
                 // 3. refill the register buffer just consumed with the half-chunk R steps ahead
                 load_x(xr[b]);
                 // 4. 64 MFMAs: 16 query tiles x 4 row tiles, k-step h of the chunk
                 const uint4* qb_base = qlds + (c & 1) * kChunkVec + h * 64 + lane;
-                uint4 qraw[2];
-                qraw[0] = qb_base[0];
+                uint4 qraw[QD];  // B fragments read QD-1 query tiles ahead of their MFMAs
+#pragma unroll
+                for (int i = 0; i < QD - 1; ++i) qraw[i] = qb_base[i * 128];
 #pragma unroll
                 for (int n = 0; n < 16; ++n) {
-                    if (n + 1 < 16) qraw[(n + 1) & 1] = qb_base[(n + 1) * 128];
-                    const bf16x8 qb = __builtin_bit_cast(bf16x8, qraw[n & 1]);
+                    if (n + QD - 1 < 16) qraw[(n + QD - 1) % QD] = qb_base[(n + QD - 1) * 128];
+                    const bf16x8 qb = __builtin_bit_cast(bf16x8, qraw[n % QD]);
 #pragma unroll
-                    for (int m = 0; m < kMT; ++m)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[m], qb, acc[m][n], 0, 0, 0);
+                    for (int m = 0; m < kMT; ++m) {
+                        if (kMT == 2 && R > 2) mfma_tied<!XB>(acc[m][n], xa[m], qb);  // A from loads: no VALU write to pad
+                        else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[m], qb, acc[m][n], 0, 0, 0);
+                    }
+                }
+                if (kMT == 2 && R > 2) __builtin_amdgcn_sched_barrier(0);  // no code motion across steps: caps live ranges
+                if (PIN) {
+                    // pin the interleave: QD-1 reads up front, then one read per group of kMT MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, QD - 1, 0);
+#pragma unroll
+                    for (int n = 0; n < 16; ++n) {
+                        if (n + QD - 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, kMT, 0);
+                    }
                 }
             }
         }
@@ -356,17 +421,17 @@ __device__ __forceinline__ float entry_eps(int space, float e1, float sq, float 
     return sq * (e1 + kSlack) * nr + kSlack * nr * nr;
 }
 
-__device__ __forceinline__ uint32_t float_order_key(float f) {  // monotone float -> uint
-    const uint32_t b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-
-// One block per query.  thr[q] = max(thr[q], k-th largest lower bound); entries with u < thr dropped.
-constexpr int kUpdThreads = 1024;
-constexpr int kUpdWaves = kUpdThreads / 64;
+// One block (4 waves) per query.  thr[q] = max(thr[q], k-th largest lower bound); entries with
+// u < thr are dropped.  The k-th largest lower bound comes from a wave-level top-k (WaveTopK on
+// the negated bound, label = list position) per wave, merged through LDS -- no block-wide passes.
+constexpr int kUpdThreads = 256;
 __global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const FilterArgs a, const int32_t k, const float e1) {
-    __shared__ uint32_t s_count[kUpdWaves];
-    __shared__ uint32_t s_scan[kUpdWaves + 1];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    CandEntry* stage = reinterpret_cast<CandEntry*>(smem);                            // [kCandCap]
+    double(*sd)[64] = reinterpret_cast<double(*)[64]>(smem + kCandCap * sizeof(CandEntry));  // [4][64]
+    int32_t(*sl)[64] = reinterpret_cast<int32_t(*)[64]>(smem + kCandCap * sizeof(CandEntry) + 4 * 64 * 8);
+    uint32_t* s_scan = reinterpret_cast<uint32_t*>(smem + kCandCap * sizeof(CandEntry) + 4 * 64 * 12);  // [5]
+    float* s_thr = reinterpret_cast<float*>(s_scan + 5);
     const int q = blockIdx.x;
     if (q >= a.nq || a.overflow[q]) return;
     const uint32_t cnt = a.cnt[q];
@@ -374,80 +439,60 @@ __global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const Filter
         if (threadIdx.x == 0) a.overflow[q] = 1u;
         return;
     }
-    constexpr int kPer = kCandCap / kUpdThreads;  // 8 entries per thread
     CandEntry* list = a.cand + (int64_t)q * kCandCap;
     const float sq = a.qscale[q];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float u[kPer];
-    int32_t row[kPer];
-    uint32_t key[kPer];  // order key of the lower bound; 0 = absent
-#pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-        const uint32_t idx = threadIdx.x + i * kUpdThreads;
-        key[i] = 0;
-        u[i] = 0.f;
-        row[i] = 0;
-        if (idx < cnt) {
-            const CandEntry e = list[idx];
-            u[i] = e.u;
-            row[i] = e.row;
-            const float eps = entry_eps(a.space, e1, sq, a.rn[e.row]);
-            float l = e.u - 2.0f * eps;
-            l -= kSlack * (__builtin_fabsf(e.u) + eps);  // rounding of the line above
-            key[i] = float_order_key(l);
-            if (key[i] == 0) key[i] = 1;
-        }
-    }
     float thr = a.thr[q];
     if (cnt >= (uint32_t)k) {
-        // largest key value T such that at least k entries have key >= T (bitwise bisection)
-        uint32_t T = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const uint32_t trial = T | (1u << bit);
-            uint32_t c = 0;
-#pragma unroll
-            for (int i = 0; i < kPer; ++i) c += key[i] >= trial ? 1u : 0u;
-            for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-            __syncthreads();
-            if (lane == 0) s_count[wave] = c;
-            __syncthreads();
-            uint32_t tot = 0;
-#pragma unroll
-            for (int w = 0; w < kUpdWaves; ++w) tot += s_count[w];
-            if (tot >= (uint32_t)k) T = trial;
+        WaveTopK top;
+        top.init();
+        for (uint32_t i0 = wave * 64; i0 < cnt; i0 += kUpdThreads) {
+            const uint32_t idx = i0 + lane;
+            double key = __builtin_inf();
+            if (idx < cnt) {
+                const CandEntry e = list[idx];
+                const float eps = entry_eps(a.space, e1, sq, a.rn[e.row]);
+                float l = e.u - 2.0f * eps;
+                l -= kSlack * (__builtin_fabsf(e.u) + eps);  // rounding of the line above
+                key = -(double)l;
+            }
+            top.offer(idx < cnt, key, (int32_t)idx, k, lane);
         }
-        // invert the order key
-        const uint32_t b = (T & 0x80000000u) ? (T & 0x7fffffffu) : ~T;
-        const float lk = __uint_as_float(b);
-        if (lk > thr) thr = lk;
-    }
-    // compaction: keep u >= thr, stable order not required
-    uint32_t keep = 0;
+        sd[wave][lane] = top.d;
+        sl[wave][lane] = top.l;
+        __syncthreads();
+        if (wave == 0) {
+            WaveTopK f;
+            f.init();
 #pragma unroll
-    for (int i = 0; i < kPer; ++i) keep += (key[i] != 0 && u[i] >= thr) ? 1u : 0u;
+            for (int w2 = 0; w2 < 4; ++w2)
+                f.offer(lane < k && sl[w2][lane] != kNoLabel, sd[w2][lane], sl[w2][lane], k, lane);
+            if (lane == 0) *s_thr = f.kth_l != kNoLabel ? (float)(-f.kth_d) : -3.0e38f;
+        }
+        __syncthreads();
+        if (*s_thr > thr) thr = *s_thr;
+    }
+    // compaction through LDS: survivors (u >= thr) keep their relative order
+    uint32_t keep = 0;
+    for (uint32_t idx = threadIdx.x * 32; idx < min(cnt, threadIdx.x * 32 + 32); ++idx) keep += list[idx].u >= thr ? 1u : 0u;
     uint32_t incl = keep;
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t v = __shfl_up(incl, off);
         if (lane >= off) incl += v;
     }
-    __syncthreads();
     if (lane == 63) s_scan[wave + 1] = incl;
     if (threadIdx.x == 0) s_scan[0] = 0;
     __syncthreads();
-    uint32_t wave_base = 0;
-    for (int w = 0; w < wave; ++w) wave_base += s_scan[w + 1];
-    uint32_t new_cnt = 0;
-    for (int w = 0; w < kUpdWaves; ++w) new_cnt += s_scan[w + 1];
-    uint32_t pos = wave_base + incl - keep;
-    __syncthreads();  // every entry has been read into registers; safe to overwrite the list
-#pragma unroll
-    for (int i = 0; i < kPer; ++i) {
-        if (key[i] != 0 && u[i] >= thr) {
-            CandEntry e;
-            e.u = u[i];
-            e.row = row[i];
-            list[pos++] = e;
+    uint32_t pos = incl - keep;
+    for (int w = 0; w < wave; ++w) pos += s_scan[w + 1];
+    const uint32_t new_cnt = s_scan[1] + s_scan[2] + s_scan[3] + s_scan[4];
+    if (new_cnt != cnt) {
+        for (uint32_t idx = threadIdx.x * 32; idx < min(cnt, threadIdx.x * 32 + 32); ++idx) {
+            const CandEntry e = list[idx];
+            if (e.u >= thr) stage[pos++] = e;
         }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < new_cnt; i += kUpdThreads) list[i] = stage[i];
     }
     if (threadIdx.x == 0) {
         a.thr[q] = thr;
@@ -458,34 +503,35 @@ __global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const Filter
 // ------------------------------------------------------------------ exact rescoring
 // One block per query: the surviving rows are scored by the exact-scan arithmetic
 // (accumulate_rows, 16 gathered rows per wave step) and ranked (distance, label).
+constexpr int kRescoreWaves = 8;
 template <int SPACE>
-__global__ __launch_bounds__(256) void filter_rescore_kernel(const FilterArgs a, const int32_t k, const int32_t q0,
+__global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_kernel(const FilterArgs a, const int32_t k, const int32_t q0,
                                                              int64_t* out_labels, float* out_dist,
                                                              int32_t* out_counts, double* out_d64,
                                                              unsigned long long* rescored) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ld = a.ld;
     double* qs = reinterpret_cast<double*>(smem);                         // [ld]
-    double(*sd)[64] = reinterpret_cast<double(*)[64]>(qs + ld);          // [4][64]
-    int32_t(*sl)[64] = reinterpret_cast<int32_t(*)[64]>(qs + ld + 256);  // [4][64]
+    double(*sd)[64] = reinterpret_cast<double(*)[64]>(qs + ld);                          // [waves][64]
+    int32_t(*sl)[64] = reinterpret_cast<int32_t(*)[64]>(qs + ld + kRescoreWaves * 64);  // [waves][64]
     const int q = blockIdx.x;
     if (q >= a.nq || a.overflow[q]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, r = lane & 15;
-    for (int c = threadIdx.x; c < ld; c += 256) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
+    for (int c = threadIdx.x; c < ld; c += kRescoreWaves * 64) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
     __syncthreads();
     const double qinv = a.qaux[q];
     const uint32_t cnt = min(a.cnt[q], (uint32_t)kCandCap);
     const CandEntry* list = a.cand + (int64_t)q * kCandCap;
     WaveTopK top;
     top.init();
-    for (uint32_t i0 = wave * 16; i0 < cnt; i0 += 64) {
+    for (uint32_t i0 = wave * 16; i0 < cnt; i0 += kRescoreWaves * 16) {
         const uint32_t idx = i0 + r;
         const bool have = idx < cnt;
         const int32_t row = have ? list[idx].row : 0;
         const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 4 + g * 64};
         double acc[1][1], nx[1];
-        accumulate_rows<SPACE, 1, 1>(base, qs, ld, g, acc, nx);
+        accumulate_rows<SPACE, 1, 1, 8>(base, qs, ld, g, acc, nx);
         const double dist = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
         bool live = have && lane < 16;
         if (live) {
@@ -501,7 +547,8 @@ __global__ __launch_bounds__(256) void filter_rescore_kernel(const FilterArgs a,
     WaveTopK f;
     f.init();
 #pragma unroll
-    for (int w2 = 0; w2 < 4; ++w2) f.offer(lane < k && sl[w2][lane] != kNoLabel, sd[w2][lane], sl[w2][lane], k, lane);
+    for (int w2 = 0; w2 < kRescoreWaves; ++w2)
+        f.offer(lane < k && sl[w2][lane] != kNoLabel, sd[w2][lane], sl[w2][lane], k, lane);
     const bool valid = lane < k && f.l != kNoLabel;
     const int64_t o = (int64_t)(q0 + q) * k + lane;
     if (lane < k) {
@@ -550,7 +597,7 @@ __global__ __launch_bounds__(256) void range_rescore_kernel(const FilterArgs a, 
         const int32_t row = have ? list[idx].row : 0;
         const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 4 + g * 64};
         double acc[1][1], nx[1];
-        accumulate_rows<SPACE, 1, 1>(base, qs, ld, g, acc, nx);
+        accumulate_rows<SPACE, 1, 1, 4>(base, qs, ld, g, acc, nx);
         const double dist = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
         bool hit = have && lane < 16 && dist <= rad;
         if (hit) {
@@ -596,7 +643,33 @@ __global__ __launch_bounds__(256) void range_rescore_kernel(const FilterArgs a, 
     if (threadIdx.x == 0) out_counts[q0 + q] = n;
 }
 
+// One block: compact the indices of the overflowed queries (ascending) and publish their count.
+__global__ __launch_bounds__(256) void filter_collect_kernel(const FilterArgs a, int32_t* qsel, int32_t* nflag,
+                                                             unsigned long long* stats) {
+    __shared__ int32_t wave_cnt[4];
+    const int q = threadIdx.x;
+    const int lane = q & 63, wave = q >> 6;
+    const bool flagged = q < a.nq && a.overflow[q] != 0;
+    const unsigned long long b = __ballot(flagged);
+    if (lane == 0) wave_cnt[wave] = __popcll(b);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wave_cnt[w];
+    if (flagged) qsel[base + __popcll(b & ((1ull << lane) - 1))] = q;
+    if (q == 0) {
+        const int n = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        *nflag = n;
+        if (stats) stats[1] += (unsigned long long)n;
+    }
+}
+
 // ------------------------------------------------------------------ launchers
+hipError_t launch_filter_collect(const FilterArgs& a, int32_t* qsel, int32_t* nflag, unsigned long long* stats,
+                                 hipStream_t s) {
+    filter_collect_kernel<<<1, 256, 0, s>>>(a, qsel, nflag, stats);
+    return hipGetLastError();
+}
+
 hipError_t launch_filter_prep(const FilterArgs& a, hipStream_t s) {
     const int nkc = a.ld / kFilterChunkK;
     filter_prep_kernel<<<nkc > 0 ? nkc * 16 : 1, 256, 0, s>>>(a);  // nkc == 0: only the per-query state
@@ -613,61 +686,92 @@ hipError_t launch_filter_range_thr(const FilterArgs& a, float radius, hipStream_
     return hipGetLastError();
 }
 
-template <int SPACE, int R>
-static hipError_t launch_scan_one(const FilterArgs& a, int64_t tile_begin, int64_t tile_end, int grid, size_t lds,
-                                  float e1, hipStream_t s) {
-    auto kern = filter_scan_kernel<SPACE, R>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    kern<<<grid, kFilterThreads, lds, s>>>(a, tile_begin, tile_end, e1);
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <int SPACE, int R, int MT, bool XB>
+static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
+    constexpr int NW = 4;
+    constexpr int tile_rows = NW * 16 * MT;
+    const int64_t tile_begin = row_begin / tile_rows;
+    const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
+    if (tile_end <= tile_begin) return hipSuccess;
+    const size_t lds = 2 * kChunkVec * sizeof(uint4) + 2 * kFilterQueries * sizeof(float) +
+                       (size_t)NW * 4 * MT * 64 * sizeof(float);
+    const int64_t ntiles = tile_end - tile_begin;
+    const int max_grid = 256 * (MT == 3 ? 1 : 2);  // workgroups resident per launch
+    const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
+    auto kern = filter_scan_kernel<SPACE, R, 2, false, MT, NW, XB>;
+    static bool configured = false;  // per instantiation
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end, filter_e1(a.ld));
     return hipGetLastError();
 }
 
+// Geometry: 2 panels per wave (128 accumulators), two 4-wave workgroups per CU.  Scanning the
+// bf16 shadow needs 4 VGPRs per k-step in flight, so 4-8 k-steps rotate; scanning fp32 needs 16,
+// so only 2 fit (3 panels x 3 k-steps at one workgroup per CU is kept for comparison).
+// MLVDB_SCAN_R / MLVDB_SCAN_MT override the choice for experiments (read per launch).
 template <int SPACE>
-static hipError_t launch_scan_space(const FilterArgs& a, int64_t tile_begin, int64_t tile_end, int grid, size_t lds,
-                                    float e1, hipStream_t s) {
+static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
     // steps per tile = 2 * (ld / 64) must be a multiple of lcm(R, 2)
     const int nkc = a.ld / kFilterChunkK;
-    if (nkc % 3 == 0) return launch_scan_one<SPACE, 3>(a, tile_begin, tile_end, grid, lds, e1, s);
-    if (nkc % 2 == 0) return launch_scan_one<SPACE, 4>(a, tile_begin, tile_end, grid, lds, e1, s);
-    return launch_scan_one<SPACE, 2>(a, tile_begin, tile_end, grid, lds, e1, s);
+    if (a.Xb) {
+        const int want_r = env_int("MLVDB_SCAN_R", 2);
+        if (env_int("MLVDB_SCAN_MT", 2) == 3) {
+            if (want_r >= 8 && nkc % 4 == 0) return launch_scan_one<SPACE, 8, 3, true>(a, row_begin, row_end, s);
+            if (want_r >= 4 && nkc % 2 == 0) return launch_scan_one<SPACE, 4, 3, true>(a, row_begin, row_end, s);
+            return launch_scan_one<SPACE, 2, 3, true>(a, row_begin, row_end, s);
+        }
+        if (want_r >= 8 && nkc % 4 == 0) return launch_scan_one<SPACE, 8, 2, true>(a, row_begin, row_end, s);
+        if (want_r >= 4 && nkc % 2 == 0) return launch_scan_one<SPACE, 4, 2, true>(a, row_begin, row_end, s);
+        return launch_scan_one<SPACE, 2, 2, true>(a, row_begin, row_end, s);
+    }
+    if (env_int("MLVDB_SCAN_MT", 2) == 3 && nkc % 3 == 0) return launch_scan_one<SPACE, 3, 3, false>(a, row_begin, row_end, s);
+    return launch_scan_one<SPACE, 2, 2, false>(a, row_begin, row_end, s);
 }
 
 hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
-    const int64_t tile_begin = row_begin / kFilterTileRows;
-    const int64_t tile_end = (row_end + kFilterTileRows - 1) / kFilterTileRows;
-    if (tile_end <= tile_begin) return hipSuccess;
-    const size_t lds = 2 * kChunkVec * sizeof(uint4) + 2 * kFilterQueries * sizeof(float) +
-                       (size_t)kFilterWaves * 16 * 64 * sizeof(float);
-    const int64_t ntiles = tile_end - tile_begin;
-    const int grid = (int)(ntiles < 256 ? ntiles : 256);
-    const float e1 = filter_e1(a.ld);
     switch (a.space) {
-        case kSpaceL2: return launch_scan_space<kSpaceL2>(a, tile_begin, tile_end, grid, lds, e1, s);
-        case kSpaceCosine: return launch_scan_space<kSpaceCosine>(a, tile_begin, tile_end, grid, lds, e1, s);
-        default: return launch_scan_space<kSpaceIp>(a, tile_begin, tile_end, grid, lds, e1, s);
+        case kSpaceL2: return launch_scan_space<kSpaceL2>(a, row_begin, row_end, s);
+        case kSpaceCosine: return launch_scan_space<kSpaceCosine>(a, row_begin, row_end, s);
+        default: return launch_scan_space<kSpaceIp>(a, row_begin, row_end, s);
     }
 }
 
 hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s) {
-    filter_update_kernel<<<a.nq, kUpdThreads, 0, s>>>(a, k, filter_e1(a.ld));
+    const size_t lds = (size_t)kCandCap * sizeof(CandEntry) + 4 * 64 * 12 + 32;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_update_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    filter_update_kernel<<<a.nq, kUpdThreads, lds, s>>>(a, k, filter_e1(a.ld));
     return hipGetLastError();
 }
 
 hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
                                  int32_t* out_counts, double* out_d64, unsigned long long* rescored, hipStream_t s) {
-    const size_t lds = (size_t)a.ld * sizeof(double) + 256 * sizeof(double) + 256 * sizeof(int32_t);
+    const size_t lds = (size_t)a.ld * sizeof(double) + kRescoreWaves * 64 * (sizeof(double) + sizeof(int32_t));
     switch (a.space) {
         case kSpaceL2:
-            filter_rescore_kernel<kSpaceL2><<<a.nq, 256, lds, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored);
+            filter_rescore_kernel<kSpaceL2><<<a.nq, kRescoreWaves * 64, lds, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored);
             break;
         case kSpaceCosine:
-            filter_rescore_kernel<kSpaceCosine><<<a.nq, 256, lds, s>>>(a, k, q0, out_labels, out_dist, out_counts,
-                                                                      out_d64, rescored);
+            filter_rescore_kernel<kSpaceCosine><<<a.nq, kRescoreWaves * 64, lds, s>>>(a, k, q0, out_labels, out_dist,
+                                                                                    out_counts, out_d64, rescored);
             break;
         default:
-            filter_rescore_kernel<kSpaceIp><<<a.nq, 256, lds, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored);
+            filter_rescore_kernel<kSpaceIp><<<a.nq, kRescoreWaves * 64, lds, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored);
             break;
     }
     return hipGetLastError();

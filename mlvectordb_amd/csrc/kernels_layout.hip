@@ -28,6 +28,26 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
     }
 }
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+
+// One thread per (row, 8-column group): fp32 panels -> bf16 shadow, round-to-nearest-even
+// (the same v_cvt_pk_bf16_f32 the scan kernel uses when it converts in registers).
+__global__ __launch_bounds__(256) void shadow_rows_kernel(const float* __restrict__ X, __bf16* __restrict__ Xb,
+                                                          int64_t first_row, int64_t n, int32_t ld) {
+    const int32_t ngrp = ld >> 3;
+    const int64_t total = n * ngrp;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = first_row + idx / ngrp;
+        const int32_t col = (int32_t)(idx % ngrp) << 3;
+        const float4 lo = *reinterpret_cast<const float4*>(X + layout_offset(r, col, ld));
+        const float4 hi = *reinterpret_cast<const float4*>(X + layout_offset(r, col + 4, ld));
+        const f32x8_t v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        *reinterpret_cast<bf16x8_t*>(Xb + layout_offset_b(r, col, ld)) = __builtin_convertvector(v, bf16x8_t);
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ X, float* __restrict__ out,
                                                           int64_t first_row, int64_t n, int32_t dim, int32_t ld) {
     const int64_t total = n * dim;
@@ -111,6 +131,12 @@ hipError_t launch_scatter_rows(const float* stage, float* X, int64_t first_row, 
                                hipStream_t s) {
     if (n <= 0) return hipSuccess;
     scatter_rows_kernel<<<grid_for(n * (ld >> 2), 256), 256, 0, s>>>(stage, X, first_row, n, dim, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_shadow_rows(const float* X, void* Xb, int64_t first_row, int64_t n, int32_t ld, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    shadow_rows_kernel<<<grid_for(n * (ld >> 3), 256), 256, 0, s>>>(X, static_cast<__bf16*>(Xb), first_row, n, ld);
     return hipGetLastError();
 }
 

@@ -33,6 +33,15 @@ MLVDB_HD int64_t layout_offset(int64_t row, int32_t col, int32_t ld) {
            (row & 15) * 4 + (col & 3);
 }
 
+// bf16 shadow of the corpus (filter scans only): same 16-row panels, 32-column groups of 1 KiB,
+// inside a group [g = (col%32)/8][r = row%16][col%8]: lane 16*g + r of a wave reads 16 contiguous
+// bytes = its whole A fragment of one v_mfma_f32_16x16x32_bf16 k-step, in natural k order.
+// Offset in bf16 elements.
+MLVDB_HD int64_t layout_offset_b(int64_t row, int32_t col, int32_t ld) {
+    return (row >> 4) * (int64_t)(kPanelRows * ld) + (int64_t)(col >> 5) * 512 + ((col & 31) >> 3) * 128 +
+           (row & 15) * 8 + (col & 7);
+}
+
 MLVDB_HD int64_t round_up_rows(int64_t rows) { return (rows + kTileRows - 1) / kTileRows * kTileRows; }
 
 // distance spaces (include/mlvdb_hip.h)

@@ -17,7 +17,47 @@ namespace mlvdb {
 // in fp64, so the only rounding is in the sums; the order (j ascending inside a group,
 // groups ascending, then g via xor-16 / xor-32) is the same in every kernel that calls
 // this, which makes a row's distance bit-identical wherever it is computed.
+// One column group: x[p] holds this lane's float4 of row p.
 template <int SPACE, int QT, int PW>
+__device__ __forceinline__ void accumulate_group(const float4 (&x)[PW], const double* qs, int ld, int g, int kb,
+                                                 double (&acc)[PW][QT], double (&nx)[PW]) {
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const double* qp = qs + t * ld + kb * 16 + g * 4;
+        const double2 q01 = *reinterpret_cast<const double2*>(qp);
+        const double2 q23 = *reinterpret_cast<const double2*>(qp + 2);
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            if (SPACE == kSpaceL2) {
+                double e;
+                e = q01.x - (double)x[p].x; acc[p][t] = __builtin_fma(e, e, acc[p][t]);
+                e = q01.y - (double)x[p].y; acc[p][t] = __builtin_fma(e, e, acc[p][t]);
+                e = q23.x - (double)x[p].z; acc[p][t] = __builtin_fma(e, e, acc[p][t]);
+                e = q23.y - (double)x[p].w; acc[p][t] = __builtin_fma(e, e, acc[p][t]);
+            } else {
+                acc[p][t] = __builtin_fma(q01.x, (double)x[p].x, acc[p][t]);
+                acc[p][t] = __builtin_fma(q01.y, (double)x[p].y, acc[p][t]);
+                acc[p][t] = __builtin_fma(q23.x, (double)x[p].z, acc[p][t]);
+                acc[p][t] = __builtin_fma(q23.y, (double)x[p].w, acc[p][t]);
+            }
+        }
+    }
+    if (SPACE == kSpaceCosine) {
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            nx[p] = __builtin_fma((double)x[p].x, (double)x[p].x, nx[p]);
+            nx[p] = __builtin_fma((double)x[p].y, (double)x[p].y, nx[p]);
+            nx[p] = __builtin_fma((double)x[p].z, (double)x[p].z, nx[p]);
+            nx[p] = __builtin_fma((double)x[p].w, (double)x[p].w, nx[p]);
+        }
+    }
+}
+
+// PF = 0: plain loop (high-occupancy callers: other waves hide the latency).
+// PF > 0: the groups are fetched in blocks of PF, two register banks, the next block is in
+//         flight while the current one is consumed (low-occupancy callers: seed scan, rescoring).
+//         The summation order is the same for every PF.
+template <int SPACE, int QT, int PW, int PF = 0>
 __device__ __forceinline__ void accumulate_rows(const float* const (&base)[PW], const double* qs, int ld, int g,
                                                 double (&acc)[PW][QT], double (&nx)[PW]) {
     const int nkb = ld >> 4;
@@ -27,40 +67,44 @@ __device__ __forceinline__ void accumulate_rows(const float* const (&base)[PW], 
 #pragma unroll
         for (int t = 0; t < QT; ++t) acc[p][t] = 0.0;
     }
+    if (PF == 0) {
 #pragma unroll QT * PW <= 4 ? 2 : 1
-    for (int kb = 0; kb < nkb; ++kb) {
-        float4 x[PW];
+        for (int kb = 0; kb < nkb; ++kb) {
+            float4 x[PW];
 #pragma unroll
-        for (int p = 0; p < PW; ++p) x[p] = *reinterpret_cast<const float4*>(base[p] + (int64_t)kb * kGroupFloats);
+            for (int p = 0; p < PW; ++p) x[p] = *reinterpret_cast<const float4*>(base[p] + (int64_t)kb * kGroupFloats);
+            accumulate_group<SPACE, QT, PW>(x, qs, ld, g, kb, acc, nx);
+        }
+    } else {
+        constexpr int B = PF > 0 ? PF : 1;
+        const int nblk = nkb / B;
+        float4 bank0[B][PW], bank1[B][PW];
+        auto fetch = [&](float4(&bank)[B][PW], int blk) __attribute__((always_inline)) {
+            const int bb = blk < nblk ? blk : (nblk > 0 ? nblk - 1 : 0);  // clamped: loads stay unconditional
 #pragma unroll
-        for (int t = 0; t < QT; ++t) {
-            const double* qp = qs + t * ld + kb * 16 + g * 4;
-            const double2 q01 = *reinterpret_cast<const double2*>(qp);
-            const double2 q23 = *reinterpret_cast<const double2*>(qp + 2);
+            for (int i = 0; i < B; ++i)
 #pragma unroll
-            for (int p = 0; p < PW; ++p) {
-                if (SPACE == kSpaceL2) {
-                    double e;
-                    e = q01.x - (double)x[p].x; acc[p][t] = __builtin_fma(e, e, acc[p][t]);
-                    e = q01.y - (double)x[p].y; acc[p][t] = __builtin_fma(e, e, acc[p][t]);
-                    e = q23.x - (double)x[p].z; acc[p][t] = __builtin_fma(e, e, acc[p][t]);
-                    e = q23.y - (double)x[p].w; acc[p][t] = __builtin_fma(e, e, acc[p][t]);
-                } else {
-                    acc[p][t] = __builtin_fma(q01.x, (double)x[p].x, acc[p][t]);
-                    acc[p][t] = __builtin_fma(q01.y, (double)x[p].y, acc[p][t]);
-                    acc[p][t] = __builtin_fma(q23.x, (double)x[p].z, acc[p][t]);
-                    acc[p][t] = __builtin_fma(q23.y, (double)x[p].w, acc[p][t]);
-                }
+                for (int p = 0; p < PW; ++p)
+                    bank[i][p] = *reinterpret_cast<const float4*>(base[p] + (int64_t)(bb * B + i) * kGroupFloats);
+        };
+        auto consume = [&](const float4(&bank)[B][PW], int blk) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < B; ++i) accumulate_group<SPACE, QT, PW>(bank[i], qs, ld, g, blk * B + i, acc, nx);
+        };
+        if (nblk > 0) {
+            fetch(bank0, 0);
+            for (int blk = 0; blk < nblk; blk += 2) {
+                fetch(bank1, blk + 1);
+                consume(bank0, blk);
+                fetch(bank0, blk + 2);
+                if (blk + 1 < nblk) consume(bank1, blk + 1);
             }
         }
-        if (SPACE == kSpaceCosine) {
+        for (int kb = nblk * B; kb < nkb; ++kb) {  // remainder groups
+            float4 x[PW];
 #pragma unroll
-            for (int p = 0; p < PW; ++p) {
-                nx[p] = __builtin_fma((double)x[p].x, (double)x[p].x, nx[p]);
-                nx[p] = __builtin_fma((double)x[p].y, (double)x[p].y, nx[p]);
-                nx[p] = __builtin_fma((double)x[p].z, (double)x[p].z, nx[p]);
-                nx[p] = __builtin_fma((double)x[p].w, (double)x[p].w, nx[p]);
-            }
+            for (int p = 0; p < PW; ++p) x[p] = *reinterpret_cast<const float4*>(base[p] + (int64_t)kb * kGroupFloats);
+            accumulate_group<SPACE, QT, PW>(x, qs, ld, g, kb, acc, nx);
         }
     }
     // combine the four column slices of each row: (g0+g1) + (g2+g3), identical in all 4 lanes
