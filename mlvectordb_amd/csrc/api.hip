@@ -284,18 +284,13 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
     int rc = setup_filter_ws(h, fa, Qpad + (size_t)q0 * h->ld, qaux + q0, nq);
     if (rc) return rc;
     HIP_TRY(h, launch_filter_prep(fa, s));
-    // seed thresholds with the exact k-th best of a prefix (those rows are scanned again below)
-    const int64_t n_seed = std::min<int64_t>(h->total, 4096);
-    HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * k * sizeof(int64_t)));
-    HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * k * sizeof(float)));
-    HIP_TRY(h, h->seed_cnt.ensure(kFilterQueries * sizeof(int32_t)));
-    HIP_TRY(h, h->seed_d64.ensure((size_t)kFilterQueries * k * sizeof(double)));
-    rc = run_exact(h, s, fa.Qpad, fa.qaux, nq, nullptr, 0, n_seed, k, h->seed_lab.as<int64_t>(),
-                   h->seed_dist.as<float>(), h->seed_cnt.as<int32_t>(), h->seed_d64.as<double>(), false);
-    if (rc) return rc;
-    HIP_TRY(h, launch_filter_seed_thr(fa, h->seed_d64.as<double>(), k, s));
-    // scan in rounds of growing size; thresholds tighten between rounds
-    const int64_t bounds[] = {0, (int64_t)kFilterTile * 64, (int64_t)kFilterTile * 2048, h->total};
+    // seed: a dense pass of the filter kernel over the first rows puts every bound into the lists,
+    // the update kernel turns them into thresholds; the remaining rows follow in rounds of growing
+    // size so that thresholds tighten early
+    const int64_t n_seed = std::min<int64_t>(h->total, kSeedRows);
+    HIP_TRY(h, launch_filter_seed_scan(fa, n_seed, s));
+    HIP_TRY(h, launch_filter_update(fa, k, s));
+    const int64_t bounds[] = {kSeedRows, (int64_t)kFilterTile * 64, (int64_t)kFilterTile * 2048, h->total};
     for (int r = 0; r < 3; ++r) {
         const int64_t b = std::min(bounds[r], h->total), e = std::min(bounds[r + 1], h->total);
         if (e <= b) continue;

@@ -54,6 +54,7 @@ __device__ __forceinline__ uint4 buf_load_u4(__amdgpu_buffer_rsrc_t r, uint32_t 
 
 constexpr int kChunkVec = kFilterQueries * kFilterChunkK * 2 / 16;  // uint4 per Q chunk (2048)
 constexpr float kSlack = 1.9073486328125e-06f;                      // 2^-19
+constexpr int kSeedTileRows = 128;                                  // tile of the 2-panel geometry
 static_assert(kFilterTile % 192 == 0 && kFilterTile % 128 == 0, "kFilterTile");
 
 bool filter_supported(int32_t ld) { return ld >= kFilterChunkK && (ld % kFilterChunkK) == 0; }
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void filter_range_thr_kernel(const FilterArgs 
 //       loads are older than the X prefetches issued meanwhile, so waiting for them (in-order
 //       vmcnt) never drains those.
 // All loads are ordinary loads on purpose: hipcc then tracks them with counted s_waitcnt.
-template <int SPACE, int R, int QD, bool PIN, int kMT, int NW, bool XB>
+template <int SPACE, int R, int QD, bool PIN, int kMT, int NW, bool XB, bool DENSE>
 __global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(const FilterArgs a, const int64_t tile_begin,
                                                                         const int64_t tile_end, const float e1) {
     constexpr int U = (R % 2 == 0) ? R : 2 * R;  // steps per unrolled body
@@ -289,21 +290,46 @@ __global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(
             if (SPACE == kSpaceIp) return av + p0[m][i];
             return __builtin_fmaf(sq, av + p0[m][i], p1[m][i]);
         };
-        // pass 1: admission masks; one slot reservation (atomic) per lane and query tile with hits.
-        // The atomics' results are not touched before pass 2, so all of them are in flight together.
+        if (DENSE) {
+            // seeding pass: every (query,row) bound of these tiles goes straight into the candidate
+            // lists, slot = row - first row of the pass (the caller sets cnt and runs the update kernel)
+            const int32_t base_row = (int32_t)(tile_begin * kFilterTileRows);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
+                CandEntry* dst = a.cand + (int64_t)(16 * n + c16) * kCandCap + (row0 - base_row);
+#pragma unroll
+                for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        CandEntry e;
+                        e.u = bound(m, i, n, sq);
+                        e.row = row0 + 16 * m + i;
+                        dst[16 * m + i] = e;
+                    }
+            }
+            return;
+        }
+        // pass 1: quick reject per query tile on the maximum bound (NaN bounds of tombstoned rows are
+        // ignored by v_max); the per-row mask and one slot reservation (atomic) per lane only where it
+        // is needed.  The atomics' results are not touched before pass 2: all of them are in flight.
         uint32_t packed[16];  // bits 0..11 hit mask, bits 12.. first reserved slot (clamped)
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
             __builtin_amdgcn_sched_barrier(0);  // keep only one query tile's scores live at a time
             const float thr = thr_l[16 * n + c16];
             const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
-            uint32_t mask = 0;
+            float mx = -3.4e38f;
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mask |= bound(m, i, n, sq) >= thr ? 1u << (4 * m + i) : 0u;
-            uint32_t slot = 0;
-            if (__ballot(mask != 0)) {
+                for (int i = 0; i < 4; ++i) mx = __builtin_fmaxf(mx, bound(m, i, n, sq));
+            uint32_t mask = 0, slot = 0;
+            if (__ballot(mx >= thr)) {
+#pragma unroll
+                for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mask |= bound(m, i, n, sq) >= thr ? 1u << (4 * m + i) : 0u;
                 if (mask) slot = atomicAdd(&a.cnt[16 * n + c16], (uint32_t)__popc(mask));
             }
             packed[n] = mask | (min(slot, (uint32_t)kCandCap) << 12);
@@ -691,7 +717,7 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-template <int SPACE, int R, int MT, bool XB>
+template <int SPACE, int R, int MT, bool XB, bool DENSE = false>
 static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
     constexpr int NW = 4;
     constexpr int tile_rows = NW * 16 * MT;
@@ -703,7 +729,7 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
     const int64_t ntiles = tile_end - tile_begin;
     const int max_grid = 256 * (MT == 3 ? 1 : 2);  // workgroups resident per launch
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
-    auto kern = filter_scan_kernel<SPACE, R, 2, false, MT, NW, XB>;
+    auto kern = filter_scan_kernel<SPACE, R, 2, false, MT, NW, XB, DENSE>;
     static bool configured = false;  // per instantiation
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -736,6 +762,36 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
     }
     if (env_int("MLVDB_SCAN_MT", 2) == 3 && nkc % 3 == 0) return launch_scan_one<SPACE, 3, 3, false>(a, row_begin, row_end, s);
     return launch_scan_one<SPACE, 2, 2, false>(a, row_begin, row_end, s);
+}
+
+// Seeding pass over rows [0, row_end): every bound goes into the candidate lists (slot = row).
+// row_end <= kCandCap; the caller then sets cnt[q] = row_end rounded up to the tile and runs the
+// update kernel, which turns the lists into thresholds and drops what is below them.
+__global__ __launch_bounds__(256) void filter_set_cnt_kernel(const FilterArgs a, uint32_t value) {
+    if ((int)threadIdx.x < a.nq) a.cnt[threadIdx.x] = value;
+}
+
+hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, hipStream_t s) {
+    const int64_t rows = (row_end + kSeedTileRows - 1) / kSeedTileRows * kSeedTileRows;
+    hipError_t e;
+    const bool xb = a.Xb != nullptr;
+    switch (a.space) {
+        case kSpaceL2:
+            e = xb ? launch_scan_one<kSpaceL2, 2, 2, true, true>(a, 0, rows, s)
+                   : launch_scan_one<kSpaceL2, 2, 2, false, true>(a, 0, rows, s);
+            break;
+        case kSpaceCosine:
+            e = xb ? launch_scan_one<kSpaceCosine, 2, 2, true, true>(a, 0, rows, s)
+                   : launch_scan_one<kSpaceCosine, 2, 2, false, true>(a, 0, rows, s);
+            break;
+        default:
+            e = xb ? launch_scan_one<kSpaceIp, 2, 2, true, true>(a, 0, rows, s)
+                   : launch_scan_one<kSpaceIp, 2, 2, false, true>(a, 0, rows, s);
+            break;
+    }
+    if (e != hipSuccess) return e;
+    filter_set_cnt_kernel<<<1, 256, 0, s>>>(a, (uint32_t)rows);
+    return hipGetLastError();
 }
 
 hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {

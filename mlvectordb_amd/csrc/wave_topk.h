@@ -15,6 +15,14 @@ __device__ __forceinline__ bool entry_less(double ad, int32_t al, double bd, int
     return ad < bd || (ad == bd && al < bl);
 }
 
+// Cross-lane moves go through __shfl / __shfl_up (ds_bpermute).  Two faster-looking forms were tried
+// and are wrong on gfx950 / ROCm 7.2 in this code: DPP wave_shr:1 and v_readlane-based reads both
+// made list entries vanish (the exact-scan parity tests catch it), so they stay out.
+__device__ __forceinline__ int32_t lane_read(int32_t v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ double lane_read(double v, int src) { return __shfl(v, src); }
+__device__ __forceinline__ int32_t lane_shr1(int32_t v) { return __shfl_up(v, 1); }
+__device__ __forceinline__ double lane_shr1(double v) { return __shfl_up(v, 1); }
+
 struct WaveTopK {
     double d;     // this lane's entry
     int32_t l;
@@ -34,12 +42,12 @@ struct WaveTopK {
         while (m) {
             const int src = __builtin_ctzll(m);
             m &= m - 1;
-            const double vd = __shfl(cd, src);
-            const int32_t vl = __shfl(cl, src);
+            const double vd = lane_read(cd, src);
+            const int32_t vl = lane_read(cl, src);
             if (!entry_less(vd, vl, kth_d, kth_l)) continue;  // threshold moved since the ballot
             const int pos = __popcll(__ballot(entry_less(d, l, vd, vl)));
-            const double up_d = __shfl_up(d, 1);
-            const int32_t up_l = __shfl_up(l, 1);
+            const double up_d = lane_shr1(d);
+            const int32_t up_l = lane_shr1(l);
             if (lane > pos) {
                 d = up_d;
                 l = up_l;
@@ -47,8 +55,8 @@ struct WaveTopK {
                 d = vd;
                 l = vl;
             }
-            kth_d = __shfl(d, k - 1);
-            kth_l = __shfl(l, k - 1);
+            kth_d = lane_read(d, k - 1);
+            kth_l = lane_read(l, k - 1);
         }
     }
 };
