@@ -188,8 +188,18 @@ def main() -> None:
     roofline = None
     if scan_ms > 0:
         achieved = alg_bytes_scan / (scan_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = ROOT / "profiles" / "r01" / "pmc_traffic.json"
+        if stats0["strategy_used"] == 2 and n_local == 10_000_000 and d == 768 and tfile.exists():
+            # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+            # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); counters cannot be read from inside the process
+            traffic = json.loads(tfile.read_text())["traffic_bytes_per_launch_avg"]
+        flops = 2.0 * float(rows_scanned) * d * 256 * passes
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc, separate passes)" if traffic else None,
+                    "hbm_actual_frac": round(traffic * scan_launches / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    "mfma_bf16_frac": round(flops / (scan_ms * 1e-3) / 2.5e15, 4) if stats0["strategy_used"] == 2 else None,
                     "kernel": "filter_scan_kernel" if stats0["strategy_used"] == 2 else "exact_scan_kernel",
                     "avg_launch_ms": round(scan_ms / max(1, scan_launches), 4), "launches": scan_launches,
                     "alg_bytes_per_launch": round(alg_bytes_scan / max(1, scan_launches)),
