@@ -7,6 +7,7 @@
 // gives up on.  It takes the place of hnswlib's knn_query as called from the reference
 // (src/mlvectordb/implementations/index.py:111), computed exhaustively.
 #include <algorithm>
+#include <cstdlib>
 
 #include "internal.h"
 #include "scan_common.h"
@@ -263,7 +264,10 @@ ExactPlan plan_exact(int64_t nrows, int32_t ld, int32_t nq_sel, int32_t k) {
     const int64_t npanels = (nrows + 15) / 16;
     const int64_t ntasks = (npanels + pw - 1) / pw;
     int64_t nblk = (ntasks + nw - 1) / nw;
-    int64_t cap = qt <= 2 ? 512 : 1024 / p.nqtiles;
+    // one block per CU is the sweet spot for the streaming scan (tools/exact_ab.py); with several query
+    // tiles the corpus is split over fewer blocks each
+    int64_t cap = std::min<int64_t>(256, 1024 / p.nqtiles);
+    if (const char* e = getenv("MLVDB_EXACT_NBLK")) cap = atoi(e);  // tuning experiments only
     if (cap < 8) cap = 8;
     if (nblk > cap) nblk = cap;
     if (nblk < 1) nblk = 1;
