@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-2 (1M x 768, batch 1) side measurement")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (gloo for single-device rehearsals)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -65,11 +67,16 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     host_group = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        host_group = dist.new_group(backend="gloo")  # the per-shard candidates are merged on the host
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            host_group = dist.new_group(backend="gloo")  # the per-shard candidates are merged on the host
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
 
     n_local, d, k = args.rows_per_gpu, args.dim, args.k
@@ -142,6 +149,15 @@ def main() -> None:
         verify["oracle_sample"] = f"{sample_rows.shape[0]} rows x 64 queries"
         verify["oracle_ids_equal"] = bool(np.array_equal(sl, ol))
         verify["oracle_max_abs_err"] = float(np.abs(sd - od).max())
+    if world > 1:
+        # sharded path: the host-merged answer of the filter strategy must equal the merged exact scans
+        merged_fast = step()
+        eng.set_strategy("exact")
+        merged_exact = step()
+        eng.set_strategy(args.strategy)
+        if rank == 0:
+            verify["sharded_merge_equals_exact_ids"] = bool(np.array_equal(merged_fast[0], merged_exact[0]))
+            verify["sharded_merge_max_abs_err"] = float(np.abs(merged_fast[1] - merged_exact[1]).max())
     if not verify["filter_equals_exact_scan_ids"] or verify.get("oracle_ids_equal") is False:
         log(f"PARITY GATE FAILED: {verify}")
 
@@ -167,7 +183,7 @@ def main() -> None:
     rescored, fallbacks = st["candidates_rescored"], st["fallback_queries"]
     eng.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # latency of a single wave (host-synchronised), measured outside the throughput region

@@ -48,8 +48,10 @@ extern "C" {
 #define MLVDB_SPACE_COSINE 1
 #define MLVDB_SPACE_IP 2
 
-/* largest top_k the fused wave-level selection handles */
+/* largest top_k one scan selects (one list entry per wavefront lane); larger top_k is served in
+ * rank-ordered pages of this size by the exact scan, up to MLVDB_MAX_TOPK_PAGED */
 #define MLVDB_MAX_TOPK 64
+#define MLVDB_MAX_TOPK_PAGED 16384
 
 /* search strategy (mlvdb_index_set_strategy); AUTO picks per call */
 #define MLVDB_STRATEGY_AUTO 0
@@ -116,7 +118,7 @@ int mlvdb_index_get_rows(mlvdb_index* h, int64_t first, int64_t n, float* out_ro
 /*
  * Batched exact kNN.  Replaces hnswlib knn_query (index.py:111) for nq >= 1 queries.
  *   queries     [nq, dim] fp32
- *   k           1..MLVDB_MAX_TOPK; the caller clamps to the live count (index.py:107);
+ *   k           1..MLVDB_MAX_TOPK_PAGED; the caller clamps to the live count (index.py:107);
  *               if fewer than k live rows exist the tail is padded (label -1, distance +inf)
  *   out_labels  [nq, k] int64, nearest first
  *   out_dist    [nq, k] fp32 distances in this index's space

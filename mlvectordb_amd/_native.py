@@ -17,6 +17,7 @@ ERR_OVERFLOW = 7
 SPACE_CODES = {"l2": 0, "cosine": 1, "ip": 2}
 STRATEGY_CODES = {"auto": 0, "exact": 1, "filter": 2}
 MAX_TOPK = 64
+MAX_TOPK_PAGED = 16384
 ABI_VERSION = 1
 
 

@@ -59,6 +59,7 @@ struct mlvdb_index {
     // workspaces (grow only)
     DevBuf stage, qpad, qaux, partial, qsel, seed_lab, seed_dist, seed_cnt, seed_d64;
     DevBuf qimg, fmisc, cand, io_q, io_lab, io_dist, io_cnt, counters, labels_in;
+    DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
     uint32_t* host_flags = nullptr;  // pinned, kFilterQueries words
     std::string err;
     // statistics / profiling
@@ -180,7 +181,8 @@ int scan_event(mlvdb_index* h, hipStream_t s, bool start) {
 int run_exact(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qaux, int32_t nq_sel,
               const int32_t* qsel, int64_t row_begin, int64_t row_end, int32_t k, int64_t* out_labels,
               float* out_dist, int32_t* out_counts, double* out_d64, bool is_main_scan,
-              const int32_t* nq_sel_dev = nullptr) {
+              const int32_t* nq_sel_dev = nullptr, const double* cursor_d = nullptr,
+              const int32_t* cursor_l = nullptr) {
     if (nq_sel <= 0) return MLVDB_OK;
     ExactPlan plan = plan_exact(row_end - row_begin, h->ld, nq_sel, k);
     if (nq_sel_dev) {
@@ -203,8 +205,8 @@ int run_exact(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qa
     a.nq_sel = nq_sel;
     a.nq_sel_dev = nq_sel_dev;
     a.k = k;
-    a.cursor_d = nullptr;
-    a.cursor_l = nullptr;
+    a.cursor_d = cursor_d;
+    a.cursor_l = cursor_l;
     a.partial = h->partial.as<TopEntry>();
     if (is_main_scan) {
         int rc = scan_event(h, s, true);
@@ -319,6 +321,71 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
     return MLVDB_OK;
 }
 
+// ---- top_k above MLVDB_MAX_TOPK: rank-ordered pages of the exact scan.  Page p returns the next
+// entries strictly after the cursor (fp64 distance, label) of page p-1, so pages never overlap.
+__global__ void page_init_kernel(double* cur_d, int32_t* cur_l, int32_t* out_counts, int64_t nq) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < nq) {
+        cur_d[q] = -__builtin_inf();
+        cur_l[q] = -1;
+        out_counts[q] = 0;
+    }
+}
+
+__global__ void page_commit_kernel(const int64_t* page_lab, const float* page_dist, const int32_t* page_cnt,
+                                   const double* page_d64, int32_t kp, int32_t offset, int32_t k, int64_t* out_labels,
+                                   float* out_dist, int32_t* out_counts, double* out_d64, double* cur_d,
+                                   int32_t* cur_l) {
+    const int q = blockIdx.x;
+    const int i = threadIdx.x;  // kp <= 64 threads
+    const int n = page_cnt[q];
+    if (i < kp) {
+        const int64_t o = (int64_t)q * k + offset + i;
+        const bool ok = i < n;
+        out_labels[o] = ok ? page_lab[(int64_t)q * kp + i] : -1;
+        out_dist[o] = ok ? page_dist[(int64_t)q * kp + i] : __builtin_inff();
+        if (out_d64) out_d64[o] = ok ? page_d64[(int64_t)q * kp + i] : __builtin_inf();
+    }
+    if (i == 0) {
+        out_counts[q] += n;
+        if (n > 0) {
+            cur_d[q] = page_d64[(int64_t)q * kp + n - 1];
+            cur_l[q] = (int32_t)page_lab[(int64_t)q * kp + n - 1];
+        }
+        if (n < kp) {  // exhausted: later pages must find nothing
+            cur_d[q] = __builtin_inf();
+            cur_l[q] = 0x7fffffff;
+        }
+    }
+}
+
+int run_paged_exact(mlvdb_index* h, hipStream_t s, int64_t nq, int32_t k, int64_t* out_labels, float* out_dist,
+                    int32_t* out_counts, double* out_d64) {
+    const int32_t page = MLVDB_MAX_TOPK;
+    HIP_TRY(h, h->page_lab.ensure((size_t)nq * page * sizeof(int64_t)));
+    HIP_TRY(h, h->page_dist.ensure((size_t)nq * page * sizeof(float)));
+    HIP_TRY(h, h->page_cnt.ensure((size_t)nq * sizeof(int32_t)));
+    HIP_TRY(h, h->page_d64.ensure((size_t)nq * page * sizeof(double)));
+    HIP_TRY(h, h->cur_d.ensure((size_t)nq * sizeof(double)));
+    HIP_TRY(h, h->cur_l.ensure((size_t)nq * sizeof(int32_t)));
+    page_init_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, s>>>(h->cur_d.as<double>(), h->cur_l.as<int32_t>(),
+                                                                  out_counts, nq);
+    HIP_TRY(h, hipGetLastError());
+    for (int32_t offset = 0; offset < k; offset += page) {
+        const int32_t kp = std::min(page, k - offset);
+        int rc = run_exact(h, s, h->qpad.as<float>(), h->qaux.as<double>(), (int32_t)nq, nullptr, 0, h->total, kp,
+                           h->page_lab.as<int64_t>(), h->page_dist.as<float>(), h->page_cnt.as<int32_t>(),
+                           h->page_d64.as<double>(), true, nullptr, h->cur_d.as<double>(), h->cur_l.as<int32_t>());
+        if (rc) return rc;
+        page_commit_kernel<<<(unsigned)nq, 64, 0, s>>>(h->page_lab.as<int64_t>(), h->page_dist.as<float>(),
+                                                       h->page_cnt.as<int32_t>(), h->page_d64.as<double>(), kp, offset,
+                                                       k, out_labels, out_dist, out_counts, out_d64,
+                                                       h->cur_d.as<double>(), h->cur_l.as<int32_t>());
+        HIP_TRY(h, hipGetLastError());
+    }
+    return MLVDB_OK;
+}
+
 bool use_filter(const mlvdb_index* h, int64_t nq) {
     if (h->strategy == MLVDB_STRATEGY_EXACT || !filter_supported(h->ld)) return false;
     if (h->strategy == MLVDB_STRATEGY_FILTER) return true;
@@ -412,7 +479,8 @@ int mlvdb_index_destroy(mlvdb_index* h) {
     if (h->Xb) (void)hipFree(h->Xb);
     for (DevBuf* b : {&h->stage, &h->qpad, &h->qaux, &h->partial, &h->qsel, &h->seed_lab, &h->seed_dist, &h->seed_cnt,
                       &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt,
-                      &h->counters, &h->labels_in})
+                      &h->counters, &h->labels_in, &h->page_lab, &h->page_dist, &h->page_cnt, &h->page_d64, &h->cur_d,
+                      &h->cur_l})
         b->release();
     if (h->host_flags) (void)hipHostFree(h->host_flags);
     for (auto& p : h->scan_events) {
@@ -533,7 +601,7 @@ int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64
     if (rc) return rc;
     if (nq < 0 || nq > (1 << 24)) return fail(h, MLVDB_ERR_INVALID_ARG, "nq out of range");
     if (k < 1) return fail(h, MLVDB_ERR_INVALID_ARG, "k must be >= 1");
-    if (k > MLVDB_MAX_TOPK) return fail(h, MLVDB_ERR_UNSUPPORTED, "k above MLVDB_MAX_TOPK");
+    if (k > MLVDB_MAX_TOPK_PAGED) return fail(h, MLVDB_ERR_UNSUPPORTED, "k above MLVDB_MAX_TOPK_PAGED");
     if (nq == 0) return MLVDB_OK;
     if (!queries_device || !out_labels_device || !out_dist_device || !out_counts_device)
         return fail(h, MLVDB_ERR_INVALID_ARG, "null buffer");
@@ -552,7 +620,11 @@ int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64
     h->counters_stream = s;
     HIP_TRY(h, launch_query_prep(queries_device, (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
                                  h->qaux.as<double>(), s));
-    if (use_filter(h, nq)) {
+    if (k > MLVDB_MAX_TOPK) {
+        h->stats.strategy_used = MLVDB_STRATEGY_EXACT;
+        rc = run_paged_exact(h, s, nq, k, out_labels_device, out_dist_device, out_counts_device, out_dist64_device);
+        if (rc) return rc;
+    } else if (use_filter(h, nq)) {
         h->stats.strategy_used = MLVDB_STRATEGY_FILTER;
         h->counters_pending = true;
         for (int64_t q0 = 0; q0 < nq; q0 += kFilterQueries) {
@@ -576,7 +648,7 @@ int mlvdb_search_batch(mlvdb_index* h, const float* queries, int64_t nq, int32_t
     if (rc) return rc;
     if (nq < 0 || nq > (1 << 24)) return fail(h, MLVDB_ERR_INVALID_ARG, "nq out of range");
     if (k < 1) return fail(h, MLVDB_ERR_INVALID_ARG, "k must be >= 1");
-    if (k > MLVDB_MAX_TOPK) return fail(h, MLVDB_ERR_UNSUPPORTED, "k above MLVDB_MAX_TOPK");
+    if (k > MLVDB_MAX_TOPK_PAGED) return fail(h, MLVDB_ERR_UNSUPPORTED, "k above MLVDB_MAX_TOPK_PAGED");
     if (nq == 0) return MLVDB_OK;
     if (!queries || !out_labels || !out_dist || !out_counts) return fail(h, MLVDB_ERR_INVALID_ARG, "null buffer");
     HIP_TRY(h, h->io_q.ensure((size_t)nq * h->dim * sizeof(float)));

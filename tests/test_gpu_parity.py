@@ -126,6 +126,28 @@ def test_committed_golden_vectors(name, strategy):
     assert np.abs(dist - g["dist"]).max() <= SCORE_ATOL
 
 
+@pytest.mark.parametrize("space", ["l2", "cosine"])
+@pytest.mark.parametrize("n,d,nq,k", [(3000, 64, 3, 100), (5000, 20, 2, 333), (700, 128, 9, 700), (2000, 64, 1, 1000)])
+def test_topk_above_64_is_served_in_rank_ordered_pages(n, d, nq, k, space):
+    rows, qs = make_case(55, n, d, nq, dup=True)
+    deleted = deleted_mask(55, n, 0.1)
+    got, stats = run_hip(rows, qs, k, space, "auto", deleted)
+    assert stats["strategy_used"] == 1 and stats["scan_launches"] == -(-k // 64)
+    assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"paged/{space}/n{n}k{k}")
+
+
+@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+def test_filter_without_bf16_shadow_matches_oracle(space, monkeypatch):
+    """MLVDB_NO_SHADOW=1: the scan converts the fp32 panels in registers instead of reading the shadow."""
+    monkeypatch.setenv("MLVDB_NO_SHADOW", "1")
+    for seed, n, d, nq, k in [(61, 9000, 768, 40, 10), (62, 5000, 128, 256, 5), (63, 3000, 192, 24, 10)]:
+        rows, qs = make_case(seed, n, d, nq, dup=True)
+        deleted = deleted_mask(seed, n, 0.1)
+        got, stats = run_hip(rows, qs, k, space, "filter", deleted)
+        assert stats["strategy_used"] == 2
+        assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"noshadow/{space}/n{n}d{d}")
+
+
 def test_k_larger_than_live_rows_pads():
     rows, qs = make_case(51, 6, 64, 2)
     got, _ = run_hip(rows, qs, 10, "l2", "exact", deleted_mask(51, 6, 0.4))
