@@ -447,17 +447,24 @@ __device__ __forceinline__ float entry_eps(int space, float e1, float sq, float 
     return sq * (e1 + kSlack) * nr + kSlack * nr * nr;
 }
 
-// One block (4 waves) per query.  thr[q] = max(thr[q], k-th largest lower bound); entries with
-// u < thr are dropped.  The k-th largest lower bound comes from a wave-level top-k (WaveTopK on
-// the negated bound, label = list position) per wave, merged through LDS -- no block-wide passes.
+__device__ __forceinline__ uint32_t float_order_key(float f) {  // monotone float -> uint (larger float, larger key)
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float float_from_order_key(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// One block per query.  thr[q] = max(thr[q], k-th largest lower bound l = u - 2 eps); entries with
+// u < thr are dropped.  The k-th largest lower bound is found by a 4-pass radix select on the order
+// keys through an LDS histogram (no shuffles, 8 barriers), then the list is compacted through LDS.
 constexpr int kUpdThreads = 256;
 __global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const FilterArgs a, const int32_t k, const float e1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    CandEntry* stage = reinterpret_cast<CandEntry*>(smem);                            // [kCandCap]
-    double(*sd)[64] = reinterpret_cast<double(*)[64]>(smem + kCandCap * sizeof(CandEntry));  // [4][64]
-    int32_t(*sl)[64] = reinterpret_cast<int32_t(*)[64]>(smem + kCandCap * sizeof(CandEntry) + 4 * 64 * 8);
-    uint32_t* s_scan = reinterpret_cast<uint32_t*>(smem + kCandCap * sizeof(CandEntry) + 4 * 64 * 12);  // [5]
-    float* s_thr = reinterpret_cast<float*>(s_scan + 5);
+    CandEntry* stage = reinterpret_cast<CandEntry*>(smem);                                   // [kCandCap]
+    uint32_t* keys = reinterpret_cast<uint32_t*>(smem + kCandCap * sizeof(CandEntry));       // [kCandCap]
+    uint32_t* hist = keys + kCandCap;                                                        // [256]
+    uint32_t* s_scan = hist + 256;                                                           // [8]
     const int q = blockIdx.x;
     if (q >= a.nq || a.overflow[q]) return;
     const uint32_t cnt = a.cnt[q];
@@ -468,57 +475,92 @@ __global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const Filter
     CandEntry* list = a.cand + (int64_t)q * kCandCap;
     const float sq = a.qscale[q];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool need_norm = a.space != kSpaceCosine;
     float thr = a.thr[q];
-    if (cnt >= (uint32_t)k) {
-        WaveTopK top;
-        top.init();
-        for (uint32_t i0 = wave * 64; i0 < cnt; i0 += kUpdThreads) {
-            const uint32_t idx = i0 + lane;
-            double key = __builtin_inf();
-            if (idx < cnt) {
-                const CandEntry e = list[idx];
-                const float eps = entry_eps(a.space, e1, sq, a.rn[e.row]);
-                float l = e.u - 2.0f * eps;
-                l -= kSlack * (__builtin_fabsf(e.u) + eps);  // rounding of the line above
-                key = -(double)l;
-            }
-            top.offer(idx < cnt, key, (int32_t)idx, k, lane);
+    // order keys of the lower bounds (0 = not a candidate: NaN bound of a tombstoned / padding row)
+    uint32_t n_valid = 0;
+    for (uint32_t idx = threadIdx.x; idx < cnt; idx += kUpdThreads) {
+        const CandEntry e = list[idx];
+        stage[idx] = e;
+        uint32_t key = 0;
+        if (e.u == e.u) {
+            const float eps = entry_eps(a.space, e1, sq, need_norm ? a.rn[e.row] : 0.f);
+            float l = e.u - 2.0f * eps;
+            l -= kSlack * (__builtin_fabsf(e.u) + eps);  // rounding of the line above
+            key = float_order_key(l);
+            if (key == 0) key = 1;
+            ++n_valid;
         }
-        sd[wave][lane] = top.d;
-        sl[wave][lane] = top.l;
-        __syncthreads();
-        if (wave == 0) {
-            WaveTopK f;
-            f.init();
-#pragma unroll
-            for (int w2 = 0; w2 < 4; ++w2)
-                f.offer(lane < k && sl[w2][lane] != kNoLabel, sd[w2][lane], sl[w2][lane], k, lane);
-            if (lane == 0) *s_thr = f.kth_l != kNoLabel ? (float)(-f.kth_d) : -3.0e38f;
-        }
-        __syncthreads();
-        if (*s_thr > thr) thr = *s_thr;
+        keys[idx] = key;
     }
-    // compaction through LDS: survivors (u >= thr) keep their relative order
+    for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_xor(n_valid, off);
+    if (lane == 0) s_scan[wave] = n_valid;
+    __syncthreads();
+    n_valid = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    if (n_valid >= (uint32_t)k) {
+        // radix select, most significant byte first: prefix/mask narrow the keys, `want` = rank still wanted
+        uint32_t prefix = 0, mask = 0, want = (uint32_t)k;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            __syncthreads();
+            hist[threadIdx.x] = 0;
+            __syncthreads();
+            for (uint32_t idx = threadIdx.x; idx < cnt; idx += kUpdThreads) {
+                const uint32_t key = keys[idx];
+                if (key != 0 && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                // suffix sums over the 256 bins: lane owns bins 4*lane .. 4*lane+3
+                const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                uint32_t above = h0 + h1 + h2 + h3;  // becomes the count in bins of higher lanes
+                uint32_t run = above;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t v = __shfl_down(run, off);
+                    if (lane + off < 64) run += v;
+                }
+                above = run - above;  // keys in bins > 4*lane+3
+                // the wanted bin is the highest bin b with (count in bins >= b) >= want
+                const uint32_t c3 = above + h3, c2 = c3 + h2, c1 = c2 + h1, c0 = c1 + h0;
+                int bin = -1;
+                uint32_t before = 0;  // keys in bins strictly above the chosen one
+                if (above < want && c0 >= want) {
+                    if (c3 >= want) { bin = 4 * lane + 3; before = above; }
+                    else if (c2 >= want) { bin = 4 * lane + 2; before = c3; }
+                    else if (c1 >= want) { bin = 4 * lane + 1; before = c2; }
+                    else { bin = 4 * lane; before = c1; }
+                }
+                if (bin >= 0) {
+                    s_scan[4] = (uint32_t)bin;
+                    s_scan[5] = before;
+                }
+            }
+            __syncthreads();
+            prefix |= s_scan[4] << shift;
+            mask |= 255u << shift;
+            want -= s_scan[5];
+        }
+        const float lk = float_from_order_key(prefix);
+        if (lk > thr) thr = lk;
+    }
+    // compaction through LDS: survivors (u >= thr) in list order
     uint32_t keep = 0;
-    for (uint32_t idx = threadIdx.x * 32; idx < min(cnt, threadIdx.x * 32 + 32); ++idx) keep += list[idx].u >= thr ? 1u : 0u;
+    for (uint32_t idx = threadIdx.x * 32; idx < min(cnt, threadIdx.x * 32 + 32); ++idx) keep += stage[idx].u >= thr ? 1u : 0u;
     uint32_t incl = keep;
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t v = __shfl_up(incl, off);
         if (lane >= off) incl += v;
     }
-    if (lane == 63) s_scan[wave + 1] = incl;
-    if (threadIdx.x == 0) s_scan[0] = 0;
+    __syncthreads();
+    if (lane == 63) s_scan[wave] = incl;
     __syncthreads();
     uint32_t pos = incl - keep;
-    for (int w = 0; w < wave; ++w) pos += s_scan[w + 1];
-    const uint32_t new_cnt = s_scan[1] + s_scan[2] + s_scan[3] + s_scan[4];
+    for (int w = 0; w < wave; ++w) pos += s_scan[w];
+    const uint32_t new_cnt = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
     if (new_cnt != cnt) {
         for (uint32_t idx = threadIdx.x * 32; idx < min(cnt, threadIdx.x * 32 + 32); ++idx) {
-            const CandEntry e = list[idx];
-            if (e.u >= thr) stage[pos++] = e;
+            const CandEntry e = stage[idx];
+            if (e.u >= thr) list[pos++] = e;
         }
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < new_cnt; i += kUpdThreads) list[i] = stage[i];
     }
     if (threadIdx.x == 0) {
         a.thr[q] = thr;
@@ -530,6 +572,7 @@ __global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const Filter
 // One block per query: the surviving rows are scored by the exact-scan arithmetic
 // (accumulate_rows, 16 gathered rows per wave step) and ranked (distance, label).
 constexpr int kRescoreWaves = 8;
+constexpr int kRescoreRankMax = 2048;  // lists up to this length are ranked by counting in LDS
 template <int SPACE>
 __global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_kernel(const FilterArgs a, const int32_t k, const int32_t q0,
                                                              int64_t* out_labels, float* out_dist,
@@ -537,18 +580,23 @@ __global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_kernel(cons
                                                              unsigned long long* rescored) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ld = a.ld;
-    double* qs = reinterpret_cast<double*>(smem);                         // [ld]
-    double(*sd)[64] = reinterpret_cast<double(*)[64]>(qs + ld);                          // [waves][64]
-    int32_t(*sl)[64] = reinterpret_cast<int32_t(*)[64]>(qs + ld + kRescoreWaves * 64);  // [waves][64]
+    double* qs = reinterpret_cast<double*>(smem);                                        // [ld]
+    double* ed = qs + ld;                                                                // [kRescoreRankMax] exact distances
+    int32_t* el = reinterpret_cast<int32_t*>(ed + kRescoreRankMax);                      // [kRescoreRankMax] labels
+    double(*sd)[64] = reinterpret_cast<double(*)[64]>(el + kRescoreRankMax);             // [waves][64]
+    int32_t(*sl)[64] = reinterpret_cast<int32_t(*)[64]>(sd + kRescoreWaves);             // [waves][64]
+    int32_t* s_nvalid = reinterpret_cast<int32_t*>(sl + kRescoreWaves);
     const int q = blockIdx.x;
     if (q >= a.nq || a.overflow[q]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, r = lane & 15;
     for (int c = threadIdx.x; c < ld; c += kRescoreWaves * 64) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
+    if (threadIdx.x == 0) *s_nvalid = 0;
     __syncthreads();
     const double qinv = a.qaux[q];
     const uint32_t cnt = min(a.cnt[q], (uint32_t)kCandCap);
     const CandEntry* list = a.cand + (int64_t)q * kCandCap;
+    const bool by_rank = cnt <= (uint32_t)kRescoreRankMax;
     WaveTopK top;
     top.init();
     for (uint32_t i0 = wave * 16; i0 < cnt; i0 += kRescoreWaves * 16) {
@@ -564,7 +612,46 @@ __global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_kernel(cons
             const float nrm = a.rn[row];
             live = nrm == nrm;
         }
-        top.offer(live, dist, row, k, lane);
+        if (by_rank) {
+            if (have && lane < 16) {
+                ed[idx] = live ? dist : __builtin_inf();
+                el[idx] = live ? row : kNoLabel;
+            }
+        } else {
+            top.offer(live, dist, row, k, lane);
+        }
+    }
+    const int64_t o = (int64_t)(q0 + q) * k;
+    if (by_rank) {
+        // every entry counts how many entries precede it in (distance, label) order: that is its rank
+        __syncthreads();
+        int mine = 0;
+        for (uint32_t i = threadIdx.x; i < cnt; i += kRescoreWaves * 64) {
+            const double di = ed[i];
+            const int32_t li = el[i];
+            if (li == kNoLabel) continue;
+            ++mine;
+            int rank = 0;
+            for (uint32_t j = 0; j < cnt; ++j) rank += entry_less(ed[j], el[j], di, li) ? 1 : 0;
+            if (rank < k) {
+                out_labels[o + rank] = (int64_t)li;
+                out_dist[o + rank] = (float)di;
+                if (out_d64) out_d64[o + rank] = di;
+            }
+        }
+        if (mine) atomicAdd(s_nvalid, mine);
+        __syncthreads();
+        const int n_out = min(*s_nvalid, k);
+        for (int i = n_out + threadIdx.x; i < k; i += kRescoreWaves * 64) {
+            out_labels[o + i] = -1;
+            out_dist[o + i] = __builtin_inff();
+            if (out_d64) out_d64[o + i] = __builtin_inf();
+        }
+        if (threadIdx.x == 0) {
+            out_counts[q0 + q] = n_out;
+            if (rescored) atomicAdd(rescored, (unsigned long long)cnt);
+        }
+        return;
     }
     sd[wave][lane] = top.d;
     sl[wave][lane] = top.l;
@@ -576,11 +663,10 @@ __global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_kernel(cons
     for (int w2 = 0; w2 < kRescoreWaves; ++w2)
         f.offer(lane < k && sl[w2][lane] != kNoLabel, sd[w2][lane], sl[w2][lane], k, lane);
     const bool valid = lane < k && f.l != kNoLabel;
-    const int64_t o = (int64_t)(q0 + q) * k + lane;
     if (lane < k) {
-        out_labels[o] = valid ? (int64_t)f.l : -1;
-        out_dist[o] = valid ? (float)f.d : __builtin_inff();
-        if (out_d64) out_d64[o] = valid ? f.d : __builtin_inf();
+        out_labels[o + lane] = valid ? (int64_t)f.l : -1;
+        out_dist[o + lane] = valid ? (float)f.d : __builtin_inff();
+        if (out_d64) out_d64[o + lane] = valid ? f.d : __builtin_inf();
     }
     const int n_valid = __popcll(__ballot(valid));
     if (lane == 0) {
@@ -803,7 +889,7 @@ hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t ro
 }
 
 hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s) {
-    const size_t lds = (size_t)kCandCap * sizeof(CandEntry) + 4 * 64 * 12 + 32;
+    const size_t lds = (size_t)kCandCap * (sizeof(CandEntry) + sizeof(uint32_t)) + 256 * 4 + 64;
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_update_kernel),
@@ -817,19 +903,25 @@ hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s) {
 
 hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
                                  int32_t* out_counts, double* out_d64, unsigned long long* rescored, hipStream_t s) {
-    const size_t lds = (size_t)a.ld * sizeof(double) + kRescoreWaves * 64 * (sizeof(double) + sizeof(int32_t));
+    const size_t lds = (size_t)a.ld * sizeof(double) + kRescoreRankMax * (sizeof(double) + sizeof(int32_t)) +
+                       kRescoreWaves * 64 * (sizeof(double) + sizeof(int32_t)) + 16;
+    hipError_t e = hipSuccess;
+#define MLVDB_LAUNCH_RESCORE(SP)                                                                                     \
+    do {                                                                                                             \
+        auto kern = filter_rescore_kernel<SP>;                                                                       \
+        if (lds > 48 * 1024)                                                                                         \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds);                                                                       \
+        if (e == hipSuccess)                                                                                         \
+            kern<<<a.nq, kRescoreWaves * 64, lds, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored); \
+    } while (0)
     switch (a.space) {
-        case kSpaceL2:
-            filter_rescore_kernel<kSpaceL2><<<a.nq, kRescoreWaves * 64, lds, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored);
-            break;
-        case kSpaceCosine:
-            filter_rescore_kernel<kSpaceCosine><<<a.nq, kRescoreWaves * 64, lds, s>>>(a, k, q0, out_labels, out_dist,
-                                                                                    out_counts, out_d64, rescored);
-            break;
-        default:
-            filter_rescore_kernel<kSpaceIp><<<a.nq, kRescoreWaves * 64, lds, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored);
-            break;
+        case kSpaceL2: MLVDB_LAUNCH_RESCORE(kSpaceL2); break;
+        case kSpaceCosine: MLVDB_LAUNCH_RESCORE(kSpaceCosine); break;
+        default: MLVDB_LAUNCH_RESCORE(kSpaceIp); break;
     }
+#undef MLVDB_LAUNCH_RESCORE
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
