@@ -143,7 +143,8 @@ int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64
  *   capacity    entries available per query in out_labels / out_dist
  *   out_counts  [nq] int64 exact number of hits per query, even when > capacity
  * Returns MLVDB_ERR_OVERFLOW (outputs hold the nearest `capacity` hits) when any
- * query had more hits than capacity.
+ * query had more hits than capacity, and MLVDB_ERR_UNSUPPORTED when a query has more than
+ * MLVDB_MAX_TOPK_PAGED hits and more than that were asked for (counts are still exact).
  */
 int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float radius, int64_t capacity,
                       int64_t* out_labels, float* out_dist, int64_t* out_counts);

@@ -61,6 +61,7 @@ struct mlvdb_index {
     DevBuf qimg, fmisc, cand, io_q, io_lab, io_dist, io_cnt, counters, labels_in;
     DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
     uint32_t* host_flags = nullptr;  // pinned, kFilterQueries words
+    bool host_overflow[256] = {};    // flags of the last collect_overflow
     std::string err;
     // statistics / profiling
     mlvdb_stats stats{};
@@ -268,6 +269,7 @@ int collect_overflow(mlvdb_index* h, hipStream_t s, const FilterArgs& fa, int32_
     HIP_TRY(h, hipStreamSynchronize(s));
     int32_t sel[kFilterQueries];
     int32_t n = 0;
+    for (int q = 0; q < kFilterQueries; ++q) h->host_overflow[q] = q < fa.nq && h->host_flags[q] != 0;
     for (int q = 0; q < fa.nq; ++q)
         if (h->host_flags[q]) sel[n++] = q;
     *n_flagged = n;
@@ -323,9 +325,11 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
 
 // ---- top_k above MLVDB_MAX_TOPK: rank-ordered pages of the exact scan.  Page p returns the next
 // entries strictly after the cursor (fp64 distance, label) of page p-1, so pages never overlap.
-__global__ void page_init_kernel(double* cur_d, int32_t* cur_l, int32_t* out_counts, int64_t nq) {
-    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q < nq) {
+// Query ids: blockIdx / thread index i addresses qsel[i] when a selection is given.
+__global__ void page_init_kernel(double* cur_d, int32_t* cur_l, int32_t* out_counts, const int32_t* qsel, int64_t nsel) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nsel) {
+        const int64_t q = qsel ? qsel[i] : i;
         cur_d[q] = -__builtin_inf();
         cur_l[q] = -1;
         out_counts[q] = 0;
@@ -333,10 +337,10 @@ __global__ void page_init_kernel(double* cur_d, int32_t* cur_l, int32_t* out_cou
 }
 
 __global__ void page_commit_kernel(const int64_t* page_lab, const float* page_dist, const int32_t* page_cnt,
-                                   const double* page_d64, int32_t kp, int32_t offset, int32_t k, int64_t* out_labels,
-                                   float* out_dist, int32_t* out_counts, double* out_d64, double* cur_d,
-                                   int32_t* cur_l) {
-    const int q = blockIdx.x;
+                                   const double* page_d64, const int32_t* qsel, int32_t kp, int32_t offset, int32_t k,
+                                   int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_d64,
+                                   double* cur_d, int32_t* cur_l) {
+    const int q = qsel ? qsel[blockIdx.x] : blockIdx.x;
     const int i = threadIdx.x;  // kp <= 64 threads
     const int n = page_cnt[q];
     if (i < kp) {
@@ -359,31 +363,54 @@ __global__ void page_commit_kernel(const int64_t* page_lab, const float* page_di
     }
 }
 
-int run_paged_exact(mlvdb_index* h, hipStream_t s, int64_t nq, int32_t k, int64_t* out_labels, float* out_dist,
+// nq_space = size of the query index space of Qpad/qaux and of the outputs; (qsel, nsel) = the queries to serve
+int run_paged_exact(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qaux, int64_t nq_space,
+                    const int32_t* qsel, int32_t nsel, int32_t k, int64_t* out_labels, float* out_dist,
                     int32_t* out_counts, double* out_d64) {
     const int32_t page = MLVDB_MAX_TOPK;
-    HIP_TRY(h, h->page_lab.ensure((size_t)nq * page * sizeof(int64_t)));
-    HIP_TRY(h, h->page_dist.ensure((size_t)nq * page * sizeof(float)));
-    HIP_TRY(h, h->page_cnt.ensure((size_t)nq * sizeof(int32_t)));
-    HIP_TRY(h, h->page_d64.ensure((size_t)nq * page * sizeof(double)));
-    HIP_TRY(h, h->cur_d.ensure((size_t)nq * sizeof(double)));
-    HIP_TRY(h, h->cur_l.ensure((size_t)nq * sizeof(int32_t)));
-    page_init_kernel<<<(unsigned)((nq + 255) / 256), 256, 0, s>>>(h->cur_d.as<double>(), h->cur_l.as<int32_t>(),
-                                                                  out_counts, nq);
+    HIP_TRY(h, h->page_lab.ensure((size_t)nq_space * page * sizeof(int64_t)));
+    HIP_TRY(h, h->page_dist.ensure((size_t)nq_space * page * sizeof(float)));
+    HIP_TRY(h, h->page_cnt.ensure((size_t)nq_space * sizeof(int32_t)));
+    HIP_TRY(h, h->page_d64.ensure((size_t)nq_space * page * sizeof(double)));
+    HIP_TRY(h, h->cur_d.ensure((size_t)nq_space * sizeof(double)));
+    HIP_TRY(h, h->cur_l.ensure((size_t)nq_space * sizeof(int32_t)));
+    page_init_kernel<<<(unsigned)((nsel + 255) / 256), 256, 0, s>>>(h->cur_d.as<double>(), h->cur_l.as<int32_t>(),
+                                                                    out_counts, qsel, nsel);
     HIP_TRY(h, hipGetLastError());
     for (int32_t offset = 0; offset < k; offset += page) {
         const int32_t kp = std::min(page, k - offset);
-        int rc = run_exact(h, s, h->qpad.as<float>(), h->qaux.as<double>(), (int32_t)nq, nullptr, 0, h->total, kp,
-                           h->page_lab.as<int64_t>(), h->page_dist.as<float>(), h->page_cnt.as<int32_t>(),
-                           h->page_d64.as<double>(), true, nullptr, h->cur_d.as<double>(), h->cur_l.as<int32_t>());
+        int rc = run_exact(h, s, Qpad, qaux, nsel, qsel, 0, h->total, kp, h->page_lab.as<int64_t>(),
+                           h->page_dist.as<float>(), h->page_cnt.as<int32_t>(), h->page_d64.as<double>(), true, nullptr,
+                           h->cur_d.as<double>(), h->cur_l.as<int32_t>());
         if (rc) return rc;
-        page_commit_kernel<<<(unsigned)nq, 64, 0, s>>>(h->page_lab.as<int64_t>(), h->page_dist.as<float>(),
-                                                       h->page_cnt.as<int32_t>(), h->page_d64.as<double>(), kp, offset,
-                                                       k, out_labels, out_dist, out_counts, out_d64,
-                                                       h->cur_d.as<double>(), h->cur_l.as<int32_t>());
+        page_commit_kernel<<<(unsigned)nsel, 64, 0, s>>>(h->page_lab.as<int64_t>(), h->page_dist.as<float>(),
+                                                         h->page_cnt.as<int32_t>(), h->page_d64.as<double>(), qsel, kp,
+                                                         offset, k, out_labels, out_dist, out_counts, out_d64,
+                                                         h->cur_d.as<double>(), h->cur_l.as<int32_t>());
         HIP_TRY(h, hipGetLastError());
     }
     return MLVDB_OK;
+}
+
+// Range fallback for queries whose candidate list overflowed: copy the nearest hits found by the paged
+// exact kNN into the range outputs and publish the exact counts.
+__global__ void range_fallback_commit_kernel(const int32_t* qsel, const uint32_t* exact_cnt, const int64_t* knn_lab,
+                                             const float* knn_dist, int32_t kmax, int32_t q0, int64_t cap_eff,
+                                             int64_t* out_labels, float* out_dist, int64_t* out_counts) {
+    const int q = qsel[blockIdx.x];
+    const int64_t n = exact_cnt[q];
+    const int64_t emit = n < cap_eff ? n : cap_eff;
+    for (int64_t i = threadIdx.x; i < emit; i += blockDim.x) {
+        out_labels[(int64_t)(q0 + q) * cap_eff + i] = knn_lab[(int64_t)q * kmax + i];
+        out_dist[(int64_t)(q0 + q) * cap_eff + i] = knn_dist[(int64_t)q * kmax + i];
+    }
+    if (threadIdx.x == 0) out_counts[q0 + q] = n;
+}
+
+__global__ void range_reset_kernel(uint32_t* cnt, const int32_t* qsel) { cnt[qsel[threadIdx.x]] = 0; }
+__global__ void range_resolve_kernel(uint32_t* overflow, const uint32_t* cnt, const int32_t* qsel) {
+    const int q = qsel[threadIdx.x];
+    overflow[q] = cnt[q] > (uint32_t)kCandCap ? 1u : 0u;
 }
 
 bool use_filter(const mlvdb_index* h, int64_t nq) {
@@ -622,7 +649,8 @@ int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64
                                  h->qaux.as<double>(), s));
     if (k > MLVDB_MAX_TOPK) {
         h->stats.strategy_used = MLVDB_STRATEGY_EXACT;
-        rc = run_paged_exact(h, s, nq, k, out_labels_device, out_dist_device, out_counts_device, out_dist64_device);
+        rc = run_paged_exact(h, s, h->qpad.as<float>(), h->qaux.as<double>(), nq, nullptr, (int32_t)nq, k, out_labels_device,
+                             out_dist_device, out_counts_device, out_dist64_device);
         if (rc) return rc;
     } else if (use_filter(h, nq)) {
         h->stats.strategy_used = MLVDB_STRATEGY_FILTER;
@@ -684,7 +712,7 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
     HIP_TRY(h, h->io_q.ensure((size_t)nq * h->dim * sizeof(float)));
     HIP_TRY(h, h->qpad.ensure((size_t)nq * h->ld * sizeof(float)));
     HIP_TRY(h, h->qaux.ensure((size_t)nq * sizeof(double)));
-    const int64_t cap_eff = std::min<int64_t>(capacity, kCandCap);
+    const int64_t cap_eff = std::min<int64_t>(capacity, MLVDB_MAX_TOPK_PAGED);  // most hits returned per query
     HIP_TRY(h, h->io_lab.ensure((size_t)nq * cap_eff * sizeof(int64_t)));
     HIP_TRY(h, h->io_dist.ensure((size_t)nq * cap_eff * sizeof(float)));
     HIP_TRY(h, h->io_cnt.ensure((size_t)nq * sizeof(int64_t)));
@@ -706,7 +734,7 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
             HIP_TRY(h, launch_filter_range_thr(fa, radius, s));
             HIP_TRY(h, launch_filter_scan(fa, 0, h->total, s));
         } else {
-            HIP_TRY(h, launch_exact_range_scan(fa, radius, s));
+            HIP_TRY(h, launch_exact_range_scan(fa, radius, nullptr, 0, s));
         }
         rc = scan_event(h, s, false);
         if (rc) return rc;
@@ -715,9 +743,47 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
         int32_t n_flagged = 0;
         rc = collect_overflow(h, s, fa, &n_flagged);
         if (rc) return rc;
-        if (n_flagged)
-            return fail(h, MLVDB_ERR_UNSUPPORTED,
-                        "range query admits more than 8192 candidate rows for some query; use a smaller radius");
+        if (n_flagged) {
+            // more candidates than list slots: exact hit counts from the exact range scan restricted to those
+            // queries, then their nearest min(count, capacity) hits from the paged exact kNN
+            h->stats.fallback_queries += n_flagged;
+            const int32_t* qsel = h->qsel.as<int32_t>();
+            range_reset_kernel<<<1, n_flagged, 0, s>>>(fa.cnt, qsel);
+            HIP_TRY(h, hipGetLastError());
+            HIP_TRY(h, launch_exact_range_scan(fa, radius, qsel, n_flagged, s));
+            HIP_TRY(h, hipMemcpyAsync(h->host_flags, fa.cnt, kFilterQueries * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+            // a query whose exact hits fit its list is complete now (the list holds exactly its hits): clear its
+            // flag so that the normal rescoring/sort handles it; only larger result sets are paged
+            int32_t still[kFilterQueries];
+            int32_t n_still = 0;
+            int64_t kmax = 1;
+            for (int q = 0; q < n; ++q) {
+                if (!h->host_overflow[q]) continue;
+                if (h->host_flags[q] > (uint32_t)kCandCap) {
+                    still[n_still++] = q;
+                    kmax = std::max<int64_t>(kmax, std::min<int64_t>(h->host_flags[q], cap_eff));
+                }
+            }
+            range_resolve_kernel<<<1, n_flagged, 0, s>>>(fa.overflow, fa.cnt, qsel);
+            HIP_TRY(h, hipGetLastError());
+            if (n_still) {
+                HIP_TRY(h, hipMemcpyAsync(h->qsel.p, still, n_still * sizeof(int32_t), hipMemcpyHostToDevice, s));
+                HIP_TRY(h, hipStreamSynchronize(s));  // `still` is on this stack frame
+                HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * kmax * sizeof(int64_t)));
+                HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * kmax * sizeof(float)));
+                HIP_TRY(h, h->seed_cnt.ensure(kFilterQueries * sizeof(int32_t)));
+                rc = run_paged_exact(h, s, fa.Qpad, fa.qaux, kFilterQueries, qsel, n_still, (int32_t)kmax,
+                                     h->seed_lab.as<int64_t>(), h->seed_dist.as<float>(), h->seed_cnt.as<int32_t>(),
+                                     nullptr);
+                if (rc) return rc;
+                range_fallback_commit_kernel<<<n_still, 256, 0, s>>>(qsel, fa.cnt, h->seed_lab.as<int64_t>(),
+                                                                     h->seed_dist.as<float>(), (int32_t)kmax, (int32_t)q0,
+                                                                     cap_eff, h->io_lab.as<int64_t>(),
+                                                                     h->io_dist.as<float>(), h->io_cnt.as<int64_t>());
+                HIP_TRY(h, hipGetLastError());
+            }
+        }
         HIP_TRY(h, launch_range_rescore(fa, radius, (int32_t)q0, cap_eff, h->io_lab.as<int64_t>(),
                                         h->io_dist.as<float>(), h->io_cnt.as<int64_t>(), s));
     }
@@ -729,13 +795,18 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
     HIP_TRY(h, hipMemcpy2DAsync(out_dist, (size_t)capacity * sizeof(float), h->io_dist.p, (size_t)cap_eff * sizeof(float),
                                 (size_t)cap_eff * sizeof(float), (size_t)nq, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
-    bool over = false;
+    bool over = false, hard = false;
     for (int64_t i = 0; i < nq; ++i) {
         out_counts[i] = counts[i];
         over |= counts[i] > capacity;
+        hard |= counts[i] > cap_eff && capacity > cap_eff;
     }
     rc = end_call(h, s);
     if (rc) return rc;
+    if (hard)
+        return fail(h, MLVDB_ERR_UNSUPPORTED,
+                    "range query: a query has more than MLVDB_MAX_TOPK_PAGED hits; out_counts holds the exact counts, the "
+                    "outputs the nearest MLVDB_MAX_TOPK_PAGED");
     if (over) return fail(h, MLVDB_ERR_OVERFLOW, "some query has more hits than `capacity`; out_counts holds the exact counts");
     return MLVDB_OK;
 }

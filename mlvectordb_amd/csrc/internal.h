@@ -112,7 +112,8 @@ hipError_t launch_filter_collect(const FilterArgs& a, int32_t* qsel, int32_t* nf
 // range variant: fixed per-query threshold from the radius, then exact rescoring with emit
 hipError_t launch_filter_range_thr(const FilterArgs& a, float radius, hipStream_t s);
 // exact candidate generator for range queries (any dim): appends every live row with dist <= radius
-hipError_t launch_exact_range_scan(const FilterArgs& a, float radius, hipStream_t s);
+// qsel/nsel: restrict to these queries of the pass (nullptr = all a.nq); cnt[q] ends as the exact hit count
+hipError_t launch_exact_range_scan(const FilterArgs& a, float radius, const int32_t* qsel, int32_t nsel, hipStream_t s);
 hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, int64_t capacity, int64_t* out_labels,
                                 float* out_dist, int64_t* out_counts, hipStream_t s);
 

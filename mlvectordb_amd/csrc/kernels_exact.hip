@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void exact_merge_kernel(const TopEntry* __rest
 // Range-query candidate generator: same scan, but every live row with dist <= radius is
 // appended to its query's candidate list (rescored and sorted by range_rescore_kernel).
 template <int SPACE>
-__global__ __launch_bounds__(512) void exact_range_kernel(const FilterArgs a, const double radius, const int nblk) {
+__global__ __launch_bounds__(512) void exact_range_kernel(const FilterArgs a, const double radius, const int nblk,
+                                                          const int32_t* qsel, const int32_t nsel) {
     constexpr int QT = 4, PW = 2, NW = 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* qs = reinterpret_cast<double*>(smem);  // [QT][ld]
@@ -176,8 +177,8 @@ __global__ __launch_bounds__(512) void exact_range_kernel(const FilterArgs a, co
     double qinv[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        const int q = blockIdx.y * QT + t;
-        qid[t] = q < a.nq ? q : -1;
+        const int sel = blockIdx.y * QT + t;
+        qid[t] = sel < nsel ? (qsel ? qsel[sel] : sel) : -1;
         for (int c = threadIdx.x; c < ld; c += NW * 64)
             qs[t * ld + c] = qid[t] >= 0 ? (double)a.Qpad[(int64_t)qid[t] * ld + c] : 0.0;
         qinv[t] = qid[t] >= 0 ? a.qaux[qid[t]] : 0.0;
@@ -224,8 +225,10 @@ __global__ __launch_bounds__(512) void exact_range_kernel(const FilterArgs a, co
     }
 }
 
-hipError_t launch_exact_range_scan(const FilterArgs& a, float radius, hipStream_t s) {
-    const int nqtiles = (a.nq + 3) / 4;
+hipError_t launch_exact_range_scan(const FilterArgs& a, float radius, const int32_t* qsel, int32_t nsel, hipStream_t s) {
+    if (!qsel) nsel = a.nq;
+    if (nsel <= 0) return hipSuccess;
+    const int nqtiles = (nsel + 3) / 4;
     const int64_t ntasks = ((a.total + 15) / 16 + 1) / 2;
     int64_t nblk = (ntasks + 7) / 8;
     const int64_t cap = std::max<int64_t>(8, 1024 / nqtiles);
@@ -239,7 +242,7 @@ hipError_t launch_exact_range_scan(const FilterArgs& a, float radius, hipStream_
         if (lds > 48 * 1024)                                                                                     \
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds);                                                                   \
-        if (e == hipSuccess) kern<<<dim3((unsigned)nblk, nqtiles), 512, lds, s>>>(a, (double)radius, (int)nblk); \
+        if (e == hipSuccess) kern<<<dim3((unsigned)nblk, nqtiles), 512, lds, s>>>(a, (double)radius, (int)nblk, qsel, nsel); \
     } while (0)
     switch (a.space) {
         case kSpaceL2: MLVDB_LAUNCH_ER(kSpaceL2); break;

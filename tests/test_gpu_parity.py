@@ -220,6 +220,25 @@ def test_range_query_matches_oracle(space, strategy, n, d):
         assert np.abs(gd - wd).max(initial=0.0) <= SCORE_ATOL
 
 
+@pytest.mark.parametrize("strategy,d", [("filter", 64), ("exact", 24)])
+def test_range_with_more_hits_than_candidate_slots(strategy, d):
+    """A radius that admits > 8192 rows for some queries: exact counts + nearest hits via the paged exact scan."""
+    rows, qs = make_case(93, 40000, d, 6)
+    dmat = exact_scan.exact_distances(qs, rows, "l2")
+    radius = float(np.float32(np.sort(dmat, axis=1)[:, 9000].min()))  # one query has 9001 hits, the rest fewer
+    eng = HipScanEngine(d, "l2", device=0, strategy=strategy)
+    try:
+        eng.append(rows)
+        got = eng.range(qs, radius, 100)  # capacity 100 < hits: the engine retries with the reported counts
+    finally:
+        eng.close()
+    want = exact_scan.range_query(qs, rows, radius, "l2")
+    assert max(len(w[0]) for w in want) > 8192
+    for (gl, gd), (wl, wd) in zip(got, want):
+        assert np.array_equal(gl, wl)
+        assert np.abs(gd - wd).max(initial=0.0) <= SCORE_ATOL
+
+
 def test_range_capacity_overflow_is_reported_then_resolved():
     rows, qs = make_case(91, 3000, 64, 4)
     eng = HipScanEngine(64, "l2", device=0)
