@@ -147,6 +147,110 @@ __global__ __launch_bounds__(256) void filter_range_thr_kernel(const FilterArgs 
 }
 
 // ------------------------------------------------------------------ the scan
+// Tile finished: bounds, admission test, rare appends.  acc[m][n] = bf16 dot products of this
+// lane's rows (16 m + 4 g + i, i = register component) with query 16 n + c16; rnv[m] = |x| of the rows;
+// row0 = first of this lane's rows; dump = this lane's column of a [4*kMT][64] LDS scratch per wave.
+template <int SPACE, int kMT, bool DENSE>
+__device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (&acc)[kMT][16], const float4 (&rnv)[kMT],
+                                              const int32_t row0, const int32_t base_row, const float e1,
+                                              const float* thr_l, const float* sq_l, float* dump, const int c16) {
+    // per-row constants: cosine  u = a*p0 + ec      (p0 = 1/(|x|+1e-30))
+    //                    ip      u = a + p0          (p0 = (e1+slack)|x|)
+    //                    l2      u = sq*(a + p0) + p1 (p1 = -|x|^2 (1-slack))
+    float p0[kMT][4], p1[kMT][4];
+    const float ec = e1 + 2.0f * kSlack;
+#pragma unroll
+    for (int m = 0; m < kMT; ++m) {
+        const float nr[4] = {rnv[m].x, rnv[m].y, rnv[m].z, rnv[m].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (SPACE == kSpaceCosine) {
+                p0[m][i] = 1.0f / (nr[i] + 1e-30f);
+                p1[m][i] = 0.f;
+            } else {
+                p0[m][i] = (e1 + kSlack) * nr[i];
+                p1[m][i] = SPACE == kSpaceL2 ? -(nr[i] * nr[i]) * (1.0f - kSlack) : 0.f;
+            }
+        }
+    }
+    auto bound = [&](int m, int i, int n, float sq) __attribute__((always_inline)) {
+        const float av = acc[m][n][i];
+        if (SPACE == kSpaceCosine) return __builtin_fmaf(av, p0[m][i], ec);
+        if (SPACE == kSpaceIp) return av + p0[m][i];
+        return __builtin_fmaf(sq, av + p0[m][i], p1[m][i]);
+    };
+    if (DENSE) {
+        // seeding pass: every (query,row) bound of these tiles goes straight into the candidate
+        // lists, slot = row - first row of the pass (the caller sets cnt and runs the update kernel)
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
+            CandEntry* dst = a.cand + (int64_t)(16 * n + c16) * kCandCap + (row0 - base_row);
+#pragma unroll
+            for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    CandEntry e;
+                    e.u = bound(m, i, n, sq);
+                    e.row = row0 + 16 * m + i;
+                    dst[16 * m + i] = e;
+                }
+        }
+        return;
+    }
+    // pass 1: quick reject per query tile on the maximum bound (NaN bounds of tombstoned rows are
+    // ignored by v_max); the per-row mask and one slot reservation (atomic) per lane only where it
+    // is needed.  The atomics' results are not touched before pass 2: all of them are in flight.
+    uint32_t packed[16];  // bits 0..11 hit mask, bits 12.. first reserved slot (clamped)
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        __builtin_amdgcn_sched_barrier(0);  // keep only one query tile's scores live at a time
+        const float thr = thr_l[16 * n + c16];
+        const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
+        float mx = -3.4e38f;
+#pragma unroll
+        for (int m = 0; m < kMT; ++m)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mx = __builtin_fmaxf(mx, bound(m, i, n, sq));
+        uint32_t mask = 0, slot = 0;
+        if (__ballot(mx >= thr)) {
+#pragma unroll
+            for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mask |= bound(m, i, n, sq) >= thr ? 1u << (4 * m + i) : 0u;
+            if (mask) slot = atomicAdd(&a.cnt[16 * n + c16], (uint32_t)__popc(mask));
+        }
+        packed[n] = mask | (min(slot, (uint32_t)kCandCap) << 12);
+    }
+    // pass 2 (rare): write the admitted (bound, row) pairs into the reserved slots
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        if (__ballot((packed[n] & 0xfffu) != 0)) {
+            const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
+#pragma unroll
+            for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dump[(4 * m + i) * 64] = bound(m, i, n, sq);
+            const int q = 16 * n + c16;
+            uint32_t mask = packed[n] & 0xfffu;
+            uint32_t slot = packed[n] >> 12;
+            while (mask) {
+                const int j = __builtin_ctz(mask);
+                mask &= mask - 1;
+                if (slot < (uint32_t)kCandCap) {
+                    CandEntry e;
+                    e.u = dump[j * 64];
+                    e.row = row0 + 16 * (j >> 2) + (j & 3);
+                    a.cand[(int64_t)q * kCandCap + slot] = e;
+                } else {
+                    a.overflow[q] = 1u;
+                }
+                ++slot;
+            }
+        }
+    }
+}
+
 // One workgroup = 4 waves (one per SIMD, so each wave may use the whole 512-entry register
 // file) = one 192-row tile (12 panels) against all 256 queries; wave w owns panels 3w..3w+2,
 // i.e. a 48 x 256 block of scores in 192 accumulator registers (AGPRs).  (64 rows per wave
@@ -260,107 +364,11 @@ __global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(
 #pragma unroll
     for (int b = 0; b < R; ++b) load_x(xr[b]);
 
-    // Tile finished: bounds, admission test, rare appends.
     auto epilogue = [&](const int64_t ti) __attribute__((always_inline)) {
         if (kMT == 2 && R > 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // XDL write -> VALU read wait states
-        const int32_t row0 = (int32_t)(tile_of(ti) * kFilterTileRows) + wave * (16 * kMT) + g * 4;
-        float* dump = hit_l + wave * (4 * kMT * 64) + lane;  // [4*kMT][64] floats per wave
-        // per-row constants: cosine  u = a*p0 + ec      (p0 = 1/(|x|+1e-30))
-        //                    ip      u = a + p0          (p0 = (e1+slack)|x|)
-        //                    l2      u = sq*(a + p0) + p1 (p1 = -|x|^2 (1-slack))
-        float p0[kMT][4], p1[kMT][4];
-        const float ec = e1 + 2.0f * kSlack;
-#pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-            const float nr[4] = {rnv[m].x, rnv[m].y, rnv[m].z, rnv[m].w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (SPACE == kSpaceCosine) {
-                    p0[m][i] = 1.0f / (nr[i] + 1e-30f);
-                    p1[m][i] = 0.f;
-                } else {
-                    p0[m][i] = (e1 + kSlack) * nr[i];
-                    p1[m][i] = SPACE == kSpaceL2 ? -(nr[i] * nr[i]) * (1.0f - kSlack) : 0.f;
-                }
-            }
-        }
-        auto bound = [&](int m, int i, int n, float sq) __attribute__((always_inline)) {
-            const float av = acc[m][n][i];
-            if (SPACE == kSpaceCosine) return __builtin_fmaf(av, p0[m][i], ec);
-            if (SPACE == kSpaceIp) return av + p0[m][i];
-            return __builtin_fmaf(sq, av + p0[m][i], p1[m][i]);
-        };
-        if (DENSE) {
-            // seeding pass: every (query,row) bound of these tiles goes straight into the candidate
-            // lists, slot = row - first row of the pass (the caller sets cnt and runs the update kernel)
-            const int32_t base_row = (int32_t)(tile_begin * kFilterTileRows);
-#pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
-                CandEntry* dst = a.cand + (int64_t)(16 * n + c16) * kCandCap + (row0 - base_row);
-#pragma unroll
-                for (int m = 0; m < kMT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        CandEntry e;
-                        e.u = bound(m, i, n, sq);
-                        e.row = row0 + 16 * m + i;
-                        dst[16 * m + i] = e;
-                    }
-            }
-            return;
-        }
-        // pass 1: quick reject per query tile on the maximum bound (NaN bounds of tombstoned rows are
-        // ignored by v_max); the per-row mask and one slot reservation (atomic) per lane only where it
-        // is needed.  The atomics' results are not touched before pass 2: all of them are in flight.
-        uint32_t packed[16];  // bits 0..11 hit mask, bits 12.. first reserved slot (clamped)
-#pragma unroll
-        for (int n = 0; n < 16; ++n) {
-            __builtin_amdgcn_sched_barrier(0);  // keep only one query tile's scores live at a time
-            const float thr = thr_l[16 * n + c16];
-            const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
-            float mx = -3.4e38f;
-#pragma unroll
-            for (int m = 0; m < kMT; ++m)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) mx = __builtin_fmaxf(mx, bound(m, i, n, sq));
-            uint32_t mask = 0, slot = 0;
-            if (__ballot(mx >= thr)) {
-#pragma unroll
-                for (int m = 0; m < kMT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) mask |= bound(m, i, n, sq) >= thr ? 1u << (4 * m + i) : 0u;
-                if (mask) slot = atomicAdd(&a.cnt[16 * n + c16], (uint32_t)__popc(mask));
-            }
-            packed[n] = mask | (min(slot, (uint32_t)kCandCap) << 12);
-        }
-        // pass 2 (rare): write the admitted (bound, row) pairs into the reserved slots
-#pragma unroll
-        for (int n = 0; n < 16; ++n) {
-            if (__ballot((packed[n] & 0xfffu) != 0)) {
-                const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
-#pragma unroll
-                for (int m = 0; m < kMT; ++m)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) dump[(4 * m + i) * 64] = bound(m, i, n, sq);
-                const int q = 16 * n + c16;
-                uint32_t mask = packed[n] & 0xfffu;
-                uint32_t slot = packed[n] >> 12;
-                while (mask) {
-                    const int j = __builtin_ctz(mask);
-                    mask &= mask - 1;
-                    if (slot < (uint32_t)kCandCap) {
-                        CandEntry e;
-                        e.u = dump[j * 64];
-                        e.row = row0 + 16 * (j >> 2) + (j & 3);
-                        a.cand[(int64_t)q * kCandCap + slot] = e;
-                    } else {
-                        a.overflow[q] = 1u;
-                    }
-                    ++slot;
-                }
-            }
-        }
+        scan_epilogue<SPACE, kMT, DENSE>(a, acc, rnv, (int32_t)(tile_of(ti) * kFilterTileRows) + wave * (16 * kMT) + g * 4,
+                                         (int32_t)(tile_begin * kFilterTileRows), e1, thr_l, sq_l,
+                                         hit_l + wave * (4 * kMT * 64) + lane, c16);
     };
 
     for (int64_t ti = 0; ti < my_tiles; ++ti) {
@@ -436,6 +444,114 @@ __global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(
             }
         }
         epilogue(ti);
+    }
+}
+
+// ------------------------------------------------------------------ the scan, hand-written for gfx950
+// Same geometry, data flow and bounds as filter_scan_kernel<.., kMT = 2, XB = true> above, but the
+// whole body -- prologue, persistent tile loop, k-loop, admission test, append path -- is the
+// generated assembly of tools/gen_scan_asm.py (scan_asm_<space>_nw<NW>_r<R>.inc; the schedule and
+// the reasons are documented there).  This wrapper only computes addresses.
+// Requires the bf16 shadow.  Tile = NW*32 rows; the 2*ld/64 k-steps of a tile must be a multiple of R.
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+
+template <int SPACE, int R, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void filter_scan_asm_kernel(const FilterArgs a, const int64_t tile_begin,
+                                                                      const int64_t tile_end, const float e1) {
+    constexpr int kThreads = NW * 64;
+    constexpr int kQPer = 1024 / kThreads;  // uint4 of a Q half-chunk moved per thread
+    constexpr int kTileRowsV = NW * 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][32 KiB] Q chunks at LDS offset 0, thr[256], qscale[256]
+    float* thr_l = reinterpret_cast<float*>(smem + 2 * kChunkVec * sizeof(uint4));
+    float* sq_l = thr_l + kFilterQueries;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const int c16 = lane & 15;
+    const int nkc = a.ld / kFilterChunkK;
+    for (int t = threadIdx.x; t < kFilterQueries; t += kThreads) {
+        thr_l[t] = a.thr[t];
+        sq_l[t] = a.qscale[t];
+    }
+    const int64_t ntiles_all = tile_end - tile_begin;
+    const int64_t my_tiles = ntiles_all > blockIdx.x ? (ntiles_all - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    if (my_tiles == 0) return;
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
+    if (lds_base != 0) __builtin_trap();  // the assembly toggles the Q buffers with xor 0x8000
+
+    const uint32_t chunk_bytes = (uint32_t)(kChunkVec * sizeof(uint4));
+    const uint32_t pb = (uint32_t)a.ld * 32u;  // bytes of one bf16 panel (16 rows)
+    const uint32_t wbytes = 2 * pb;            // this wave's two panels of a tile
+    const uint64_t tile_bytes = (uint64_t)NW * wbytes;
+    const int64_t first_tile = tile_begin + blockIdx.x;
+    const uint64_t xbase = reinterpret_cast<uint64_t>(a.Xb) + (uint64_t)first_tile * tile_bytes + (uint64_t)wave * wbytes;
+    const uint64_t xstride = (uint64_t)gridDim.x * tile_bytes;
+    const uint64_t rnbase = reinterpret_cast<uint64_t>(a.rn + first_tile * kTileRowsV + wave * 32);
+    const uint32_t xlo = (uint32_t)xbase, xhi = (uint32_t)(xbase >> 32) & 0xffffu;
+    const uint32_t xslo = (uint32_t)xstride, xshi = (uint32_t)(xstride >> 32);
+    const uint32_t rnlo = (uint32_t)rnbase, rnhi = (uint32_t)(rnbase >> 32) & 0xffffu;
+    const uint32_t rnstride = gridDim.x * (uint32_t)(kTileRowsV * 4);
+    const uint32_t row0 = (uint32_t)(first_tile * kTileRowsV);
+    const uint32_t rowstride = gridDim.x * (uint32_t)kTileRowsV;
+    const uint32_t ntiles = (uint32_t)my_tiles;
+    const uint32_t qbytes = (uint32_t)nkc * chunk_bytes;
+    const uint32_t nb = (uint32_t)(2 * nkc / R);
+    const uint32_t qcur0 = (uint32_t)(2 % nkc) * chunk_bytes;
+    const uint32_t qc1 = (uint32_t)(1 % nkc) * chunk_bytes;
+    u32x4s qsrd;
+    {
+        const uint64_t qb = reinterpret_cast<uint64_t>(a.qimg);
+        qsrd[0] = (uint32_t)qb;
+        qsrd[1] = (uint32_t)(qb >> 32) & 0xffffu;
+        qsrd[2] = qbytes;
+        qsrd[3] = 0x00020000u;
+    }
+    const float k0 = SPACE == kSpaceCosine ? e1 + 2.0f * kSlack : e1 + kSlack;
+    const float k1 = -(1.0f - kSlack);
+    const uint32_t* cntb = a.cnt;
+    const CandEntry* candb = a.cand;
+    const uint32_t* ovfb = a.overflow;
+    const uint32_t lane16 = lane * 16;
+    const uint32_t qvoff = (uint32_t)wave * 2048u + lane16;  // this thread's uint4 of fragment piece 2*wave + h
+    const uint32_t rnvoff = g * 16;
+    const uint32_t thra = (uint32_t)(2 * chunk_bytes) + c16 * 4;
+    const uint32_t qoff4 = c16 * 4;
+    const uint32_t qc64k = (uint32_t)c16 * (uint32_t)(kCandCap * sizeof(CandEntry));
+    const uint32_t crow = (uint32_t)wave * 32u + g * 4;
+    static_assert(kCandCap * sizeof(CandEntry) == 65536 && kCandCap == 8192, "the assembly hard-codes the list geometry");
+
+    u32x4s xring[R * 2], qsa[kQPer], qsb[kQPer], qt[4];
+    float vr[8], vp[8], vu[8];
+    uint32_t ve[12], ldr, ldw;
+    uint32_t s_xso0, s_xso1, s_qcur, s_cnt, s_st0, s_tl, s_trow, s_sn64, s_sn1m;
+    uint64_t s_sx0, s_sx1, s_sx2;
+    (void)vp;
+    (void)k1;
+    if constexpr (SPACE == kSpaceL2 && NW == 4 && R == 4) {
+#include "scan_asm_l2_nw4_r4.inc"
+    } else if constexpr (SPACE == kSpaceL2 && NW == 4 && R == 2) {
+#include "scan_asm_l2_nw4_r2.inc"
+    } else if constexpr (SPACE == kSpaceCosine && NW == 4 && R == 4) {
+#include "scan_asm_cosine_nw4_r4.inc"
+    } else if constexpr (SPACE == kSpaceCosine && NW == 4 && R == 2) {
+#include "scan_asm_cosine_nw4_r2.inc"
+    } else if constexpr (SPACE == kSpaceIp && NW == 4 && R == 4) {
+#include "scan_asm_ip_nw4_r4.inc"
+    } else if constexpr (SPACE == kSpaceIp && NW == 4 && R == 2) {
+#include "scan_asm_ip_nw4_r2.inc"
+    } else if constexpr (SPACE == kSpaceL2 && NW == 8 && R == 4) {
+#include "scan_asm_l2_nw8_r4.inc"
+    } else if constexpr (SPACE == kSpaceL2 && NW == 8 && R == 2) {
+#include "scan_asm_l2_nw8_r2.inc"
+    } else if constexpr (SPACE == kSpaceCosine && NW == 8 && R == 4) {
+#include "scan_asm_cosine_nw8_r4.inc"
+    } else if constexpr (SPACE == kSpaceCosine && NW == 8 && R == 2) {
+#include "scan_asm_cosine_nw8_r2.inc"
+    } else if constexpr (SPACE == kSpaceIp && NW == 8 && R == 4) {
+#include "scan_asm_ip_nw8_r4.inc"
+    } else {
+#include "scan_asm_ip_nw8_r2.inc"
     }
 }
 
@@ -827,6 +943,28 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
     return hipGetLastError();
 }
 
+template <int SPACE, int R, int NW>
+static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
+    constexpr int tile_rows = NW * 32;
+    const int64_t tile_begin = row_begin / tile_rows;
+    const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
+    if (tile_end <= tile_begin) return hipSuccess;
+    const size_t lds = 2 * kChunkVec * sizeof(uint4) + 2 * kFilterQueries * sizeof(float);
+    const int64_t ntiles = tile_end - tile_begin;
+    const int max_grid = 256 * (8 / NW);  // two waves per SIMD on every CU
+    const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
+    auto kern = filter_scan_asm_kernel<SPACE, R, NW>;
+    static bool configured = false;  // per instantiation
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end, filter_e1(a.ld));
+    return hipGetLastError();
+}
+
 // Geometry: 2 panels per wave (128 accumulators), two 4-wave workgroups per CU.  Scanning the
 // bf16 shadow needs 4 VGPRs per k-step in flight, so 4-8 k-steps rotate; scanning fp32 needs 16,
 // so only 2 fit (3 panels x 3 k-steps at one workgroup per CU is kept for comparison).
@@ -835,6 +973,15 @@ template <int SPACE>
 static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
     // steps per tile = 2 * (ld / 64) must be a multiple of lcm(R, 2)
     const int nkc = a.ld / kFilterChunkK;
+    if (a.Xb && env_int("MLVDB_SCAN_ASM", 1)) {
+        // hand-scheduled k-loop; ring depth 4 needs an even number of chunks per tile
+        if (env_int("MLVDB_SCAN_NW", 4) == 8) {
+            if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8>(a, row_begin, row_end, s);
+            return launch_scan_asm<SPACE, 2, 8>(a, row_begin, row_end, s);
+        }
+        if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4>(a, row_begin, row_end, s);
+        return launch_scan_asm<SPACE, 2, 4>(a, row_begin, row_end, s);
+    }
     if (a.Xb) {
         const int want_r = env_int("MLVDB_SCAN_R", 2);
         if (env_int("MLVDB_SCAN_MT", 2) == 3) {

@@ -1,0 +1,453 @@
+#!/usr/bin/env python3
+"""Generates the gfx950 assembly of the filter scan (bf16 MFMA bounds of all rows x 256 queries).
+
+Output: mlvectordb_amd/csrc/scan_asm_{space}_nw{NW}_r{R}.inc -- ONE `asm volatile(...)` statement,
+the whole body of filter_scan_asm_kernel (kernels_filter.hip): prologue, the persistent loop over
+the workgroup's row tiles, the k-loop of a tile, the admission test and the (rare) append path.
+
+Why assembly: hipcc's schedule of the same loop drains the X prefetch every two k-steps
+(vmcnt(0) + register copies at the back edge), reads each B fragment right before its MFMAs, and
+spills around the epilogue; values that are the targets of loads still in flight cannot be handed
+through compiler-managed code at all.  Here everything that is in flight stays inside one
+statement, and the waits are computed by simulating the two in-order queues (vmcnt: buffer/global
+operations; lgkmcnt: LDS operations).
+
+Per wave: MT = 2 row panels (32 rows) x 16 query tiles = 32 accumulators of 16x16 in a[0:127].
+(Two waves per SIMD: hipcc splits the 256 registers 128 VGPR / 128 AGPR as soon as a kernel
+touches an AGPR, so the accumulators take the AGPRs and everything else lives in <= 128 VGPRs.)
+  * X (bf16 shadow panels, HBM): buffer_load_dwordx4 into a ring of R k-steps that are the MFMA A
+    operands; a slot is refilled right after its last MFMA with the k-step R ahead -- the last R
+    k-steps of a tile fetch the first R of the workgroup's next tile through a second descriptor,
+    so the stream never stops, not even during the admission test.
+  * Q (bf16 image, L2): 64-column chunks, double buffered in LDS; during chunk c every thread
+    writes its share of chunk c+1 (fetched one chunk earlier into two register sets) into the other
+    buffer and fetches its share of chunk c+2; one s_barrier per chunk.  vmcnt completes in order,
+    so waiting for a Q set also waits for every X refill issued before that set's fetch: the
+    fetches sit just BEFORE the refills, which gives each refill about three k-steps.
+  * the 32 B fragments of a chunk are one software-pipelined stream: ds_read_b128 runs QD
+    fragments ahead of the two MFMAs that consume a fragment.
+  * admission test per query tile: 8 bounds per lane (same arithmetic as scan_epilogue), their
+    maximum against the threshold; only if some lane passes, an out-of-line routine reserves
+    slots (one atomic per lane) and stores the (bound, row) pairs.  That routine waits for its
+    atomic with vmcnt(0); its memory operations are younger than every prefetch, so the counted
+    waits elsewhere only become more conservative.
+"""
+import argparse
+from pathlib import Path
+
+MT = 2
+CHUNK_BYTES = 0x8000      # 256 queries x 64 columns x 2 B
+CAND_CAP = 8192           # kCandCap
+SPACES = {"l2": 0, "cosine": 1, "ip": 2}
+
+
+class Sched:
+    """Instruction list + in-order queue simulation for counted waits."""
+
+    def __init__(self):
+        self.lines = []
+        self.vm = []
+        self.lg = []
+        self.vm_done = 0
+        self.lg_done = 0
+        self.recording = True
+
+    def emit(self, text):
+        if self.recording:
+            self.lines.append(text)
+
+    def vmem(self, text, tag):
+        self.emit(text)
+        self.vm.append(tag)
+
+    def lds(self, text, tag):
+        self.emit(text)
+        self.lg.append(tag)
+
+    def _last(self, q, tag):
+        for i in range(len(q) - 1, -1, -1):
+            if q[i] == tag:
+                return i
+        if not self.recording:
+            return -1      # warm-up pass: nothing older exists yet
+        raise KeyError(tag)
+
+    def need_vm(self, *tags):
+        idx = max(self._last(self.vm, t) for t in tags)
+        if idx < self.vm_done:
+            return
+        n = len(self.vm) - 1 - idx
+        assert n <= 63, n
+        self.emit(f"s_waitcnt vmcnt({n})")
+        self.vm_done = idx + 1
+
+    def need_lg(self, *tags):
+        idx = max(self._last(self.lg, t) for t in tags)
+        if idx < self.lg_done:
+            return
+        n = min(len(self.lg) - 1 - idx, 15)
+        self.emit(f"s_waitcnt lgkmcnt({n})")
+        self.lg_done = max(self.lg_done, len(self.lg) - n)
+
+    def drain_lg(self):
+        if self.lg_done < len(self.lg):
+            self.emit("s_waitcnt lgkmcnt(0)")
+            self.lg_done = len(self.lg)
+
+
+def acc(m, n):
+    b = (m * 16 + n) * 4
+    return f"a[{b}:{b + 3}]"
+
+
+def ring(b, m):
+    return f"%[x{b * MT + m}]"
+
+
+# explicit scalar registers (listed as clobbers): descriptors need sub-register arithmetic
+XCUR, XNEXT, RNS, RET = "s[80:83]", "s[84:87]", "s[88:91]", "s[92:93]"
+
+
+def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last):
+    """One 64-column chunk = 2 k-steps = 32 fragments x 2 MFMAs."""
+    s.emit("v_xor_b32 %[ldr], 0x8000, %[ldr]")
+    s.emit("v_xor_b32 %[ldw], 0x8000, %[ldw]")
+
+    def read(f):
+        h, n = f >> 4, f & 15
+        s.lds(f"ds_read_b128 %[t{f % QD}], %[ldr] offset:{n * 2048 + h * 1024}", ("rd", f))
+
+    def refill(h):
+        step = step0 + h
+        b = step % R
+        for m in range(MT):
+            if last:
+                so = "0" if m == 0 else "%[pb]"
+                off = f" offset:{step * 1024}" if step else ""
+                s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XNEXT}, {so} offen{off}", ("x", b, m))
+            else:
+                s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, %[xso{m}] offen", ("x", b, m))
+        if not last:
+            s.emit("s_add_u32 %[xso0], %[xso0], 0x400")
+            s.emit("s_add_u32 %[xso1], %[xso1], 0x400")
+
+    # Staging plan, fragment index -> action.  Set qb (first halves) is written and re-fetched just
+    # before the ring refill that follows fragment 15, set qa (second halves) just before the one
+    # that follows fragment 31 (see the module docstring).
+    plan = {}
+    for setname, half, f in (("qb", 0, 16 - 2 * KQ), ("qa", 1, 32 - 2 * KQ)):
+        for i in range(KQ):
+            plan[f] = ("w", setname, i, half)
+            f += 1
+        for i in range(KQ):
+            plan[f] = ("l", setname, i, half)
+            f += 1
+
+    for f0 in range(QD):
+        read(f0)
+    for f in range(32):
+        h, n = f >> 4, f & 15
+        b = (step0 + h) % R
+        if n == 0:
+            s.need_vm(*[("x", b, m) for m in range(MT)])
+        s.need_lg(("rd", f))
+        for m in range(MT):
+            c = "0" if (zero_first and h == 0) else acc(m, n)
+            s.emit(f"v_mfma_f32_16x16x32_bf16 {acc(m, n)}, {ring(b, m)}, %[t{f % QD}], {c}")
+        if f + QD < 32:
+            read(f + QD)
+        if f in plan:
+            kind, setname, i, half = plan[f]
+            reg = f"%[{setname}{i}]"
+            const = i * NW * 2048 + half * 1024
+            if kind == "w":
+                s.need_vm((setname, i))
+                s.lds(f"ds_write_b128 %[ldw], {reg} offset:{const}", ("wr", setname, i))
+            else:
+                s.emit(f"s_add_u32 %[st0], %[qcur], 0x{const:x}")
+                s.vmem(f"buffer_load_dwordx4 {reg}, %[qvoff], %[qsrd], %[st0] offen", (setname, i))
+        if n == 15:
+            refill(h)
+    # advance the Q cursor (chunk c+2 -> c+3, wrapping) and publish the chunk just staged
+    s.emit("s_add_u32 %[qcur], %[qcur], 0x8000")
+    s.emit("s_cmp_eq_u32 %[qcur], %[qbytes]")
+    s.emit("s_cselect_b32 %[qcur], 0, %[qcur]")
+    s.drain_lg()
+    s.emit("s_barrier")
+
+
+def gen_body(s, R, QD, KQ, NW, first, last):
+    if last:
+        # |x| of this lane's 8 rows (rows 4g..4g+3 of both panels) for the admission test
+        for j in range(8):
+            off = (j >> 2) * 64 + (j & 3) * 4
+            s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{off}" if off else ""),
+                   ("rn", j))
+    for ch in range(R // 2):
+        gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last)
+    if last:
+        s.need_vm(*[("rn", j) for j in range(8)])
+
+
+def body_lines(R, QD, KQ, NW, first, last):
+    s = Sched()
+    s.recording = False
+    for _ in range(2):   # history: every predecessor issues this pattern of memory operations
+        gen_body(s, R, QD, KQ, NW, False, False)
+    s.recording = True
+    gen_body(s, R, QD, KQ, NW, first, last)
+    return s.lines
+
+
+def gen_admission(space):
+    """After the k-loop of a tile: bounds, quick reject per query tile, calls into .Lslow."""
+    s = Sched()
+    a = s.emit
+    a("s_nop 15")   # XDL write -> v_accvgpr_read of the accumulators
+    a("s_nop 7")
+    # per-row constants (scan_epilogue): cosine p0 = 1/(|x|+1e-30); ip p0 = (e1+slack)|x|;
+    # l2 p0 = (e1+slack)|x|, p1 = -|x|^2 (1-slack)
+    for j in range(8):
+        if space == "cosine":
+            a(f"v_add_f32 %[r{j}], 0x0da24260, %[r{j}]")   # + 1e-30f
+            a(f"v_rcp_f32 %[r{j}], %[r{j}]")
+        else:
+            if space == "l2":
+                a(f"v_mul_f32 %[p{j}], %[r{j}], %[r{j}]")
+                a(f"v_mul_f32 %[p{j}], %[k1], %[p{j}]")    # k1 = -(1 - slack)
+            a(f"v_mul_f32 %[r{j}], %[k0], %[r{j}]")        # k0 = e1 + slack
+    thr = lambda n: f"%[e{n & 1}]"
+    sq = lambda n: f"%[e{2 + (n & 1)}]"
+
+    def fetch(n):
+        s.lds(f"ds_read_b32 {thr(n)}, %[thra] offset:{n * 64}", ("thr", n))
+        if space == "l2":
+            s.lds(f"ds_read_b32 {sq(n)}, %[thra] offset:{1024 + n * 64}", ("sq", n))
+
+    fetch(0)
+    for n in range(16):
+        if n + 1 < 16:
+            fetch(n + 1)
+        for j in range(8):
+            m, i = j >> 2, j & 3
+            a(f"v_accvgpr_read_b32 %[u{j}], a{(m * 16 + n) * 4 + i}")
+        if space == "l2":
+            s.need_lg(("sq", n))
+        for j in range(8):
+            if space == "cosine":
+                a(f"v_fma_f32 %[u{j}], %[u{j}], %[r{j}], %[k0]")    # k0 = e1 + 2 slack
+            elif space == "ip":
+                a(f"v_add_f32 %[u{j}], %[u{j}], %[r{j}]")
+            else:
+                a(f"v_add_f32 %[u{j}], %[u{j}], %[r{j}]")
+                a(f"v_fma_f32 %[u{j}], {sq(n)}, %[u{j}], %[p{j}]")
+        a("v_max3_f32 %[e4], %[u0], %[u1], %[u2]")
+        a("v_max3_f32 %[e5], %[u3], %[u4], %[u5]")
+        a("v_max3_f32 %[e4], %[u6], %[u7], %[e4]")
+        a("v_max_f32 %[e4], %[e4], %[e5]")
+        s.need_lg(("thr", n))
+        a(f"v_cmp_ge_f32 vcc, %[e4], {thr(n)}")
+        a(f"s_cbranch_vccnz .Lhit{n}_%=")
+        a(f".Lback{n}_%=:")
+    return s.lines
+
+
+def gen_hit_stubs():
+    out = []
+    for n in range(16):
+        out += [f".Lhit{n}_%=:",
+                f"v_mov_b32 %[e6], %[e{n & 1}]",          # the threshold of this query tile
+                f"s_movk_i32 %[sn64], 0x{n * 64:x}",      # byte offset of query 16n in cnt[] / overflow[]
+                f"s_mov_b32 %[sn1m], 0x{n << 20:x}",      # byte offset of query 16n's list in cand[]
+                f"s_getpc_b64 {RET}",
+                "s_add_u32 s92, s92, 12",                 # return to the instruction after the branch below
+                "s_addc_u32 s93, s93, 0",
+                "s_branch .Lslow_%=",
+                f"s_branch .Lback{n}_%="]
+    return out
+
+
+def gen_slow():
+    """u0..u7 = bounds of this lane's 8 rows for query 16n + c16, e6 = threshold."""
+    o = [".Lslow_%=:", "v_mov_b32 %[e7], 0"]
+    for j in range(8):
+        o += [f"v_cmp_ge_f32 vcc, %[u{j}], %[e6]",
+              "v_cndmask_b32_e64 %[e8], 0, 1, vcc",
+              f"v_lshl_or_b32 %[e7], %[e8], {j}, %[e7]"]            # e7 = hit mask
+    o += ["v_cmp_ne_u32 vcc, 0, %[e7]",
+          "s_and_saveexec_b64 %[sx0], vcc",
+          "s_cbranch_execz .Lslowend_%=",
+          "v_bcnt_u32_b32 %[e8], %[e7], 0",
+          "v_add_u32 %[e9], %[sn64], %[qoff4]",                     # e9 = 4 * query
+          "global_atomic_add %[e10], %[e9], %[e8], %[cntb] sc0",    # e10 = first reserved slot
+          "v_add_u32 %[e11], %[trow], %[crow]",                     # e11 = this lane's first row
+          "s_waitcnt vmcnt(0)"]
+    for j in range(8):
+        o += [f"v_and_b32 %[e8], 0x{1 << j:x}, %[e7]",
+              "v_cmp_ne_u32 vcc, 0, %[e8]",
+              "s_and_saveexec_b64 %[sx1], vcc",
+              f"s_cbranch_execz .Lskip{j}_%="]
+        if j:
+            o += [f"v_and_b32 %[e8], 0x{(1 << j) - 1:x}, %[e7]",
+                  "v_bcnt_u32_b32 %[e8], %[e8], %[e10]"]            # e8 = this entry's slot
+        else:
+            o += ["v_mov_b32 %[e8], %[e10]"]
+        o += [f"v_cmp_gt_u32 vcc, 0x{CAND_CAP:x}, %[e8]",
+              "s_and_saveexec_b64 %[sx2], vcc",
+              "v_lshl_add_u32 %[e8], %[e8], 3, %[qc64k]",
+              "v_add_u32 %[e8], %[sn1m], %[e8]",                    # byte offset of cand[q][slot]
+              f"global_store_dword %[e8], %[u{j}], %[candb]",
+              f"v_add_u32 %[e5], {16 * (j >> 2) + (j & 3)}, %[e11]",
+              "global_store_dword %[e8], %[e5], %[candb] offset:4",
+              "s_andn2_b64 exec, %[sx2], exec",                     # lanes whose slot is past the list
+              "v_mov_b32 %[e5], 1",
+              "global_store_dword %[e9], %[e5], %[ovfb]",
+              f".Lskip{j}_%=:",
+              "s_mov_b64 exec, %[sx1]"]
+    o += [".Lslowend_%=:", "s_mov_b64 exec, %[sx0]", f"s_setpc_b64 {RET}"]
+    return o
+
+
+def generate(space, R, QD, NW):
+    assert R in (2, 4) and 2 <= QD <= 4
+    KQ = 1024 // (NW * 64)
+    out = []
+    a = out.append
+    # ---- descriptors and per-workgroup state
+    a("s_mov_b32 s80, %[xlo]")
+    a("s_mov_b32 s81, %[xhi]")
+    a("s_mov_b32 s82, %[wbytes]")
+    a("s_mov_b32 s83, 0x00020000")
+    a("s_mov_b32 s86, s82")
+    a("s_mov_b32 s87, s83")
+    a("s_mov_b32 s88, %[rnlo]")
+    a("s_mov_b32 s89, %[rnhi]")
+    a("s_movk_i32 s90, 0x80")          # 32 rows x 4 B
+    a("s_mov_b32 s91, s83")
+    a("s_mov_b32 %[tl], %[ntiles]")
+    a("s_mov_b32 %[trow], %[row0]")
+    a("v_add_u32 %[ldr], 0x8000, %[lane16]")   # the first chunk toggles it to buffer 0
+    a("v_mov_b32 %[ldw], %[qvoff]")            # ... and this one to buffer 1
+    # ---- prologue: Q chunk 0 -> LDS buffer 0, chunk 1 -> the sets, k-steps 0..R-1 -> the ring
+    for half, setname in ((0, "qb"), (1, "qa")):
+        for i in range(KQ):
+            a(f"s_movk_i32 %[st0], 0x{i * NW * 2048 + half * 1024:x}")
+            a(f"buffer_load_dwordx4 %[{setname}{i}], %[qvoff], %[qsrd], %[st0] offen")
+    for b in range(R):
+        for m in range(MT):
+            so = "0" if m == 0 else "%[pb]"
+            off = f" offset:{b * 1024}" if b else ""
+            a(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, {so} offen{off}")
+    a("s_waitcnt vmcnt(0)")
+    for half, setname in ((0, "qb"), (1, "qa")):
+        for i in range(KQ):
+            a(f"ds_write_b128 %[ldw], %[{setname}{i}] offset:{i * NW * 2048 + half * 1024}")
+    for half, setname in ((0, "qb"), (1, "qa")):
+        for i in range(KQ):
+            a(f"s_add_u32 %[st0], %[qc1], 0x{i * NW * 2048 + half * 1024:x}")
+            a(f"buffer_load_dwordx4 %[{setname}{i}], %[qvoff], %[qsrd], %[st0] offen")
+    a("s_waitcnt vmcnt(0) lgkmcnt(0)")   # counted waits below assume the steady-state issue pattern
+    a("s_barrier")
+    # ---- persistent loop over this workgroup's tiles
+    a(".Ltile_%=:")
+    a("s_cmp_gt_u32 %[tl], 1")           # next tile's descriptor (the last tile re-reads itself: harmless)
+    a("s_cselect_b32 %[st0], %[xslo], 0")
+    a("s_cselect_b32 %[cnt], %[xshi], 0")
+    a("s_add_u32 s84, s80, %[st0]")
+    a("s_addc_u32 s85, s81, %[cnt]")
+    a("s_mov_b32 %[qcur], %[qcur0]")
+    a(f"s_movk_i32 %[xso0], 0x{R * 1024:x}")
+    a("s_add_u32 %[xso1], %[pb], %[xso0]")
+    a("s_cmp_eq_u32 %[nb], 1")
+    a("s_cbranch_scc1 .Lsingle_%=")
+    out += body_lines(R, QD, KQ, NW, True, False)
+    a("s_sub_u32 %[cnt], %[nb], 2")
+    a(".Lloop_%=:")
+    a("s_cmp_eq_u32 %[cnt], 0")
+    a("s_cbranch_scc1 .Llast_%=")
+    out += body_lines(R, QD, KQ, NW, False, False)
+    a("s_sub_u32 %[cnt], %[cnt], 1")
+    a("s_branch .Lloop_%=")
+    a(".Llast_%=:")
+    out += body_lines(R, QD, KQ, NW, False, True)
+    a("s_branch .Ladmit_%=")
+    a(".Lsingle_%=:")
+    out += body_lines(R, QD, KQ, NW, True, True)
+    a(".Ladmit_%=:")
+    out += gen_admission(space)
+    a("s_mov_b32 s80, s84")
+    a("s_mov_b32 s81, s85")
+    a("s_add_u32 s88, s88, %[rnstride]")
+    a("s_addc_u32 s89, s89, 0")
+    a("s_add_u32 %[trow], %[trow], %[rowstride]")
+    a("s_sub_u32 %[tl], %[tl], 1")
+    a("s_cmp_lg_u32 %[tl], 0")
+    a("s_cbranch_scc1 .Ltile_%=")
+    a("s_waitcnt vmcnt(0)")              # ring / Q sets still have loads in flight that nobody consumes
+    a("s_branch .Ldone_%=")
+    out += gen_hit_stubs()
+    out += gen_slow()
+    a(".Ldone_%=:")
+
+    ops_out, ops_in = [], []
+    for b in range(R):
+        for m in range(MT):
+            ops_out.append(f'[x{b * MT + m}] "=&v"(xring[{b * MT + m}])')
+    for i in range(KQ):
+        ops_out.append(f'[qa{i}] "=&v"(qsa[{i}])')
+    for i in range(KQ):
+        ops_out.append(f'[qb{i}] "=&v"(qsb[{i}])')
+    for i in range(QD):
+        ops_out.append(f'[t{i}] "=&v"(qt[{i}])')
+    for j in range(8):
+        ops_out.append(f'[r{j}] "=&v"(vr[{j}])')
+    if space == "l2":
+        for j in range(8):
+            ops_out.append(f'[p{j}] "=&v"(vp[{j}])')
+    for j in range(8):
+        ops_out.append(f'[u{j}] "=&v"(vu[{j}])')
+    for j in range(12):
+        ops_out.append(f'[e{j}] "=&v"(ve[{j}])')
+    ops_out += ['[ldr] "=&v"(ldr)', '[ldw] "=&v"(ldw)']
+    for name in ("xso0", "xso1", "qcur", "cnt", "st0", "tl", "trow", "sn64", "sn1m"):
+        ops_out.append(f'[{name}] "=&s"(s_{name})')
+    for name in ("sx0", "sx1", "sx2"):
+        ops_out.append(f'[{name}] "=&s"(s_{name})')
+    ops_in += ['[qsrd] "s"(qsrd)', '[lane16] "v"(lane16)', '[qvoff] "v"(qvoff)', '[rnvoff] "v"(rnvoff)',
+               '[thra] "v"(thra)', '[qoff4] "v"(qoff4)', '[qc64k] "v"(qc64k)', '[crow] "v"(crow)',
+               '[xlo] "s"(xlo)', '[xhi] "s"(xhi)', '[wbytes] "s"(wbytes)', '[xslo] "s"(xslo)', '[xshi] "s"(xshi)',
+               '[rnlo] "s"(rnlo)', '[rnhi] "s"(rnhi)', '[rnstride] "s"(rnstride)',
+               '[row0] "s"(row0)', '[rowstride] "s"(rowstride)', '[ntiles] "s"(ntiles)',
+               '[pb] "s"(pb)', '[qbytes] "s"(qbytes)', '[nb] "s"(nb)', '[qcur0] "s"(qcur0)', '[qc1] "s"(qc1)',
+               '[k0] "s"(k0)', '[cntb] "s"(cntb)', '[candb] "s"(candb)', '[ovfb] "s"(ovfb)']
+    if space == "l2":
+        ops_in.append('[k1] "s"(k1)')
+    clobbers = ['"memory"', '"scc"', '"vcc"'] + [f'"s{i}"' for i in range(80, 94)] + [f'"a{i}"' for i in range(128)]
+
+    text = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.",
+            f"// filter scan body: space {space}, NW={NW} waves, ring R={R} k-steps, B fragments read {QD} ahead.",
+            "asm volatile("]
+    for ln in out:
+        text.append(f'    "{ln}\\n\\t"')
+    text.append("    : " + ",\n      ".join(ops_out))
+    text.append("    : " + ",\n      ".join(ops_in))
+    text.append("    : " + ", ".join(clobbers) + ");")
+    return "\n".join(text) + "\n"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
+    ap.add_argument("--qd", type=int, default=4)
+    ap.add_argument("--nw", default="4")
+    args = ap.parse_args()
+    for space in SPACES:
+        for nw in [int(v) for v in args.nw.split(",")]:
+            for r in (2, 4):
+                p = Path(args.outdir) / f"scan_asm_{space}_nw{nw}_r{r}.inc"
+                p.write_text(generate(space, r, args.qd, nw))
+                print("wrote", p)
+
+
+if __name__ == "__main__":
+    main()

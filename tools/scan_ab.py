@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B the filter-scan kernel variants in ONE process on one resident corpus (tuning aid).
 
-Variants are compile-time instantiations picked per launch from MLVDB_SCAN_VARIANT / MLVDB_SCAN_R.
+Variants are compile-time instantiations picked per launch from environment variables
+(MLVDB_SCAN_ASM, MLVDB_SCAN_NW, MLVDB_SCAN_R, MLVDB_SCAN_MT), given as --envs "A=1,B=2;A=0".
 Prints per-variant median wave time and scan-kernel GB/s (HIP events), interleaved over rounds.
 """
 import argparse
@@ -22,16 +23,15 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--waves", type=int, default=6)
-    ap.add_argument("--variants", default="0,1,2,3")
-    ap.add_argument("--rs", default="3")
-    ap.add_argument("--mts", default="2")
+    ap.add_argument("--envs", default="MLVDB_SCAN_ASM=0;MLVDB_SCAN_ASM=1;MLVDB_SCAN_ASM=1,MLVDB_SCAN_NW=8")
+    ap.add_argument("--space", default="cosine")
     args = ap.parse_args()
     import torch
 
     from mlvectordb_amd import synth
     from mlvectordb_amd.engine import HipScanEngine
 
-    eng = HipScanEngine(args.dim, "cosine", device=0, capacity_hint=args.rows, strategy="filter")
+    eng = HipScanEngine(args.dim, args.space, device=0, capacity_hint=args.rows, strategy="filter")
     for _, rows in synth.iter_corpus(0, args.rows, args.dim, threads=16):
         eng.append(rows)
     q = torch.from_numpy(synth.queries(args.batch, args.dim)).cuda()
@@ -40,12 +40,17 @@ def main():
     dst = torch.empty((args.batch, k), dtype=torch.float32, device="cuda")
     cnt = torch.empty(args.batch, dtype=torch.int32, device="cuda")
     eng.set_profiling(True)
-    combos = [(v, r, m) for m in args.mts.split(",") for r in args.rs.split(",") for v in args.variants.split(",")]
+    combos = [c for c in args.envs.split(";")]
+    keys = sorted({kv.split("=")[0] for c in combos for kv in c.split(",") if kv})
     res = {c: {"wave": [], "scan": [], "bytes": 0} for c in combos}
     ref = None
     for rnd in range(args.rounds):
         for c in combos:
-            os.environ["MLVDB_SCAN_VARIANT"], os.environ["MLVDB_SCAN_R"], os.environ["MLVDB_SCAN_MT"] = c
+            for key in keys:
+                os.environ.pop(key, None)
+            for kv in c.split(","):
+                if kv:
+                    os.environ[kv.split("=")[0]] = kv.split("=")[1]
             for w in range(args.waves):
                 t0 = time.perf_counter()
                 eng.search_device(q.data_ptr(), args.batch, k, lab.data_ptr(), dst.data_ptr(), cnt.data_ptr(), 0, 0)
@@ -63,7 +68,7 @@ def main():
     print(f"rows {args.rows} dim {args.dim} batch {args.batch}")
     for c in combos:
         scan = np.median(res[c]["scan"])
-        print(f"variant {c[0]} R {c[1]} MT {c[2]}: wave p50 {np.median(res[c]['wave'])*1e3:7.3f} ms  min {np.min(res[c]['wave'])*1e3:7.3f}  "
+        print(f"{c:40s}: wave p50 {np.median(res[c]['wave'])*1e3:7.3f} ms  min {np.min(res[c]['wave'])*1e3:7.3f}  "
               f"scan {scan:7.3f} ms = {res[c]['bytes']/scan/1e6:7.1f} GB/s")
     eng.close()
 
