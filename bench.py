@@ -216,7 +216,7 @@ def main() -> None:
                     "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc, separate passes)" if traffic else None,
                     "hbm_actual_frac": round(traffic * scan_launches / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                     "mfma_bf16_frac": round(flops / (scan_ms * 1e-3) / 2.5e15, 4) if stats0["strategy_used"] == 2 else None,
-                    "kernel": "filter_scan_kernel" if stats0["strategy_used"] == 2 else "exact_scan_kernel",
+                    "kernel": "filter_scan_asm_kernel" if stats0["strategy_used"] == 2 else "exact_scan_kernel",
                     "avg_launch_ms": round(scan_ms / max(1, scan_launches), 4), "launches": scan_launches,
                     "alg_bytes_per_launch": round(alg_bytes_scan / max(1, scan_launches)),
                     "whole_wave_frac": round(alg_bytes_wave * passes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(
 // Requires the bf16 shadow.  Tile = NW*32 rows; the 2*ld/64 k-steps of a tile must be a multiple of R.
 typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 
-template <int SPACE, int R, int NW>
+template <int SPACE, int R, int NW, bool NT, int QD>
 __global__ __launch_bounds__(NW * 64, 2) void filter_scan_asm_kernel(const FilterArgs a, const int64_t tile_begin,
                                                                       const int64_t tile_end, const float e1) {
     constexpr int kThreads = NW * 64;
@@ -521,38 +521,14 @@ __global__ __launch_bounds__(NW * 64, 2) void filter_scan_asm_kernel(const Filte
     const uint32_t crow = (uint32_t)wave * 32u + g * 4;
     static_assert(kCandCap * sizeof(CandEntry) == 65536 && kCandCap == 8192, "the assembly hard-codes the list geometry");
 
-    u32x4s xring[R * 2], qsa[kQPer], qsb[kQPer], qt[4];
+    u32x4s xring[R * 2], qsa[kQPer], qsb[kQPer], qt[QD];
     float vr[8], vp[8], vu[8];
     uint32_t ve[12], ldr, ldw;
     uint32_t s_xso0, s_xso1, s_qcur, s_cnt, s_st0, s_tl, s_trow, s_sn64, s_sn1m;
     uint64_t s_sx0, s_sx1, s_sx2;
     (void)vp;
     (void)k1;
-    if constexpr (SPACE == kSpaceL2 && NW == 4 && R == 4) {
-#include "scan_asm_l2_nw4_r4.inc"
-    } else if constexpr (SPACE == kSpaceL2 && NW == 4 && R == 2) {
-#include "scan_asm_l2_nw4_r2.inc"
-    } else if constexpr (SPACE == kSpaceCosine && NW == 4 && R == 4) {
-#include "scan_asm_cosine_nw4_r4.inc"
-    } else if constexpr (SPACE == kSpaceCosine && NW == 4 && R == 2) {
-#include "scan_asm_cosine_nw4_r2.inc"
-    } else if constexpr (SPACE == kSpaceIp && NW == 4 && R == 4) {
-#include "scan_asm_ip_nw4_r4.inc"
-    } else if constexpr (SPACE == kSpaceIp && NW == 4 && R == 2) {
-#include "scan_asm_ip_nw4_r2.inc"
-    } else if constexpr (SPACE == kSpaceL2 && NW == 8 && R == 4) {
-#include "scan_asm_l2_nw8_r4.inc"
-    } else if constexpr (SPACE == kSpaceL2 && NW == 8 && R == 2) {
-#include "scan_asm_l2_nw8_r2.inc"
-    } else if constexpr (SPACE == kSpaceCosine && NW == 8 && R == 4) {
-#include "scan_asm_cosine_nw8_r4.inc"
-    } else if constexpr (SPACE == kSpaceCosine && NW == 8 && R == 2) {
-#include "scan_asm_cosine_nw8_r2.inc"
-    } else if constexpr (SPACE == kSpaceIp && NW == 8 && R == 4) {
-#include "scan_asm_ip_nw8_r4.inc"
-    } else {
-#include "scan_asm_ip_nw8_r2.inc"
-    }
+#include "scan_asm_dispatch.inc"
 }
 
 // ------------------------------------------------------------------ threshold update + compaction
@@ -943,7 +919,7 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
     return hipGetLastError();
 }
 
-template <int SPACE, int R, int NW>
+template <int SPACE, int R, int NW, bool NT = false, int QD = 4>
 static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
     constexpr int tile_rows = NW * 32;
     const int64_t tile_begin = row_begin / tile_rows;
@@ -953,7 +929,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     const int64_t ntiles = tile_end - tile_begin;
     const int max_grid = 256 * (8 / NW);  // two waves per SIMD on every CU
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
-    auto kern = filter_scan_asm_kernel<SPACE, R, NW>;
+    auto kern = filter_scan_asm_kernel<SPACE, R, NW, NT, QD>;
     static bool configured = false;  // per instantiation
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -974,13 +950,26 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
     // steps per tile = 2 * (ld / 64) must be a multiple of lcm(R, 2)
     const int nkc = a.ld / kFilterChunkK;
     if (a.Xb && env_int("MLVDB_SCAN_ASM", 1)) {
-        // hand-scheduled k-loop; ring depth 4 needs an even number of chunks per tile
-        if (env_int("MLVDB_SCAN_NW", 4) == 8) {
-            if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8>(a, row_begin, row_end, s);
-            return launch_scan_asm<SPACE, 2, 8>(a, row_begin, row_end, s);
+        // hand-written body (tools/gen_scan_asm.py).  Default: one 8-wave workgroup per CU (256-row tiles:
+        // the query image is staged once per CU), non-temporal X loads, ring of 4 k-steps -- measured
+        // fastest (profiles/r01/scan_ab_*.txt); a ring of R k-steps needs the tile's 2*nkc k-steps to be a
+        // multiple of R.  MLVDB_SCAN_NW / _NT / _R / _QD select the other generated variants (tuning).
+        const int nw = env_int("MLVDB_SCAN_NW", 8);
+        if constexpr (SPACE == kSpaceCosine) {
+            const int want_r = env_int("MLVDB_SCAN_R", 4);
+            if (nkc % 2 == 0 && env_int("MLVDB_SCAN_NT", 1) == 0)
+                return nw == 8 ? launch_scan_asm<SPACE, 4, 8, false>(a, row_begin, row_end, s)
+                               : launch_scan_asm<SPACE, 4, 4, false>(a, row_begin, row_end, s);
+            if (nw == 8 && want_r == 6 && (2 * nkc) % 6 == 0) return launch_scan_asm<SPACE, 6, 8, true>(a, row_begin, row_end, s);
+            if (nw == 8 && nkc % 2 == 0 && env_int("MLVDB_SCAN_QD", 4) == 8)
+                return launch_scan_asm<SPACE, 4, 8, true, 8>(a, row_begin, row_end, s);
         }
-        if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4>(a, row_begin, row_end, s);
-        return launch_scan_asm<SPACE, 2, 4>(a, row_begin, row_end, s);
+        if (nw == 8) {
+            if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8, true>(a, row_begin, row_end, s);
+            return launch_scan_asm<SPACE, 2, 8, true>(a, row_begin, row_end, s);
+        }
+        if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true>(a, row_begin, row_end, s);
+        return launch_scan_asm<SPACE, 2, 4, true>(a, row_begin, row_end, s);
     }
     if (a.Xb) {
         const int want_r = env_int("MLVDB_SCAN_R", 2);

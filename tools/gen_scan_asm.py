@@ -108,7 +108,7 @@ def ring(b, m):
 XCUR, XNEXT, RNS, RET = "s[80:83]", "s[84:87]", "s[88:91]", "s[92:93]"
 
 
-def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last):
+def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt):
     """One 64-column chunk = 2 k-steps = 32 fragments x 2 MFMAs."""
     s.emit("v_xor_b32 %[ldr], 0x8000, %[ldr]")
     s.emit("v_xor_b32 %[ldw], 0x8000, %[ldw]")
@@ -120,13 +120,20 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last):
     def refill(h):
         step = step0 + h
         b = step % R
+        pol = " nt" if nt else ""   # streamed once: non-temporal
         for m in range(MT):
-            if last:
+            if last and step * 1024 < 4096:
                 so = "0" if m == 0 else "%[pb]"
                 off = f" offset:{step * 1024}" if step else ""
-                s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XNEXT}, {so} offen{off}", ("x", b, m))
+                s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XNEXT}, {so} offen{off}{pol}", ("x", b, m))
+            elif last:
+                if m == 0:
+                    s.emit(f"s_movk_i32 %[st0], 0x{step * 1024:x}")
+                else:
+                    s.emit(f"s_add_u32 %[st0], %[pb], 0x{step * 1024:x}")
+                s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XNEXT}, %[st0] offen{pol}", ("x", b, m))
             else:
-                s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, %[xso{m}] offen", ("x", b, m))
+                s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, %[xso{m}] offen{pol}", ("x", b, m))
         if not last:
             s.emit("s_add_u32 %[xso0], %[xso0], 0x400")
             s.emit("s_add_u32 %[xso1], %[xso1], 0x400")
@@ -176,7 +183,7 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last):
     s.emit("s_barrier")
 
 
-def gen_body(s, R, QD, KQ, NW, first, last):
+def gen_body(s, R, QD, KQ, NW, first, last, nt):
     if last:
         # |x| of this lane's 8 rows (rows 4g..4g+3 of both panels) for the admission test
         for j in range(8):
@@ -184,18 +191,18 @@ def gen_body(s, R, QD, KQ, NW, first, last):
             s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{off}" if off else ""),
                    ("rn", j))
     for ch in range(R // 2):
-        gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last)
+        gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last, nt)
     if last:
         s.need_vm(*[("rn", j) for j in range(8)])
 
 
-def body_lines(R, QD, KQ, NW, first, last):
+def body_lines(R, QD, KQ, NW, first, last, nt):
     s = Sched()
     s.recording = False
     for _ in range(2):   # history: every predecessor issues this pattern of memory operations
-        gen_body(s, R, QD, KQ, NW, False, False)
+        gen_body(s, R, QD, KQ, NW, False, False, nt)
     s.recording = True
-    gen_body(s, R, QD, KQ, NW, first, last)
+    gen_body(s, R, QD, KQ, NW, first, last, nt)
     return s.lines
 
 
@@ -308,8 +315,8 @@ def gen_slow():
     return o
 
 
-def generate(space, R, QD, NW):
-    assert R in (2, 4) and 2 <= QD <= 4
+def generate(space, R, QD, NW, nt=False):
+    assert R in (2, 4, 6) and 2 <= QD <= 8
     KQ = 1024 // (NW * 64)
     out = []
     a = out.append
@@ -335,9 +342,13 @@ def generate(space, R, QD, NW):
             a(f"buffer_load_dwordx4 %[{setname}{i}], %[qvoff], %[qsrd], %[st0] offen")
     for b in range(R):
         for m in range(MT):
-            so = "0" if m == 0 else "%[pb]"
-            off = f" offset:{b * 1024}" if b else ""
-            a(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, {so} offen{off}")
+            if b * 1024 < 4096:
+                so = "0" if m == 0 else "%[pb]"
+                off = f" offset:{b * 1024}" if b else ""
+                a(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, {so} offen{off}")
+            else:
+                a(f"s_movk_i32 %[st0], 0x{b * 1024:x}" if m == 0 else f"s_add_u32 %[st0], %[pb], 0x{b * 1024:x}")
+                a(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, %[st0] offen")
     a("s_waitcnt vmcnt(0)")
     for half, setname in ((0, "qb"), (1, "qa")):
         for i in range(KQ):
@@ -360,19 +371,19 @@ def generate(space, R, QD, NW):
     a("s_add_u32 %[xso1], %[pb], %[xso0]")
     a("s_cmp_eq_u32 %[nb], 1")
     a("s_cbranch_scc1 .Lsingle_%=")
-    out += body_lines(R, QD, KQ, NW, True, False)
+    out += body_lines(R, QD, KQ, NW, True, False, nt)
     a("s_sub_u32 %[cnt], %[nb], 2")
     a(".Lloop_%=:")
     a("s_cmp_eq_u32 %[cnt], 0")
     a("s_cbranch_scc1 .Llast_%=")
-    out += body_lines(R, QD, KQ, NW, False, False)
+    out += body_lines(R, QD, KQ, NW, False, False, nt)
     a("s_sub_u32 %[cnt], %[cnt], 1")
     a("s_branch .Lloop_%=")
     a(".Llast_%=:")
-    out += body_lines(R, QD, KQ, NW, False, True)
+    out += body_lines(R, QD, KQ, NW, False, True, nt)
     a("s_branch .Ladmit_%=")
     a(".Lsingle_%=:")
-    out += body_lines(R, QD, KQ, NW, True, True)
+    out += body_lines(R, QD, KQ, NW, True, True, nt)
     a(".Ladmit_%=:")
     out += gen_admission(space)
     a("s_mov_b32 s80, s84")
@@ -425,7 +436,8 @@ def generate(space, R, QD, NW):
     clobbers = ['"memory"', '"scc"', '"vcc"'] + [f'"s{i}"' for i in range(80, 94)] + [f'"a{i}"' for i in range(128)]
 
     text = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.",
-            f"// filter scan body: space {space}, NW={NW} waves, ring R={R} k-steps, B fragments read {QD} ahead.",
+            f"// filter scan body: space {space}, NW={NW} waves, ring R={R} k-steps, B fragments read {QD} ahead"
+            f"{', X loads non-temporal' if nt else ''}.",
             "asm volatile("]
     for ln in out:
         text.append(f'    "{ln}\\n\\t"')
@@ -435,18 +447,37 @@ def generate(space, R, QD, NW):
     return "\n".join(text) + "\n"
 
 
+# (space, NW, R, nt) instantiated by kernels_filter.hip: the production set, and experiments (cosine only)
+CONFIGS = [(sp, nw, r, True, 4) for sp in SPACES for nw in (4, 8) for r in (2, 4)] + [
+    ("cosine", 4, 4, False, 4), ("cosine", 8, 4, False, 4), ("cosine", 8, 6, True, 4), ("cosine", 8, 4, True, 8)]
+
+
+def inc_name(space, nw, r, nt, qd):
+    return f"scan_asm_{space}_nw{nw}_r{r}{'_nt' if nt else ''}{'_qd%d' % qd if qd != 4 else ''}.inc"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
-    ap.add_argument("--qd", type=int, default=4)
-    ap.add_argument("--nw", default="4")
+    ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    for space in SPACES:
-        for nw in [int(v) for v in args.nw.split(",")]:
-            for r in (2, 4):
-                p = Path(args.outdir) / f"scan_asm_{space}_nw{nw}_r{r}.inc"
-                p.write_text(generate(space, r, args.qd, nw))
-                print("wrote", p)
+    names = [inc_name(*c) for c in CONFIGS] + ["scan_asm_dispatch.inc"]
+    if args.list:
+        print(" ".join(names))
+        return
+    for c in CONFIGS:
+        space, nw, r, nt, qd = c
+        (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt))
+    disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD>."]
+    for i, (space, nw, r, nt, qd) in enumerate(CONFIGS):
+        cond = f"SPACE == {SPACES[space]} && NW == {nw} && R == {r} && NT == {'true' if nt else 'false'} && QD == {qd}"
+        disp.append(("if" if i == 0 else "} else if") + f" constexpr ({cond}) {{")
+        disp.append(f'#include "{inc_name(space, nw, r, nt, qd)}"')
+    disp.append("} else {")
+    disp.append('    static_assert(SPACE < 0, "configuration not generated: add it to CONFIGS in tools/gen_scan_asm.py");')
+    disp.append("}")
+    (Path(args.outdir) / "scan_asm_dispatch.inc").write_text("\n".join(disp) + "\n")
+    print("wrote", len(names), "files to", args.outdir)
 
 
 if __name__ == "__main__":
