@@ -58,7 +58,7 @@ struct mlvdb_index {
     hipStream_t stream = nullptr;
     // workspaces (grow only)
     DevBuf stage, qpad, qaux, partial, qsel, seed_lab, seed_dist, seed_cnt, seed_d64;
-    DevBuf qimg, fmisc, cand, io_q, io_lab, io_dist, io_cnt, counters, labels_in;
+    DevBuf qimg, fmisc, cand, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, counters, labels_in;
     DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
     uint32_t* host_flags = nullptr;  // pinned, kFilterQueries words
     bool host_overflow[256] = {};    // flags of the last collect_overflow
@@ -243,6 +243,10 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     HIP_TRY(h, h->qimg.ensure(filter_qimg_bytes(h->ld)));
     HIP_TRY(h, h->fmisc.ensure(4 * kFilterQueries * sizeof(uint32_t)));
     HIP_TRY(h, h->cand.ensure((size_t)kFilterQueries * kCandCap * sizeof(CandEntry)));
+    if (h->Xb) {  // the assembly scan appends through workgroup-private buffers
+        HIP_TRY(h, h->wgbuf.ensure((size_t)kScanMaxGrid * kWgCap * sizeof(WgEntry)));
+        HIP_TRY(h, h->wgcnt.ensure((size_t)kScanMaxGrid * 8 * sizeof(uint32_t)));
+    }
     if (!h->host_flags)
         HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->host_flags), kFilterQueries * sizeof(uint32_t), 0));
     fa.X = h->X;
@@ -260,6 +264,8 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     fa.cnt = h->fmisc.as<uint32_t>() + 2 * kFilterQueries;
     fa.overflow = h->fmisc.as<uint32_t>() + 3 * kFilterQueries;
     fa.cand = h->cand.as<CandEntry>();
+    fa.wgbuf = h->wgbuf.as<WgEntry>();
+    fa.wgcnt = h->wgcnt.as<uint32_t>();
     return MLVDB_OK;
 }
 
@@ -505,7 +511,7 @@ int mlvdb_index_destroy(mlvdb_index* h) {
     if (h->rn) (void)hipFree(h->rn);
     if (h->Xb) (void)hipFree(h->Xb);
     for (DevBuf* b : {&h->stage, &h->qpad, &h->qaux, &h->partial, &h->qsel, &h->seed_lab, &h->seed_dist, &h->seed_cnt,
-                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt,
+                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->wgbuf, &h->wgcnt, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt,
                       &h->counters, &h->labels_in, &h->page_lab, &h->page_dist, &h->page_cnt, &h->page_d64, &h->cur_d,
                       &h->cur_l})
         b->release();

@@ -68,11 +68,22 @@ hipError_t launch_exact_merge(const TopEntry* partial, int32_t nq_sel, const int
 constexpr int kFilterQueries = 256;   // queries per filter pass
 constexpr int kFilterChunkK = 64;     // columns per Q chunk staged in LDS
 constexpr int kCandCap = 8192;        // candidate slots per query
-constexpr int kFilterTile = 768;      // scan ranges start on multiples of it (common multiple of the kernels' 192/128-row tiles)
+constexpr int kFilterTile = 768;      // scan ranges start on multiples of it (common multiple of the kernels' 192/128/256-row tiles)
+constexpr int kScanMaxGrid = 512;     // most workgroups any scan launch uses
+constexpr int kWgCap = 16384;         // append slots per workgroup and launch (assembly scan: split evenly over its waves)
 
 struct CandEntry {
     float u;      // upper bound of the row's score (higher = nearer)
     int32_t row;
+};
+
+// What a workgroup of the assembly scan appends to its private buffer; the scatter kernel then moves
+// the entries into the per-query lists (the scan itself never waits for a device-scope atomic).
+struct WgEntry {
+    float u;
+    int32_t row;
+    uint32_t q;
+    uint32_t pad;
 };
 
 bool filter_supported(int32_t ld);
@@ -95,6 +106,8 @@ struct FilterArgs {
     uint32_t* cnt;          // [256] candidates appended
     uint32_t* overflow;     // [256] nonzero = list overflowed, query must be re-run exactly
     CandEntry* cand;        // [256][kCandCap]
+    WgEntry* wgbuf;         // [kScanMaxGrid][kWgCap] append buffers of one scan launch, one slice per wave
+    uint32_t* wgcnt;        // [kScanMaxGrid * 8] entries appended per wave (may exceed the slice: the excess was flagged as overflow)
 };
 hipError_t launch_filter_prep(const FilterArgs& a, hipStream_t s);
 // seed thresholds from exact kNN distances of a prefix of the corpus: seed_d64[q][k]

@@ -447,6 +447,49 @@ __global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(
     }
 }
 
+// ------------------------------------------------------------------ append buffers -> candidate lists
+// One block per workgroup of the preceding assembly scan: the entries of its nw wave buffers
+// (u[cap], row[cap], q[cap] each) go to the per-query lists.  Entries are counted per query in LDS
+// first, so the block issues one device-scope atomic per query it has entries for (a per-entry
+// atomic on 256 hot counters cost ~90 us per launch).
+__global__ __launch_bounds__(256) void filter_scatter_kernel(const FilterArgs a, const int cap, const int nw) {
+    __shared__ uint32_t hist[kFilterQueries], base[kFilterQueries];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int w = 0; w < nw; ++w) {
+        const int wb = blockIdx.x * nw + w;
+        const uint32_t n = min(a.wgcnt[wb], (uint32_t)cap);  // entries past the buffer were flagged by the scan
+        const uint32_t* bq = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.wgbuf + (size_t)wb * cap) + (size_t)cap * 8);
+        for (uint32_t i = threadIdx.x; i < n; i += 256) atomicAdd(&hist[bq[i]], 1u);
+    }
+    __syncthreads();
+    {
+        const uint32_t c = hist[threadIdx.x];
+        base[threadIdx.x] = c ? atomicAdd(&a.cnt[threadIdx.x], c) : 0u;
+        if (c && base[threadIdx.x] + c > (uint32_t)kCandCap) a.overflow[threadIdx.x] = 1u;
+        hist[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (int w = 0; w < nw; ++w) {
+        const int wb = blockIdx.x * nw + w;
+        const uint32_t n = min(a.wgcnt[wb], (uint32_t)cap);
+        const char* buf = reinterpret_cast<const char*>(a.wgbuf + (size_t)wb * cap);
+        const float* bu = reinterpret_cast<const float*>(buf);
+        const int32_t* br = reinterpret_cast<const int32_t*>(buf + (size_t)cap * 4);
+        const uint32_t* bq = reinterpret_cast<const uint32_t*>(buf + (size_t)cap * 8);
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const uint32_t q = bq[i];
+            const uint32_t slot = base[q] + atomicAdd(&hist[q], 1u);
+            if (slot < (uint32_t)kCandCap) {
+                CandEntry e;
+                e.u = bu[i];
+                e.row = br[i];
+                a.cand[(size_t)q * kCandCap + slot] = e;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ the scan, hand-written for gfx950
 // Same geometry, data flow and bounds as filter_scan_kernel<.., kMT = 2, XB = true> above, but the
 // whole body -- prologue, persistent tile loop, k-loop, admission test, append path -- is the
@@ -455,15 +498,22 @@ __global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(
 // Requires the bf16 shadow.  Tile = NW*32 rows; the 2*ld/64 k-steps of a tile must be a multiple of R.
 typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 
+#include "scan_asm_consts.inc"
+static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagree");
+
 template <int SPACE, int R, int NW, bool NT, int QD>
 __global__ __launch_bounds__(NW * 64, 2) void filter_scan_asm_kernel(const FilterArgs a, const int64_t tile_begin,
                                                                       const int64_t tile_end, const float e1) {
     constexpr int kThreads = NW * 64;
     constexpr int kQPer = 1024 / kThreads;  // uint4 of a Q half-chunk moved per thread
     constexpr int kTileRowsV = NW * 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][32 KiB] Q chunks at LDS offset 0, thr[256], qscale[256]
-    float* thr_l = reinterpret_cast<float*>(smem + 2 * kChunkVec * sizeof(uint4));
+    constexpr int kQBufs = 2;
+    constexpr int kStageCap = NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4;  // appended entries a wave stages in LDS
+    // LDS: [2][32 KiB] Q chunks at offset 0, thr[256], qscale[256], [NW waves] staging {u[], row[], q[]}
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* thr_l = reinterpret_cast<float*>(smem + kQBufs * kChunkVec * sizeof(uint4));
     float* sq_l = thr_l + kFilterQueries;
+    if (threadIdx.x < NW) a.wgcnt[blockIdx.x * NW + threadIdx.x] = 0;  // workgroups without tiles return below
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -509,23 +559,27 @@ __global__ __launch_bounds__(NW * 64, 2) void filter_scan_asm_kernel(const Filte
     }
     const float k0 = SPACE == kSpaceCosine ? e1 + 2.0f * kSlack : e1 + kSlack;
     const float k1 = -(1.0f - kSlack);
-    const uint32_t* cntb = a.cnt;
-    const CandEntry* candb = a.cand;
+    // this wave's append buffer in global memory: u[cap], row[cap], q[cap]
+    constexpr int kCapW = kWgCap / NW;
+    const char* wgb = reinterpret_cast<const char*>(a.wgbuf + ((size_t)blockIdx.x * NW + wave) * kCapW);
+    const float* wgbu = reinterpret_cast<const float*>(wgb);
+    const int32_t* wgbr = reinterpret_cast<const int32_t*>(wgb + kCapW * 4);
+    const uint32_t* wgbq = reinterpret_cast<const uint32_t*>(wgb + kCapW * 8);
+    const uint32_t* wgcp = a.wgcnt + blockIdx.x * NW + wave;
+    const uint32_t stg = (uint32_t)(kQBufs * chunk_bytes) + 2 * kFilterQueries * sizeof(float) + (uint32_t)wave * (12 * kStageCap);
     const uint32_t* ovfb = a.overflow;
     const uint32_t lane16 = lane * 16;
     const uint32_t qvoff = (uint32_t)wave * 2048u + lane16;  // this thread's uint4 of fragment piece 2*wave + h
     const uint32_t rnvoff = g * 16;
-    const uint32_t thra = (uint32_t)(2 * chunk_bytes) + c16 * 4;
-    const uint32_t qoff4 = c16 * 4;
-    const uint32_t qc64k = (uint32_t)c16 * (uint32_t)(kCandCap * sizeof(CandEntry));
+    const uint32_t thra = (uint32_t)(kQBufs * chunk_bytes) + c16 * 4;
+    const uint32_t c16v = c16;
     const uint32_t crow = (uint32_t)wave * 32u + g * 4;
-    static_assert(kCandCap * sizeof(CandEntry) == 65536 && kCandCap == 8192, "the assembly hard-codes the list geometry");
+    static_assert(kWgCap == 16384 && sizeof(WgEntry) == 16, "the assembly hard-codes the append buffer geometry");
 
-    u32x4s xring[R * 2], qsa[kQPer], qsb[kQPer], qt[QD];
+    u32x4s xring[R * 2], qsa[kQPer], qsb[kQPer], qt[QD > 8 ? 4 : QD];
     float vr[8], vp[8], vu[8];
     uint32_t ve[12], ldr, ldw;
-    uint32_t s_xso0, s_xso1, s_qcur, s_cnt, s_st0, s_tl, s_trow, s_sn64, s_sn1m;
-    uint64_t s_sx0, s_sx1, s_sx2;
+    uint32_t s_xso0, s_xso1, s_qcur, s_cnt, s_st0, s_tl, s_trow, s_sn64, s_wcnt;
     (void)vp;
     (void)k1;
 #include "scan_asm_dispatch.inc"
@@ -925,9 +979,10 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     const int64_t tile_begin = row_begin / tile_rows;
     const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
     if (tile_end <= tile_begin) return hipSuccess;
-    const size_t lds = 2 * kChunkVec * sizeof(uint4) + 2 * kFilterQueries * sizeof(float);
+    const size_t lds = 2 * kChunkVec * sizeof(uint4) + 2 * kFilterQueries * sizeof(float) +
+                       (size_t)NW * 12 * (NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4);
     const int64_t ntiles = tile_end - tile_begin;
-    const int max_grid = 256 * (8 / NW);  // two waves per SIMD on every CU
+    const int max_grid = 256 * (8 / NW);  // two waves per SIMD on every CU (<= kScanMaxGrid)  // two waves per SIMD on every CU
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
     auto kern = filter_scan_asm_kernel<SPACE, R, NW, NT, QD>;
     static bool configured = false;  // per instantiation
@@ -938,6 +993,9 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
         configured = true;
     }
     kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end, filter_e1(a.ld));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    filter_scatter_kernel<<<grid, 256, 0, s>>>(a, kWgCap / NW, NW);
     return hipGetLastError();
 }
 
@@ -956,13 +1014,17 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
         // multiple of R.  MLVDB_SCAN_NW / _NT / _R / _QD select the other generated variants (tuning).
         const int nw = env_int("MLVDB_SCAN_NW", 8);
         if constexpr (SPACE == kSpaceCosine) {
-            const int want_r = env_int("MLVDB_SCAN_R", 4);
             if (nkc % 2 == 0 && env_int("MLVDB_SCAN_NT", 1) == 0)
                 return nw == 8 ? launch_scan_asm<SPACE, 4, 8, false>(a, row_begin, row_end, s)
                                : launch_scan_asm<SPACE, 4, 4, false>(a, row_begin, row_end, s);
-            if (nw == 8 && want_r == 6 && (2 * nkc) % 6 == 0) return launch_scan_asm<SPACE, 6, 8, true>(a, row_begin, row_end, s);
-            if (nw == 8 && nkc % 2 == 0 && env_int("MLVDB_SCAN_QD", 4) == 8)
-                return launch_scan_asm<SPACE, 4, 8, true, 8>(a, row_begin, row_end, s);
+            switch (nw == 8 && nkc % 2 == 0 ? env_int("MLVDB_SCAN_DIAG", 0) : 0) {  // timing diagnostics, wrong results
+                case 101: return launch_scan_asm<SPACE, 4, 8, true, 101>(a, row_begin, row_end, s);
+                case 102: return launch_scan_asm<SPACE, 4, 8, true, 102>(a, row_begin, row_end, s);
+                case 103: return launch_scan_asm<SPACE, 4, 8, true, 103>(a, row_begin, row_end, s);
+                case 104: return launch_scan_asm<SPACE, 4, 8, true, 104>(a, row_begin, row_end, s);
+                case 107: return launch_scan_asm<SPACE, 4, 8, true, 107>(a, row_begin, row_end, s);
+                default: break;
+            }
         }
         if (nw == 8) {
             if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8, true>(a, row_begin, row_end, s);

@@ -251,3 +251,27 @@ def test_range_capacity_overflow_is_reported_then_resolved():
             assert np.array_equal(gl, wl) and len(gl) >= 50
     finally:
         eng.close()
+
+
+SCAN_VARIANTS = [
+    {"MLVDB_SCAN_NW": "8"},                          # default: assembly body, one 8-wave workgroup per CU
+    {"MLVDB_SCAN_NW": "4"},                          # assembly body, two 4-wave workgroups per CU
+    {"MLVDB_SCAN_NW": "8", "MLVDB_SCAN_NT": "0"},    # (cosine only) temporal X loads
+    {"MLVDB_SCAN_ASM": "0"},                         # the hipcc-scheduled kernel (also serves corpora without shadow)
+]
+
+
+@pytest.mark.parametrize("variant", SCAN_VARIANTS, ids=lambda v: ",".join(f"{k[11:]}={x}" for k, x in v.items()))
+@pytest.mark.parametrize("space,d", [("cosine", 128), ("l2", 192), ("ip", 64), ("cosine", 768)])
+def test_scan_kernel_variants_agree_with_oracle(variant, space, d, monkeypatch):
+    """Every generated geometry of the filter scan (the variable is read per launch), on corpora with more
+    tiles than resident workgroups (persistent tile loop, prefetch across tile boundaries), ragged last
+    tile, tombstones and duplicated rows."""
+    for key, val in variant.items():
+        monkeypatch.setenv(key, val)
+    n = 150_001 if d <= 192 else 70_003
+    rows, qs = make_case(300 + d, n, d, 40, dup=True)
+    deleted = deleted_mask(7, n, 0.05)
+    got, stats = run_hip(rows, qs, 10, space, "filter", deleted, append_chunks=3)
+    assert stats["strategy_used"] == 2 and stats["fallback_queries"] == 0
+    assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"variant {variant}/{space}/d{d}")

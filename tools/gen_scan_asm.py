@@ -27,18 +27,21 @@ touches an AGPR, so the accumulators take the AGPRs and everything else lives in
   * the 32 B fragments of a chunk are one software-pipelined stream: ds_read_b128 runs QD
     fragments ahead of the two MFMAs that consume a fragment.
   * admission test per query tile: 8 bounds per lane (same arithmetic as scan_epilogue), their
-    maximum against the threshold; only if some lane passes, an out-of-line routine reserves
-    slots (one atomic per lane) and stores the (bound, row) pairs.  That routine waits for its
-    atomic with vmcnt(0); its memory operations are younger than every prefetch, so the counted
-    waits elsewhere only become more conservative.
+    maximum against the threshold; only if some lane passes, an out-of-line routine appends
+    (bound, row, query) entries to the WAVE's private buffer, staged in LDS until the kernel ends:
+    the fill count lives in an SGPR, slots come from v_mbcnt -- no atomic, no wait, and no global
+    store in the loop (see gen_slow).  filter_scatter_kernel then moves the entries into the
+    per-query lists.  The routine's memory
+    operations are younger than every prefetch, so the counted waits elsewhere stay sufficient.
 """
 import argparse
 from pathlib import Path
 
 MT = 2
 CHUNK_BYTES = 0x8000      # 256 queries x 64 columns x 2 B
-CAND_CAP = 8192           # kCandCap
+WG_CAP = 16384            # kWgCap: append entries per workgroup (split evenly over its waves)
 SPACES = {"l2": 0, "cosine": 1, "ip": 2}
+DBG = set()   # timing diagnostics only (wrong results): 'nolds' drops the B-fragment reads, 'nox' the X refills
 
 
 class Sched:
@@ -53,15 +56,19 @@ class Sched:
         self.recording = True
 
     def emit(self, text):
+        if "nobar" in DBG and text == "s_barrier":
+            return
         if self.recording:
             self.lines.append(text)
 
     def vmem(self, text, tag):
-        self.emit(text)
+        if not ("nox" in DBG and tag[0] == "x") and not ("noq" in DBG and tag[0] in ("qa", "qb")):
+            self.emit(text)
         self.vm.append(tag)
 
     def lds(self, text, tag):
-        self.emit(text)
+        if not ("nolds" in DBG and tag[0] == "rd" and tag[-1] >= 4) and not ("noq" in DBG and tag[0] == "wr"):
+            self.emit(text)
         self.lg.append(tag)
 
     def _last(self, q, tag):
@@ -254,7 +261,8 @@ def gen_admission(space):
         a("v_max_f32 %[e4], %[e4], %[e5]")
         s.need_lg(("thr", n))
         a(f"v_cmp_ge_f32 vcc, %[e4], {thr(n)}")
-        a(f"s_cbranch_vccnz .Lhit{n}_%=")
+        if "nohit" not in DBG:
+            a(f"s_cbranch_vccnz .Lhit{n}_%=")
         a(f".Lback{n}_%=:")
     return s.lines
 
@@ -264,8 +272,7 @@ def gen_hit_stubs():
     for n in range(16):
         out += [f".Lhit{n}_%=:",
                 f"v_mov_b32 %[e6], %[e{n & 1}]",          # the threshold of this query tile
-                f"s_movk_i32 %[sn64], 0x{n * 64:x}",      # byte offset of query 16n in cnt[] / overflow[]
-                f"s_mov_b32 %[sn1m], 0x{n << 20:x}",      # byte offset of query 16n's list in cand[]
+                f"s_movk_i32 %[sn64], 0x{n * 16:x}",      # first query of this tile
                 f"s_getpc_b64 {RET}",
                 "s_add_u32 s92, s92, 12",                 # return to the instruction after the branch below
                 "s_addc_u32 s93, s93, 0",
@@ -274,45 +281,93 @@ def gen_hit_stubs():
     return out
 
 
-def gen_slow():
-    """u0..u7 = bounds of this lane's 8 rows for query 16n + c16, e6 = threshold."""
-    o = [".Lslow_%=:", "v_mov_b32 %[e7], 0"]
+def lds_stage_cap(NW):
+    """Entries of a wave's staging area in LDS (12 B each, SoA): what is left of the 160 KiB per CU."""
+    per_wg = (160 * 1024) // (8 // NW) - (2 * CHUNK_BYTES + 2048)
+    return min(WG_CAP // NW, (per_wg // NW) // 12 // 8 * 8)
+
+
+def gen_slow(NW):
+    """u0..u7 = bounds of this lane's 8 rows for query sn64 + c16, e6 = threshold.
+
+    Wave-private append: the wave keeps its entry count in an SGPR; per row j the passing lanes form
+    an SGPR mask and take the slots count + (passing lanes below), via v_mbcnt -- no atomics.
+    The first LCW entries of a launch are staged in LDS (u[], row[], q[]) and copied to the wave's
+    global buffer when the kernel ends: a global store inside the loop would sit in the vmcnt queue
+    behind the prefetched loads for ~1-2 us and turn every counted wait into a drain of the X
+    prefetch (measured: 17 % of the scan).  Entries beyond the staging area go straight to global
+    memory (same slot numbering), entries beyond the global buffer flag their query as overflowed."""
+    capw = WG_CAP // NW
+    lcw = lds_stage_cap(NW)
+    o = [".Lslow_%=:"]
     for j in range(8):
-        o += [f"v_cmp_ge_f32 vcc, %[u{j}], %[e6]",
-              "v_cndmask_b32_e64 %[e8], 0, 1, vcc",
-              f"v_lshl_or_b32 %[e7], %[e8], {j}, %[e7]"]            # e7 = hit mask
-    o += ["v_cmp_ne_u32 vcc, 0, %[e7]",
-          "s_and_saveexec_b64 %[sx0], vcc",
-          "s_cbranch_execz .Lslowend_%=",
-          "v_bcnt_u32_b32 %[e8], %[e7], 0",
-          "v_add_u32 %[e9], %[sn64], %[qoff4]",                     # e9 = 4 * query
-          "global_atomic_add %[e10], %[e9], %[e8], %[cntb] sc0",    # e10 = first reserved slot
-          "v_add_u32 %[e11], %[trow], %[crow]",                     # e11 = this lane's first row
-          "s_waitcnt vmcnt(0)"]
+        o.append(f"v_cmp_ge_f32_e64 s[{60 + 2 * j}:{61 + 2 * j}], %[u{j}], %[e6]")
+    o += ["v_add_u32 %[e9], %[sn64], %[c16v]",                      # e9 = query
+          "v_add_u32 %[e11], %[trow], %[crow]"]                     # e11 = this lane's first row
     for j in range(8):
-        o += [f"v_and_b32 %[e8], 0x{1 << j:x}, %[e7]",
-              "v_cmp_ne_u32 vcc, 0, %[e8]",
-              "s_and_saveexec_b64 %[sx1], vcc",
-              f"s_cbranch_execz .Lskip{j}_%="]
-        if j:
-            o += [f"v_and_b32 %[e8], 0x{(1 << j) - 1:x}, %[e7]",
-                  "v_bcnt_u32_b32 %[e8], %[e8], %[e10]"]            # e8 = this entry's slot
-        else:
-            o += ["v_mov_b32 %[e8], %[e10]"]
-        o += [f"v_cmp_gt_u32 vcc, 0x{CAND_CAP:x}, %[e8]",
-              "s_and_saveexec_b64 %[sx2], vcc",
-              "v_lshl_add_u32 %[e8], %[e8], 3, %[qc64k]",
-              "v_add_u32 %[e8], %[sn1m], %[e8]",                    # byte offset of cand[q][slot]
-              f"global_store_dword %[e8], %[u{j}], %[candb]",
-              f"v_add_u32 %[e5], {16 * (j >> 2) + (j & 3)}, %[e11]",
-              "global_store_dword %[e8], %[e5], %[candb] offset:4",
-              "s_andn2_b64 exec, %[sx2], exec",                     # lanes whose slot is past the list
+        lo, hi = 60 + 2 * j, 61 + 2 * j
+        o += [f"s_bcnt1_i32_b64 %[st0], s[{lo}:{hi}]",
+              f"s_cbranch_scc0 .Lskip{j}_%=",
+              f"s_mov_b64 exec, s[{lo}:{hi}]",
+              f"v_mbcnt_lo_u32_b32 %[e8], s{lo}, 0",
+              f"v_mbcnt_hi_u32_b32 %[e8], s{hi}, %[e8]",
+              "v_add_u32 %[e8], %[wcnt], %[e8]",                    # e8 = this entry's slot
+              f"v_add_u32 %[e5], {16 * (j >> 2) + (j & 3)}, %[e11]",  # e5 = row
+              f"v_cmp_gt_u32 vcc, 0x{lcw:x}, %[e8]",
+              "s_and_b64 exec, exec, vcc",                          # slots inside the LDS staging area
+              "v_lshl_add_u32 %[e7], %[e8], 2, %[stg]",
+              f"ds_write_b32 %[e7], %[u{j}]",
+              f"ds_write_b32 %[e7], %[e5] offset:{lcw * 4}",
+              f"ds_write_b32 %[e7], %[e9] offset:{lcw * 8}",
+              f"s_andn2_b64 exec, s[{lo}:{hi}], vcc",               # the rest
+              f"s_cbranch_execz .Lnext{j}_%=",
+              f"v_cmp_gt_u32 vcc, 0x{capw:x}, %[e8]",
+              f"s_mov_b64 s[76:77], exec",
+              "s_and_b64 exec, exec, vcc",                          # slots inside the global buffer
+              "v_lshlrev_b32 %[e7], 2, %[e8]",
+              f"global_store_dword %[e7], %[u{j}], %[wgbu]",
+              "global_store_dword %[e7], %[e5], %[wgbr]",
+              "global_store_dword %[e7], %[e9], %[wgbq]",
+              "s_andn2_b64 exec, s[76:77], vcc",                    # slots past the buffer
+              "v_lshlrev_b32 %[e7], 2, %[e9]",
               "v_mov_b32 %[e5], 1",
-              "global_store_dword %[e9], %[e5], %[ovfb]",
-              f".Lskip{j}_%=:",
-              "s_mov_b64 exec, %[sx1]"]
-    o += [".Lslowend_%=:", "s_mov_b64 exec, %[sx0]", f"s_setpc_b64 {RET}"]
+              "global_store_dword %[e7], %[e5], %[ovfb]",           # overflow[q] = 1: the query is re-run exactly
+              f".Lnext{j}_%=:",
+              "s_add_u32 %[wcnt], %[wcnt], %[st0]",
+              f".Lskip{j}_%=:"]
+    o += ["s_mov_b64 exec, -1", f"s_setpc_b64 {RET}"]
     return o
+
+
+def gen_flush(NW):
+    """Kernel end: the wave's staged entries go to its global buffer, its count to wgcnt."""
+    lcw = lds_stage_cap(NW)
+    return ["s_waitcnt vmcnt(0) lgkmcnt(0)",   # ring / Q sets still in flight that nobody consumes; staged entries landed
+            f"s_min_u32 %[st0], %[wcnt], 0x{lcw:x}",
+            "v_mbcnt_lo_u32_b32 %[e0], -1, 0",
+            "v_mbcnt_hi_u32_b32 %[e0], -1, %[e0]",          # e0 = lane
+            ".Lflush_%=:",
+            "v_cmp_gt_u32 vcc, %[st0], %[e0]",
+            "s_and_saveexec_b64 s[76:77], vcc",
+            "s_cbranch_execz .Lflushed_%=",
+            "v_lshl_add_u32 %[e1], %[e0], 2, %[stg]",
+            "ds_read_b32 %[e2], %[e1]",
+            f"ds_read_b32 %[e3], %[e1] offset:{lcw * 4}",
+            f"ds_read_b32 %[e4], %[e1] offset:{lcw * 8}",
+            "v_lshlrev_b32 %[e1], 2, %[e0]",
+            "s_waitcnt lgkmcnt(0)",
+            "global_store_dword %[e1], %[e2], %[wgbu]",
+            "global_store_dword %[e1], %[e3], %[wgbr]",
+            "global_store_dword %[e1], %[e4], %[wgbq]",
+            "v_add_u32 %[e0], 64, %[e0]",
+            "s_mov_b64 exec, s[76:77]",
+            "s_branch .Lflush_%=",
+            ".Lflushed_%=:",
+            "s_mov_b64 exec, -1",
+            "v_mov_b32 %[e0], %[wcnt]",
+            "v_mov_b32 %[e1], 0",
+            "global_store_dword %[e1], %[e0], %[wgcp]",     # all lanes store the same value: this wave's entry count
+            "s_waitcnt vmcnt(0)"]
 
 
 def generate(space, R, QD, NW, nt=False):
@@ -333,6 +388,7 @@ def generate(space, R, QD, NW, nt=False):
     a("s_mov_b32 s91, s83")
     a("s_mov_b32 %[tl], %[ntiles]")
     a("s_mov_b32 %[trow], %[row0]")
+    a("s_mov_b32 %[wcnt], 0")
     a("v_add_u32 %[ldr], 0x8000, %[lane16]")   # the first chunk toggles it to buffer 0
     a("v_mov_b32 %[ldw], %[qvoff]")            # ... and this one to buffer 1
     # ---- prologue: Q chunk 0 -> LDS buffer 0, chunk 1 -> the sets, k-steps 0..R-1 -> the ring
@@ -394,10 +450,10 @@ def generate(space, R, QD, NW, nt=False):
     a("s_sub_u32 %[tl], %[tl], 1")
     a("s_cmp_lg_u32 %[tl], 0")
     a("s_cbranch_scc1 .Ltile_%=")
-    a("s_waitcnt vmcnt(0)")              # ring / Q sets still have loads in flight that nobody consumes
+    out += gen_flush(NW)
     a("s_branch .Ldone_%=")
     out += gen_hit_stubs()
-    out += gen_slow()
+    out += gen_slow(NW)
     a(".Ldone_%=:")
 
     ops_out, ops_in = [], []
@@ -420,20 +476,19 @@ def generate(space, R, QD, NW, nt=False):
     for j in range(12):
         ops_out.append(f'[e{j}] "=&v"(ve[{j}])')
     ops_out += ['[ldr] "=&v"(ldr)', '[ldw] "=&v"(ldw)']
-    for name in ("xso0", "xso1", "qcur", "cnt", "st0", "tl", "trow", "sn64", "sn1m"):
-        ops_out.append(f'[{name}] "=&s"(s_{name})')
-    for name in ("sx0", "sx1", "sx2"):
+    for name in ("xso0", "xso1", "qcur", "cnt", "st0", "tl", "trow", "sn64", "wcnt"):
         ops_out.append(f'[{name}] "=&s"(s_{name})')
     ops_in += ['[qsrd] "s"(qsrd)', '[lane16] "v"(lane16)', '[qvoff] "v"(qvoff)', '[rnvoff] "v"(rnvoff)',
-               '[thra] "v"(thra)', '[qoff4] "v"(qoff4)', '[qc64k] "v"(qc64k)', '[crow] "v"(crow)',
+               '[thra] "v"(thra)', '[c16v] "v"(c16v)', '[crow] "v"(crow)', '[stg] "v"(stg)',
                '[xlo] "s"(xlo)', '[xhi] "s"(xhi)', '[wbytes] "s"(wbytes)', '[xslo] "s"(xslo)', '[xshi] "s"(xshi)',
                '[rnlo] "s"(rnlo)', '[rnhi] "s"(rnhi)', '[rnstride] "s"(rnstride)',
                '[row0] "s"(row0)', '[rowstride] "s"(rowstride)', '[ntiles] "s"(ntiles)',
                '[pb] "s"(pb)', '[qbytes] "s"(qbytes)', '[nb] "s"(nb)', '[qcur0] "s"(qcur0)', '[qc1] "s"(qc1)',
-               '[k0] "s"(k0)', '[cntb] "s"(cntb)', '[candb] "s"(candb)', '[ovfb] "s"(ovfb)']
+               '[k0] "s"(k0)', '[wgbu] "s"(wgbu)', '[wgbr] "s"(wgbr)', '[wgbq] "s"(wgbq)', '[wgcp] "s"(wgcp)',
+               '[ovfb] "s"(ovfb)']
     if space == "l2":
         ops_in.append('[k1] "s"(k1)')
-    clobbers = ['"memory"', '"scc"', '"vcc"'] + [f'"s{i}"' for i in range(80, 94)] + [f'"a{i}"' for i in range(128)]
+    clobbers = ['"memory"', '"scc"', '"vcc"'] + [f'"s{i}"' for i in range(60, 78)] + [f'"s{i}"' for i in range(80, 94)] + [f'"a{i}"' for i in range(128)]
 
     text = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.",
             f"// filter scan body: space {space}, NW={NW} waves, ring R={R} k-steps, B fragments read {QD} ahead"
@@ -448,12 +503,16 @@ def generate(space, R, QD, NW, nt=False):
 
 
 # (space, NW, R, nt) instantiated by kernels_filter.hip: the production set, and experiments (cosine only)
-CONFIGS = [(sp, nw, r, True, 4) for sp in SPACES for nw in (4, 8) for r in (2, 4)] + [
-    ("cosine", 4, 4, False, 4), ("cosine", 8, 4, False, 4), ("cosine", 8, 6, True, 4), ("cosine", 8, 4, True, 8)]
+CONFIGS = [(sp, nw, r, True, 4, False) for sp in SPACES for nw in (4, 8) for r in (2, 4)] + [
+    ("cosine", 4, 4, False, 4, False), ("cosine", 8, 4, False, 4, False)]
+# timing diagnostics (cosine, NW=8, R=4, nt): QD slot carries the knob: 101 = nolds, 102 = nox, 103 = both
+DIAG = {101: {"nolds"}, 102: {"nox"}, 103: {"nolds", "nox"}, 104: {"nolds", "nox", "nobar"},
+        107: {"nohit"}}
 
 
-def inc_name(space, nw, r, nt, qd):
-    return f"scan_asm_{space}_nw{nw}_r{r}{'_nt' if nt else ''}{'_qd%d' % qd if qd != 4 else ''}.inc"
+def inc_name(space, nw, r, nt, qd, tb):
+    return (f"scan_asm_{space}_nw{nw}_r{r}{'_nt' if nt else ''}{'_qd%d' % qd if qd != 4 else ''}"
+            f"{'_tb' if tb else ''}.inc")
 
 
 def main():
@@ -461,22 +520,36 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + ["scan_asm_dispatch.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
     for c in CONFIGS:
-        space, nw, r, nt, qd = c
+        space, nw, r, nt, qd, tb = c
         (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt))
+    for code, knobs in DIAG.items():
+        DBG.clear()
+        DBG.update(knobs)
+        (Path(args.outdir) / f"scan_asm_diag{code}.inc").write_text(generate("cosine", 4, 4, 8, True))
+        DBG.clear()
     disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD>."]
-    for i, (space, nw, r, nt, qd) in enumerate(CONFIGS):
-        cond = f"SPACE == {SPACES[space]} && NW == {nw} && R == {r} && NT == {'true' if nt else 'false'} && QD == {qd}"
+    for i, (space, nw, r, nt, qd, tb) in enumerate(CONFIGS):
+        cond = (f"SPACE == {SPACES[space]} && NW == {nw} && R == {r} && NT == {'true' if nt else 'false'} && QD == {qd}"
+                "")
         disp.append(("if" if i == 0 else "} else if") + f" constexpr ({cond}) {{")
-        disp.append(f'#include "{inc_name(space, nw, r, nt, qd)}"')
+        disp.append(f'#include "{inc_name(space, nw, r, nt, qd, tb)}"')
+    for code in DIAG:
+        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code}) {{")
+        disp.append(f'#include "scan_asm_diag{code}.inc"')
     disp.append("} else {")
     disp.append('    static_assert(SPACE < 0, "configuration not generated: add it to CONFIGS in tools/gen_scan_asm.py");')
     disp.append("}")
     (Path(args.outdir) / "scan_asm_dispatch.inc").write_text("\n".join(disp) + "\n")
+    (Path(args.outdir) / "scan_asm_consts.inc").write_text(
+        "// GENERATED by tools/gen_scan_asm.py -- do not edit.\n"
+        f"constexpr int kAsmWgCap = {WG_CAP};\n"
+        f"constexpr int kAsmStageCapNw4 = {lds_stage_cap(4)};  // entries per wave staged in LDS\n"
+        f"constexpr int kAsmStageCapNw8 = {lds_stage_cap(8)};\n")
     print("wrote", len(names), "files to", args.outdir)
 
 

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--waves", type=int, default=6)
     ap.add_argument("--envs", default="MLVDB_SCAN_ASM=0;MLVDB_SCAN_ASM=1;MLVDB_SCAN_ASM=1,MLVDB_SCAN_NW=8")
     ap.add_argument("--space", default="cosine")
+    ap.add_argument("--no-check", action="store_true", help="timing diagnostics that change the answer")
     args = ap.parse_args()
     import torch
 
@@ -64,7 +65,7 @@ def main():
             ids = lab.cpu().numpy().copy()
             if ref is None:
                 ref = ids
-            assert np.array_equal(ids, ref), f"variant {c} changed the answer"
+            assert args.no_check or np.array_equal(ids, ref), f"variant {c} changed the answer"
     print(f"rows {args.rows} dim {args.dim} batch {args.batch}")
     for c in combos:
         scan = np.median(res[c]["scan"])
