@@ -452,8 +452,14 @@ __global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(
 // (u[cap], row[cap], q[cap] each) go to the per-query lists.  Entries are counted per query in LDS
 // first, so the block issues one device-scope atomic per query it has entries for (a per-entry
 // atomic on 256 hot counters cost ~90 us per launch).
-__global__ __launch_bounds__(256) void filter_scatter_kernel(const FilterArgs a, const int cap, const int nw) {
+__global__ __launch_bounds__(256) void filter_scatter_kernel(const FilterArgs a, const int cap, const int nw, const int dbg) {
     __shared__ uint32_t hist[kFilterQueries], base[kFilterQueries];
+    if (dbg && threadIdx.x < (unsigned)nw && (blockIdx.x % 64) == 0) {  // MLVDB_SCAN_DIAG=108: in-kernel cycle stamps
+        const uint32_t* bq = reinterpret_cast<const uint32_t*>(
+            reinterpret_cast<const char*>(a.wgbuf + (size_t)(blockIdx.x * nw + threadIdx.x) * cap) + (size_t)cap * 8);
+        printf("stamp wg %d wave %d: barrier-parked %u of %u cycles, entries %u\n", (int)blockIdx.x, (int)threadIdx.x,
+               bq[cap - 2], bq[cap - 1], a.wgcnt[blockIdx.x * nw + threadIdx.x]);
+    }
     hist[threadIdx.x] = 0;
     __syncthreads();
     for (int w = 0; w < nw; ++w) {
@@ -501,7 +507,7 @@ typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 #include "scan_asm_consts.inc"
 static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagree");
 
-template <int SPACE, int R, int NW, bool NT, int QD>
+template <int SPACE, int R, int NW, bool NT, int QD, bool PRIO>
 __global__ __launch_bounds__(NW * 64, 2) void filter_scan_asm_kernel(const FilterArgs a, const int64_t tile_begin,
                                                                       const int64_t tile_end, const float e1) {
     constexpr int kThreads = NW * 64;
@@ -559,6 +565,9 @@ __global__ __launch_bounds__(NW * 64, 2) void filter_scan_asm_kernel(const Filte
     }
     const float k0 = SPACE == kSpaceCosine ? e1 + 2.0f * kSlack : e1 + kSlack;
     const float k1 = -(1.0f - kSlack);
+    // the later-dispatched half of the workgroup's waves (readfirstlane: an "s" operand must live in an SGPR)
+    const uint32_t wtype = __builtin_amdgcn_readfirstlane(wave >= NW / 2 ? 1u : 0u);
+    (void)wtype;
     // this wave's append buffer in global memory: u[cap], row[cap], q[cap]
     constexpr int kCapW = kWgCap / NW;
     const char* wgb = reinterpret_cast<const char*>(a.wgbuf + ((size_t)blockIdx.x * NW + wave) * kCapW);
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(NW * 64, 2) void filter_scan_asm_kernel(const Filte
     u32x4s xring[R * 2], qsa[kQPer], qsb[kQPer], qt[QD > 8 ? 4 : QD];
     float vr[8], vp[8], vu[8];
     uint32_t ve[12], ldr, ldw;
-    uint32_t s_xso0, s_xso1, s_qcur, s_cnt, s_st0, s_tl, s_trow, s_sn64, s_wcnt;
+    uint32_t s_xso0, s_xso1, s_qcur, s_cnt, s_st0, s_tl, s_trow, s_sn64, s_wcnt, s_sacc0, s_sacc1;
     (void)vp;
     (void)k1;
 #include "scan_asm_dispatch.inc"
@@ -973,7 +982,7 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
     return hipGetLastError();
 }
 
-template <int SPACE, int R, int NW, bool NT = false, int QD = 4>
+template <int SPACE, int R, int NW, bool NT = false, int QD = 4, bool PRIO = false>
 static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
     constexpr int tile_rows = NW * 32;
     const int64_t tile_begin = row_begin / tile_rows;
@@ -984,7 +993,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     const int64_t ntiles = tile_end - tile_begin;
     const int max_grid = 256 * (8 / NW);  // two waves per SIMD on every CU (<= kScanMaxGrid)  // two waves per SIMD on every CU
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
-    auto kern = filter_scan_asm_kernel<SPACE, R, NW, NT, QD>;
+    auto kern = filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO>;
     static bool configured = false;  // per instantiation
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -995,7 +1004,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end, filter_e1(a.ld));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    filter_scatter_kernel<<<grid, 256, 0, s>>>(a, kWgCap / NW, NW);
+    filter_scatter_kernel<<<grid, 256, 0, s>>>(a, kWgCap / NW, NW, QD == 108 ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -1014,6 +1023,8 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
         // multiple of R.  MLVDB_SCAN_NW / _NT / _R / _QD select the other generated variants (tuning).
         const int nw = env_int("MLVDB_SCAN_NW", 8);
         if constexpr (SPACE == kSpaceCosine) {
+            if (nw == 8 && nkc % 2 == 0 && env_int("MLVDB_SCAN_PRIO", 0) != 0)
+                return launch_scan_asm<SPACE, 4, 8, true, 4, true>(a, row_begin, row_end, s);
             if (nkc % 2 == 0 && env_int("MLVDB_SCAN_NT", 1) == 0)
                 return nw == 8 ? launch_scan_asm<SPACE, 4, 8, false>(a, row_begin, row_end, s)
                                : launch_scan_asm<SPACE, 4, 4, false>(a, row_begin, row_end, s);
@@ -1023,6 +1034,7 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                 case 103: return launch_scan_asm<SPACE, 4, 8, true, 103>(a, row_begin, row_end, s);
                 case 104: return launch_scan_asm<SPACE, 4, 8, true, 104>(a, row_begin, row_end, s);
                 case 107: return launch_scan_asm<SPACE, 4, 8, true, 107>(a, row_begin, row_end, s);
+                case 108: return launch_scan_asm<SPACE, 4, 8, true, 108>(a, row_begin, row_end, s);
                 default: break;
             }
         }

@@ -54,6 +54,7 @@ class Sched:
         self.vm_done = 0
         self.lg_done = 0
         self.recording = True
+        self.label = 0
 
     def emit(self, text):
         if "nobar" in DBG and text == "s_barrier":
@@ -112,10 +113,11 @@ def ring(b, m):
 
 
 # explicit scalar registers (listed as clobbers): descriptors need sub-register arithmetic
+PRIO_STEPS = {8: (0, 2), 12: (1, 2), 16: (0, 1), 20: (1, 1), 24: (0, 0), 28: (1, 0)}   # fragment -> (wave half, priority)
 XCUR, XNEXT, RNS, RET = "s[80:83]", "s[84:87]", "s[88:91]", "s[92:93]"
 
 
-def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt):
+def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False):
     """One 64-column chunk = 2 k-steps = 32 fragments x 2 MFMAs."""
     s.emit("v_xor_b32 %[ldr], 0x8000, %[ldr]")
     s.emit("v_xor_b32 %[ldw], 0x8000, %[ldw]")
@@ -157,11 +159,27 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt):
             plan[f] = ("l", setname, i, half)
             f += 1
 
+    if prio:
+        s.emit("s_setprio 3")
     for f0 in range(QD):
         read(f0)
     for f in range(32):
         h, n = f >> 4, f & 15
         b = (step0 + h) % R
+        if prio and f in PRIO_STEPS:
+            # Experiment (off by default).  The two waves of a SIMD share its MFMA pipe and issue is
+            # arbitrated by priority, then age: left alone, the older wave (0..NW/2-1) runs its 64 MFMAs
+            # of the chunk first and parks at the barrier for a third of its life (s_memtime stamps:
+            # 35 % vs 5 % for the younger half).  Priority that falls with progress (3, 2, 1, 0 per
+            # quarter chunk), the younger wave's steps half a quarter later, makes the two leapfrog
+            # every 4 fragments and evens the parking out at 7 % -- and the scan gets 3 % SLOWER: the
+            # kernel is power-bound (tools/probe), cycles saved come back as a lower clock.
+            who, level = PRIO_STEPS[f]
+            s.emit(f"s_cmp_eq_u32 %[wtype], {who}")
+            s.emit(f"s_cbranch_scc0 .Lp{s.label}_%=")
+            s.emit(f"s_setprio {level}")
+            s.emit(f".Lp{s.label}_%=:")
+            s.label += 1
         if n == 0:
             s.need_vm(*[("x", b, m) for m in range(MT)])
         s.need_lg(("rd", f))
@@ -187,10 +205,18 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt):
     s.emit("s_cmp_eq_u32 %[qcur], %[qbytes]")
     s.emit("s_cselect_b32 %[qcur], 0, %[qcur]")
     s.drain_lg()
+    if "stamp" in DBG:   # cycles parked at the barrier, summed in an SGPR (timing diagnostic)
+        s.emit("s_memtime s[78:79]")
+        s.emit("s_waitcnt lgkmcnt(0)")
+        s.emit("s_sub_u32 %[sacc0], %[sacc0], s78")
     s.emit("s_barrier")
+    if "stamp" in DBG:
+        s.emit("s_memtime s[78:79]")
+        s.emit("s_waitcnt lgkmcnt(0)")
+        s.emit("s_add_u32 %[sacc0], %[sacc0], s78")
 
 
-def gen_body(s, R, QD, KQ, NW, first, last, nt):
+def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False):
     if last:
         # |x| of this lane's 8 rows (rows 4g..4g+3 of both panels) for the admission test
         for j in range(8):
@@ -198,18 +224,19 @@ def gen_body(s, R, QD, KQ, NW, first, last, nt):
             s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{off}" if off else ""),
                    ("rn", j))
     for ch in range(R // 2):
-        gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last, nt)
+        gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last, nt, prio)
     if last:
         s.need_vm(*[("rn", j) for j in range(8)])
 
 
-def body_lines(R, QD, KQ, NW, first, last, nt):
+def body_lines(R, QD, KQ, NW, first, last, nt, prio=False, label0=0):
     s = Sched()
     s.recording = False
     for _ in range(2):   # history: every predecessor issues this pattern of memory operations
-        gen_body(s, R, QD, KQ, NW, False, False, nt)
+        gen_body(s, R, QD, KQ, NW, False, False, nt, prio)
     s.recording = True
-    gen_body(s, R, QD, KQ, NW, first, last, nt)
+    s.label = label0
+    gen_body(s, R, QD, KQ, NW, first, last, nt, prio)
     return s.lines
 
 
@@ -370,7 +397,7 @@ def gen_flush(NW):
             "s_waitcnt vmcnt(0)"]
 
 
-def generate(space, R, QD, NW, nt=False):
+def generate(space, R, QD, NW, nt=False, prio=False):
     assert R in (2, 4, 6) and 2 <= QD <= 8
     KQ = 1024 // (NW * 64)
     out = []
@@ -389,6 +416,11 @@ def generate(space, R, QD, NW, nt=False):
     a("s_mov_b32 %[tl], %[ntiles]")
     a("s_mov_b32 %[trow], %[row0]")
     a("s_mov_b32 %[wcnt], 0")
+    if "stamp" in DBG:
+        a("s_mov_b32 %[sacc0], 0")
+        a("s_memtime s[78:79]")
+        a("s_waitcnt lgkmcnt(0)")
+        a("s_mov_b32 %[sacc1], s78")
     a("v_add_u32 %[ldr], 0x8000, %[lane16]")   # the first chunk toggles it to buffer 0
     a("v_mov_b32 %[ldw], %[qvoff]")            # ... and this one to buffer 1
     # ---- prologue: Q chunk 0 -> LDS buffer 0, chunk 1 -> the sets, k-steps 0..R-1 -> the ring
@@ -427,20 +459,22 @@ def generate(space, R, QD, NW, nt=False):
     a("s_add_u32 %[xso1], %[pb], %[xso0]")
     a("s_cmp_eq_u32 %[nb], 1")
     a("s_cbranch_scc1 .Lsingle_%=")
-    out += body_lines(R, QD, KQ, NW, True, False, nt)
+    out += body_lines(R, QD, KQ, NW, True, False, nt, prio, 0)
     a("s_sub_u32 %[cnt], %[nb], 2")
     a(".Lloop_%=:")
     a("s_cmp_eq_u32 %[cnt], 0")
     a("s_cbranch_scc1 .Llast_%=")
-    out += body_lines(R, QD, KQ, NW, False, False, nt)
+    out += body_lines(R, QD, KQ, NW, False, False, nt, prio, 100)
     a("s_sub_u32 %[cnt], %[cnt], 1")
     a("s_branch .Lloop_%=")
     a(".Llast_%=:")
-    out += body_lines(R, QD, KQ, NW, False, True, nt)
+    out += body_lines(R, QD, KQ, NW, False, True, nt, prio, 200)
     a("s_branch .Ladmit_%=")
     a(".Lsingle_%=:")
-    out += body_lines(R, QD, KQ, NW, True, True, nt)
+    out += body_lines(R, QD, KQ, NW, True, True, nt, prio, 300)
     a(".Ladmit_%=:")
+    if prio:
+        a("s_setprio 0")
     out += gen_admission(space)
     a("s_mov_b32 s80, s84")
     a("s_mov_b32 s81, s85")
@@ -451,6 +485,16 @@ def generate(space, R, QD, NW, nt=False):
     a("s_cmp_lg_u32 %[tl], 0")
     a("s_cbranch_scc1 .Ltile_%=")
     out += gen_flush(NW)
+    if "stamp" in DBG:   # q[cap-2] = cycles parked at barriers, q[cap-1] = cycles of the whole kernel body
+        a("s_memtime s[78:79]")
+        a("s_waitcnt lgkmcnt(0)")
+        a("s_sub_u32 %[sacc1], s78, %[sacc1]")
+        a(f"v_mov_b32 %[e1], 0x{(WG_CAP // NW - 2) * 4:x}")
+        a("v_mov_b32 %[e2], %[sacc0]")
+        a("v_mov_b32 %[e3], %[sacc1]")
+        a("global_store_dword %[e1], %[e2], %[wgbq]")
+        a("global_store_dword %[e1], %[e3], %[wgbq] offset:4")
+        a("s_waitcnt vmcnt(0)")
     a("s_branch .Ldone_%=")
     out += gen_hit_stubs()
     out += gen_slow(NW)
@@ -476,7 +520,7 @@ def generate(space, R, QD, NW, nt=False):
     for j in range(12):
         ops_out.append(f'[e{j}] "=&v"(ve[{j}])')
     ops_out += ['[ldr] "=&v"(ldr)', '[ldw] "=&v"(ldw)']
-    for name in ("xso0", "xso1", "qcur", "cnt", "st0", "tl", "trow", "sn64", "wcnt"):
+    for name in ("xso0", "xso1", "qcur", "cnt", "st0", "tl", "trow", "sn64", "wcnt", "sacc0", "sacc1"):
         ops_out.append(f'[{name}] "=&s"(s_{name})')
     ops_in += ['[qsrd] "s"(qsrd)', '[lane16] "v"(lane16)', '[qvoff] "v"(qvoff)', '[rnvoff] "v"(rnvoff)',
                '[thra] "v"(thra)', '[c16v] "v"(c16v)', '[crow] "v"(crow)', '[stg] "v"(stg)',
@@ -484,15 +528,15 @@ def generate(space, R, QD, NW, nt=False):
                '[rnlo] "s"(rnlo)', '[rnhi] "s"(rnhi)', '[rnstride] "s"(rnstride)',
                '[row0] "s"(row0)', '[rowstride] "s"(rowstride)', '[ntiles] "s"(ntiles)',
                '[pb] "s"(pb)', '[qbytes] "s"(qbytes)', '[nb] "s"(nb)', '[qcur0] "s"(qcur0)', '[qc1] "s"(qc1)',
-               '[k0] "s"(k0)', '[wgbu] "s"(wgbu)', '[wgbr] "s"(wgbr)', '[wgbq] "s"(wgbq)', '[wgcp] "s"(wgcp)',
+               '[k0] "s"(k0)', '[wtype] "s"(wtype)', '[wgbu] "s"(wgbu)', '[wgbr] "s"(wgbr)', '[wgbq] "s"(wgbq)', '[wgcp] "s"(wgcp)',
                '[ovfb] "s"(ovfb)']
     if space == "l2":
         ops_in.append('[k1] "s"(k1)')
-    clobbers = ['"memory"', '"scc"', '"vcc"'] + [f'"s{i}"' for i in range(60, 78)] + [f'"s{i}"' for i in range(80, 94)] + [f'"a{i}"' for i in range(128)]
+    clobbers = ['"memory"', '"scc"', '"vcc"'] + [f'"s{i}"' for i in range(60, 80)] + [f'"s{i}"' for i in range(80, 94)] + [f'"a{i}"' for i in range(128)]
 
     text = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.",
             f"// filter scan body: space {space}, NW={NW} waves, ring R={R} k-steps, B fragments read {QD} ahead"
-            f"{', X loads non-temporal' if nt else ''}.",
+            f"{', X loads non-temporal' if nt else ''}{', progress-based wave priority' if prio else ''}.",
             "asm volatile("]
     for ln in out:
         text.append(f'    "{ln}\\n\\t"')
@@ -504,15 +548,15 @@ def generate(space, R, QD, NW, nt=False):
 
 # (space, NW, R, nt) instantiated by kernels_filter.hip: the production set, and experiments (cosine only)
 CONFIGS = [(sp, nw, r, True, 4, False) for sp in SPACES for nw in (4, 8) for r in (2, 4)] + [
-    ("cosine", 4, 4, False, 4, False), ("cosine", 8, 4, False, 4, False)]
+    ("cosine", 4, 4, False, 4, False), ("cosine", 8, 4, False, 4, False), ("cosine", 8, 4, True, 4, True)]
 # timing diagnostics (cosine, NW=8, R=4, nt): QD slot carries the knob: 101 = nolds, 102 = nox, 103 = both
 DIAG = {101: {"nolds"}, 102: {"nox"}, 103: {"nolds", "nox"}, 104: {"nolds", "nox", "nobar"},
-        107: {"nohit"}}
+        107: {"nohit"}, 108: {"stamp"}}
 
 
-def inc_name(space, nw, r, nt, qd, tb):
+def inc_name(space, nw, r, nt, qd, prio):
     return (f"scan_asm_{space}_nw{nw}_r{r}{'_nt' if nt else ''}{'_qd%d' % qd if qd != 4 else ''}"
-            f"{'_tb' if tb else ''}.inc")
+            f"{'_pr' if prio else ''}.inc")
 
 
 def main():
@@ -525,21 +569,21 @@ def main():
         print(" ".join(names))
         return
     for c in CONFIGS:
-        space, nw, r, nt, qd, tb = c
-        (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt))
+        space, nw, r, nt, qd, prio = c
+        (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt, prio))
     for code, knobs in DIAG.items():
         DBG.clear()
         DBG.update(knobs)
-        (Path(args.outdir) / f"scan_asm_diag{code}.inc").write_text(generate("cosine", 4, 4, 8, True))
+        (Path(args.outdir) / f"scan_asm_diag{code}.inc").write_text(generate("cosine", 4, 4, 8, True, False))
         DBG.clear()
-    disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD>."]
-    for i, (space, nw, r, nt, qd, tb) in enumerate(CONFIGS):
+    disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO>."]
+    for i, (space, nw, r, nt, qd, prio) in enumerate(CONFIGS):
         cond = (f"SPACE == {SPACES[space]} && NW == {nw} && R == {r} && NT == {'true' if nt else 'false'} && QD == {qd}"
-                "")
+                f" && PRIO == {'true' if prio else 'false'}")
         disp.append(("if" if i == 0 else "} else if") + f" constexpr ({cond}) {{")
-        disp.append(f'#include "{inc_name(space, nw, r, nt, qd, tb)}"')
+        disp.append(f'#include "{inc_name(space, nw, r, nt, qd, prio)}"')
     for code in DIAG:
-        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code}) {{")
+        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false) {{")
         disp.append(f'#include "scan_asm_diag{code}.inc"')
     disp.append("} else {")
     disp.append('    static_assert(SPACE < 0, "configuration not generated: add it to CONFIGS in tools/gen_scan_asm.py");')
