@@ -507,14 +507,15 @@ typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 #include "scan_asm_consts.inc"
 static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagree");
 
-template <int SPACE, int R, int NW, bool NT, int QD, bool PRIO>
-__global__ __launch_bounds__(NW * 64, 2) void filter_scan_asm_kernel(const FilterArgs a, const int64_t tile_begin,
+template <int SPACE, int R, int NW, bool NT, int QD, bool PRIO, int MT>
+__global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kernel(const FilterArgs a, const int64_t tile_begin,
                                                                       const int64_t tile_end, const float e1) {
     constexpr int kThreads = NW * 64;
     constexpr int kQPer = 1024 / kThreads;  // uint4 of a Q half-chunk moved per thread
-    constexpr int kTileRowsV = NW * 32;
+    constexpr int kWaveRows = 16 * MT;  // MT = 2: two waves per SIMD; MT = 4: one, 64 rows each
+    constexpr int kTileRowsV = NW * kWaveRows;
     constexpr int kQBufs = 2;
-    constexpr int kStageCap = NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4;  // appended entries a wave stages in LDS
+    constexpr int kStageCap = MT == 4 ? kAsmStageCapNw4Mt4 : (NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4);  // entries a wave stages in LDS
     // LDS: [2][32 KiB] Q chunks at offset 0, thr[256], qscale[256], [NW waves] staging {u[], row[], q[]}
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* thr_l = reinterpret_cast<float*>(smem + kQBufs * kChunkVec * sizeof(uint4));
@@ -538,12 +539,12 @@ __global__ __launch_bounds__(NW * 64, 2) void filter_scan_asm_kernel(const Filte
 
     const uint32_t chunk_bytes = (uint32_t)(kChunkVec * sizeof(uint4));
     const uint32_t pb = (uint32_t)a.ld * 32u;  // bytes of one bf16 panel (16 rows)
-    const uint32_t wbytes = 2 * pb;            // this wave's two panels of a tile
+    const uint32_t wbytes = MT * pb;           // this wave's panels of a tile
     const uint64_t tile_bytes = (uint64_t)NW * wbytes;
     const int64_t first_tile = tile_begin + blockIdx.x;
     const uint64_t xbase = reinterpret_cast<uint64_t>(a.Xb) + (uint64_t)first_tile * tile_bytes + (uint64_t)wave * wbytes;
     const uint64_t xstride = (uint64_t)gridDim.x * tile_bytes;
-    const uint64_t rnbase = reinterpret_cast<uint64_t>(a.rn + first_tile * kTileRowsV + wave * 32);
+    const uint64_t rnbase = reinterpret_cast<uint64_t>(a.rn + first_tile * kTileRowsV + wave * kWaveRows);
     const uint32_t xlo = (uint32_t)xbase, xhi = (uint32_t)(xbase >> 32) & 0xffffu;
     const uint32_t xslo = (uint32_t)xstride, xshi = (uint32_t)(xstride >> 32);
     const uint32_t rnlo = (uint32_t)rnbase, rnhi = (uint32_t)(rnbase >> 32) & 0xffffu;
@@ -582,14 +583,16 @@ __global__ __launch_bounds__(NW * 64, 2) void filter_scan_asm_kernel(const Filte
     const uint32_t rnvoff = g * 16;
     const uint32_t thra = (uint32_t)(kQBufs * chunk_bytes) + c16 * 4;
     const uint32_t c16v = c16;
-    const uint32_t crow = (uint32_t)wave * 32u + g * 4;
+    const uint32_t crow = (uint32_t)wave * (uint32_t)kWaveRows + g * 4;
     static_assert(kWgCap == 16384 && sizeof(WgEntry) == 16, "the assembly hard-codes the append buffer geometry");
 
-    u32x4s xring[R * 2], qsa[kQPer], qsb[kQPer], qt[QD > 8 ? 4 : QD];
-    float vr[8], vp[8], vu[8];
+    u32x4s xring[R * MT], qsa[kQPer], qsb[kQPer], qt[QD > 8 ? 4 : QD];
+    float vr[4 * MT], vp[4 * MT], vu[4 * MT];
     uint32_t ve[12], ldr, ldw;
-    uint32_t s_xso0, s_xso1, s_qcur, s_cnt, s_st0, s_tl, s_trow, s_sn64, s_wcnt, s_sacc0, s_sacc1;
+    uint32_t s_xso0, s_xso1, s_xso2, s_xso3, s_qcur, s_cnt, s_st0, s_tl, s_trow, s_sn64, s_wcnt, s_sacc0, s_sacc1;
     (void)vp;
+    (void)s_xso2;
+    (void)s_xso3;
     (void)k1;
 #include "scan_asm_dispatch.inc"
 }
@@ -982,18 +985,18 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
     return hipGetLastError();
 }
 
-template <int SPACE, int R, int NW, bool NT = false, int QD = 4, bool PRIO = false>
+template <int SPACE, int R, int NW, bool NT = false, int QD = 4, bool PRIO = false, int MT = 2>
 static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
-    constexpr int tile_rows = NW * 32;
+    constexpr int tile_rows = NW * 16 * MT;
     const int64_t tile_begin = row_begin / tile_rows;
     const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
     if (tile_end <= tile_begin) return hipSuccess;
     const size_t lds = 2 * kChunkVec * sizeof(uint4) + 2 * kFilterQueries * sizeof(float) +
-                       (size_t)NW * 12 * (NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4);
+                       (size_t)NW * 12 * (MT == 4 ? kAsmStageCapNw4Mt4 : (NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4));
     const int64_t ntiles = tile_end - tile_begin;
-    const int max_grid = 256 * (8 / NW);  // two waves per SIMD on every CU (<= kScanMaxGrid)  // two waves per SIMD on every CU
+    const int max_grid = 256 * ((16 / MT) / NW);  // two waves per SIMD on every CU (<= kScanMaxGrid)  // two waves per SIMD on every CU
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
-    auto kern = filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO>;
+    auto kern = filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT>;
     static bool configured = false;  // per instantiation
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1022,6 +1025,10 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
         // fastest (profiles/r01/scan_ab_*.txt); a ring of R k-steps needs the tile's 2*nkc k-steps to be a
         // multiple of R.  MLVDB_SCAN_NW / _NT / _R / _QD select the other generated variants (tuning).
         const int nw = env_int("MLVDB_SCAN_NW", 8);
+        if (env_int("MLVDB_SCAN_MT", 2) == 4) {  // one wave per SIMD, 64 rows per wave
+            if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true, 4, false, 4>(a, row_begin, row_end, s);
+            return launch_scan_asm<SPACE, 2, 4, true, 4, false, 4>(a, row_begin, row_end, s);
+        }
         if constexpr (SPACE == kSpaceCosine) {
             if (nw == 8 && nkc % 2 == 0 && env_int("MLVDB_SCAN_PRIO", 0) != 0)
                 return launch_scan_asm<SPACE, 4, 8, true, 4, true>(a, row_begin, row_end, s);

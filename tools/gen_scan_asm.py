@@ -12,9 +12,12 @@ through compiler-managed code at all.  Here everything that is in flight stays i
 statement, and the waits are computed by simulating the two in-order queues (vmcnt: buffer/global
 operations; lgkmcnt: LDS operations).
 
-Per wave: MT = 2 row panels (32 rows) x 16 query tiles = 32 accumulators of 16x16 in a[0:127].
-(Two waves per SIMD: hipcc splits the 256 registers 128 VGPR / 128 AGPR as soon as a kernel
-touches an AGPR, so the accumulators take the AGPRs and everything else lives in <= 128 VGPRs.)
+Per wave: MT row panels (16 rows each) x 16 query tiles = 16*MT accumulators of 16x16 in AGPRs.
+MT = 2 (32 rows, a[0:127]): two waves per SIMD -- hipcc splits the 256 registers 128 VGPR / 128 AGPR
+as soon as a kernel touches an AGPR, so the accumulators take the AGPRs and everything else lives in
+<= 128 VGPRs.  MT = 4 (64 rows, a[0:255]): one wave per SIMD, 256 + 256 registers; every B fragment
+read from LDS feeds 4 MFMAs instead of 2 and the query image is staged once per 4 waves -- less
+energy per MFMA, which is what counts on a power-bound pipe (tools/probe).
   * X (bf16 shadow panels, HBM): buffer_load_dwordx4 into a ring of R k-steps that are the MFMA A
     operands; a slot is refilled right after its last MFMA with the k-step R ahead -- the last R
     k-steps of a tile fetch the first R of the workgroup's next tile through a second descriptor,
@@ -118,7 +121,7 @@ XCUR, XNEXT, RNS, RET = "s[80:83]", "s[84:87]", "s[88:91]", "s[92:93]"
 
 
 def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False):
-    """One 64-column chunk = 2 k-steps = 32 fragments x 2 MFMAs."""
+    """One 64-column chunk = 2 k-steps = 32 fragments x MT MFMAs."""
     s.emit("v_xor_b32 %[ldr], 0x8000, %[ldr]")
     s.emit("v_xor_b32 %[ldw], 0x8000, %[ldw]")
 
@@ -132,20 +135,24 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False):
         pol = " nt" if nt else ""   # streamed once: non-temporal
         for m in range(MT):
             if last and step * 1024 < 4096:
-                so = "0" if m == 0 else "%[pb]"
+                if m >= 2:
+                    s.emit(f"s_mul_i32 %[st0], %[pb], {m}")
+                so = "0" if m == 0 else ("%[pb]" if m == 1 else "%[st0]")
                 off = f" offset:{step * 1024}" if step else ""
                 s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XNEXT}, {so} offen{off}{pol}", ("x", b, m))
             elif last:
                 if m == 0:
                     s.emit(f"s_movk_i32 %[st0], 0x{step * 1024:x}")
                 else:
-                    s.emit(f"s_add_u32 %[st0], %[pb], 0x{step * 1024:x}")
+                    if m >= 2:
+                        s.emit(f"s_mul_i32 %[st0], %[pb], {m}")
+                    s.emit(f"s_add_u32 %[st0], {'%[pb]' if m == 1 else '%[st0]'}, 0x{step * 1024:x}")
                 s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XNEXT}, %[st0] offen{pol}", ("x", b, m))
             else:
                 s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, %[xso{m}] offen{pol}", ("x", b, m))
         if not last:
-            s.emit("s_add_u32 %[xso0], %[xso0], 0x400")
-            s.emit("s_add_u32 %[xso1], %[xso1], 0x400")
+            for m in range(MT):
+                s.emit(f"s_add_u32 %[xso{m}], %[xso{m}], 0x400")
 
     # Staging plan, fragment index -> action.  Set qb (first halves) is written and re-fetched just
     # before the ring refill that follows fragment 15, set qa (second halves) just before the one
@@ -218,15 +225,15 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False):
 
 def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False):
     if last:
-        # |x| of this lane's 8 rows (rows 4g..4g+3 of both panels) for the admission test
-        for j in range(8):
+        # |x| of this lane's 4*MT rows (rows 4g..4g+3 of every panel) for the admission test
+        for j in range(4 * MT):
             off = (j >> 2) * 64 + (j & 3) * 4
             s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{off}" if off else ""),
                    ("rn", j))
     for ch in range(R // 2):
         gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last, nt, prio)
     if last:
-        s.need_vm(*[("rn", j) for j in range(8)])
+        s.need_vm(*[("rn", j) for j in range(4 * MT)])
 
 
 def body_lines(R, QD, KQ, NW, first, last, nt, prio=False, label0=0):
@@ -248,7 +255,8 @@ def gen_admission(space):
     a("s_nop 7")
     # per-row constants (scan_epilogue): cosine p0 = 1/(|x|+1e-30); ip p0 = (e1+slack)|x|;
     # l2 p0 = (e1+slack)|x|, p1 = -|x|^2 (1-slack)
-    for j in range(8):
+    NR = 4 * MT
+    for j in range(NR):
         if space == "cosine":
             a(f"v_add_f32 %[r{j}], 0x0da24260, %[r{j}]")   # + 1e-30f
             a(f"v_rcp_f32 %[r{j}], %[r{j}]")
@@ -269,12 +277,12 @@ def gen_admission(space):
     for n in range(16):
         if n + 1 < 16:
             fetch(n + 1)
-        for j in range(8):
+        for j in range(NR):
             m, i = j >> 2, j & 3
             a(f"v_accvgpr_read_b32 %[u{j}], a{(m * 16 + n) * 4 + i}")
         if space == "l2":
             s.need_lg(("sq", n))
-        for j in range(8):
+        for j in range(NR):
             if space == "cosine":
                 a(f"v_fma_f32 %[u{j}], %[u{j}], %[r{j}], %[k0]")    # k0 = e1 + 2 slack
             elif space == "ip":
@@ -284,7 +292,10 @@ def gen_admission(space):
                 a(f"v_fma_f32 %[u{j}], {sq(n)}, %[u{j}], %[p{j}]")
         a("v_max3_f32 %[e4], %[u0], %[u1], %[u2]")
         a("v_max3_f32 %[e5], %[u3], %[u4], %[u5]")
-        a("v_max3_f32 %[e4], %[u6], %[u7], %[e4]")
+        for j in range(6, NR, 4):   # two dependency chains
+            a(f"v_max3_f32 %[e4], %[u{j}], %[u{j + 1}], %[e4]")
+            if j + 3 < NR:
+                a(f"v_max3_f32 %[e5], %[u{j + 2}], %[u{j + 3}], %[e5]")
         a("v_max_f32 %[e4], %[e4], %[e5]")
         s.need_lg(("thr", n))
         a(f"v_cmp_ge_f32 vcc, %[e4], {thr(n)}")
@@ -308,14 +319,15 @@ def gen_hit_stubs():
     return out
 
 
-def lds_stage_cap(NW):
+def lds_stage_cap(NW, mt=2):
     """Entries of a wave's staging area in LDS (12 B each, SoA): what is left of the 160 KiB per CU."""
-    per_wg = (160 * 1024) // (8 // NW) - (2 * CHUNK_BYTES + 2048)
+    wgs_per_cu = (16 // mt) // NW      # mt = 2: two waves per SIMD, mt = 4: one
+    per_wg = (160 * 1024) // wgs_per_cu - (2 * CHUNK_BYTES + 2048)
     return min(WG_CAP // NW, (per_wg // NW) // 12 // 8 * 8)
 
 
 def gen_slow(NW):
-    """u0..u7 = bounds of this lane's 8 rows for query sn64 + c16, e6 = threshold.
+    """u0.. = bounds of this lane's 4*MT rows for query sn64 + c16, e6 = threshold.
 
     Wave-private append: the wave keeps its entry count in an SGPR; per row j the passing lanes form
     an SGPR mask and take the slots count + (passing lanes below), via v_mbcnt -- no atomics.
@@ -325,50 +337,52 @@ def gen_slow(NW):
     prefetch (measured: 17 % of the scan).  Entries beyond the staging area go straight to global
     memory (same slot numbering), entries beyond the global buffer flag their query as overflowed."""
     capw = WG_CAP // NW
-    lcw = lds_stage_cap(NW)
-    o = [".Lslow_%=:"]
-    for j in range(8):
-        o.append(f"v_cmp_ge_f32_e64 s[{60 + 2 * j}:{61 + 2 * j}], %[u{j}], %[e6]")
-    o += ["v_add_u32 %[e9], %[sn64], %[c16v]",                      # e9 = query
-          "v_add_u32 %[e11], %[trow], %[crow]"]                     # e11 = this lane's first row
-    for j in range(8):
-        lo, hi = 60 + 2 * j, 61 + 2 * j
-        o += [f"s_bcnt1_i32_b64 %[st0], s[{lo}:{hi}]",
-              f"s_cbranch_scc0 .Lskip{j}_%=",
-              f"s_mov_b64 exec, s[{lo}:{hi}]",
-              f"v_mbcnt_lo_u32_b32 %[e8], s{lo}, 0",
-              f"v_mbcnt_hi_u32_b32 %[e8], s{hi}, %[e8]",
-              "v_add_u32 %[e8], %[wcnt], %[e8]",                    # e8 = this entry's slot
-              f"v_add_u32 %[e5], {16 * (j >> 2) + (j & 3)}, %[e11]",  # e5 = row
-              f"v_cmp_gt_u32 vcc, 0x{lcw:x}, %[e8]",
-              "s_and_b64 exec, exec, vcc",                          # slots inside the LDS staging area
-              "v_lshl_add_u32 %[e7], %[e8], 2, %[stg]",
-              f"ds_write_b32 %[e7], %[u{j}]",
-              f"ds_write_b32 %[e7], %[e5] offset:{lcw * 4}",
-              f"ds_write_b32 %[e7], %[e9] offset:{lcw * 8}",
-              f"s_andn2_b64 exec, s[{lo}:{hi}], vcc",               # the rest
-              f"s_cbranch_execz .Lnext{j}_%=",
-              f"v_cmp_gt_u32 vcc, 0x{capw:x}, %[e8]",
-              f"s_mov_b64 s[76:77], exec",
-              "s_and_b64 exec, exec, vcc",                          # slots inside the global buffer
-              "v_lshlrev_b32 %[e7], 2, %[e8]",
-              f"global_store_dword %[e7], %[u{j}], %[wgbu]",
-              "global_store_dword %[e7], %[e5], %[wgbr]",
-              "global_store_dword %[e7], %[e9], %[wgbq]",
-              "s_andn2_b64 exec, s[76:77], vcc",                    # slots past the buffer
-              "v_lshlrev_b32 %[e7], 2, %[e9]",
-              "v_mov_b32 %[e5], 1",
-              "global_store_dword %[e7], %[e5], %[ovfb]",           # overflow[q] = 1: the query is re-run exactly
-              f".Lnext{j}_%=:",
-              "s_add_u32 %[wcnt], %[wcnt], %[st0]",
-              f".Lskip{j}_%=:"]
+    lcw = lds_stage_cap(NW, MT)
+    o = [".Lslow_%=:",
+         "v_add_u32 %[e9], %[sn64], %[c16v]",                       # e9 = query
+         "v_add_u32 %[e11], %[trow], %[crow]"]                      # e11 = this lane's first row
+    for j0 in range(0, 4 * MT, 8):                                  # 8 rows (mask registers) at a time
+        for j in range(j0, j0 + 8):
+            o.append(f"v_cmp_ge_f32_e64 s[{60 + 2 * (j - j0)}:{61 + 2 * (j - j0)}], %[u{j}], %[e6]")
+        for j in range(j0, j0 + 8):
+            lo, hi = 60 + 2 * (j - j0), 61 + 2 * (j - j0)
+            o += [f"s_bcnt1_i32_b64 %[st0], s[{lo}:{hi}]",
+                  f"s_cbranch_scc0 .Lskip{j}_%=",
+                  f"s_mov_b64 exec, s[{lo}:{hi}]",
+                  f"v_mbcnt_lo_u32_b32 %[e8], s{lo}, 0",
+                  f"v_mbcnt_hi_u32_b32 %[e8], s{hi}, %[e8]",
+                  "v_add_u32 %[e8], %[wcnt], %[e8]",                    # e8 = this entry's slot
+                  f"v_add_u32 %[e5], {16 * (j >> 2) + (j & 3)}, %[e11]",  # e5 = row
+                  f"v_cmp_gt_u32 vcc, 0x{lcw:x}, %[e8]",
+                  "s_and_b64 exec, exec, vcc",                          # slots inside the LDS staging area
+                  "v_lshl_add_u32 %[e7], %[e8], 2, %[stg]",
+                  f"ds_write_b32 %[e7], %[u{j}]",
+                  f"ds_write_b32 %[e7], %[e5] offset:{lcw * 4}",
+                  f"ds_write_b32 %[e7], %[e9] offset:{lcw * 8}",
+                  f"s_andn2_b64 exec, s[{lo}:{hi}], vcc",               # the rest
+                  f"s_cbranch_execz .Lnext{j}_%=",
+                  f"v_cmp_gt_u32 vcc, 0x{capw:x}, %[e8]",
+                  f"s_mov_b64 s[76:77], exec",
+                  "s_and_b64 exec, exec, vcc",                          # slots inside the global buffer
+                  "v_lshlrev_b32 %[e7], 2, %[e8]",
+                  f"global_store_dword %[e7], %[u{j}], %[wgbu]",
+                  "global_store_dword %[e7], %[e5], %[wgbr]",
+                  "global_store_dword %[e7], %[e9], %[wgbq]",
+                  "s_andn2_b64 exec, s[76:77], vcc",                    # slots past the buffer
+                  "v_lshlrev_b32 %[e7], 2, %[e9]",
+                  "v_mov_b32 %[e5], 1",
+                  "global_store_dword %[e7], %[e5], %[ovfb]",           # overflow[q] = 1: the query is re-run exactly
+                  f".Lnext{j}_%=:",
+                  "s_add_u32 %[wcnt], %[wcnt], %[st0]",
+                  f".Lskip{j}_%=:",
+                  "s_mov_b64 exec, -1"]
     o += ["s_mov_b64 exec, -1", f"s_setpc_b64 {RET}"]
     return o
 
 
 def gen_flush(NW):
     """Kernel end: the wave's staged entries go to its global buffer, its count to wgcnt."""
-    lcw = lds_stage_cap(NW)
+    lcw = lds_stage_cap(NW, MT)
     return ["s_waitcnt vmcnt(0) lgkmcnt(0)",   # ring / Q sets still in flight that nobody consumes; staged entries landed
             f"s_min_u32 %[st0], %[wcnt], 0x{lcw:x}",
             "v_mbcnt_lo_u32_b32 %[e0], -1, 0",
@@ -397,8 +411,10 @@ def gen_flush(NW):
             "s_waitcnt vmcnt(0)"]
 
 
-def generate(space, R, QD, NW, nt=False, prio=False):
-    assert R in (2, 4, 6) and 2 <= QD <= 8
+def generate(space, R, QD, NW, nt=False, prio=False, mt=2):
+    global MT
+    MT = mt
+    assert R in (2, 4, 6) and 2 <= QD <= 8 and mt in (2, 4)
     KQ = 1024 // (NW * 64)
     out = []
     a = out.append
@@ -411,7 +427,7 @@ def generate(space, R, QD, NW, nt=False, prio=False):
     a("s_mov_b32 s87, s83")
     a("s_mov_b32 s88, %[rnlo]")
     a("s_mov_b32 s89, %[rnhi]")
-    a("s_movk_i32 s90, 0x80")          # 32 rows x 4 B
+    a(f"s_movk_i32 s90, 0x{16 * MT * 4:x}")   # this wave's rows x 4 B
     a("s_mov_b32 s91, s83")
     a("s_mov_b32 %[tl], %[ntiles]")
     a("s_mov_b32 %[trow], %[row0]")
@@ -430,12 +446,15 @@ def generate(space, R, QD, NW, nt=False, prio=False):
             a(f"buffer_load_dwordx4 %[{setname}{i}], %[qvoff], %[qsrd], %[st0] offen")
     for b in range(R):
         for m in range(MT):
+            if m >= 2:
+                a(f"s_mul_i32 %[st0], %[pb], {m}")
             if b * 1024 < 4096:
-                so = "0" if m == 0 else "%[pb]"
+                so = "0" if m == 0 else ("%[pb]" if m == 1 else "%[st0]")
                 off = f" offset:{b * 1024}" if b else ""
                 a(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, {so} offen{off}")
             else:
-                a(f"s_movk_i32 %[st0], 0x{b * 1024:x}" if m == 0 else f"s_add_u32 %[st0], %[pb], 0x{b * 1024:x}")
+                a(f"s_movk_i32 %[st0], 0x{b * 1024:x}" if m == 0 else
+                  f"s_add_u32 %[st0], {'%[pb]' if m == 1 else '%[st0]'}, 0x{b * 1024:x}")
                 a(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, %[st0] offen")
     a("s_waitcnt vmcnt(0)")
     for half, setname in ((0, "qb"), (1, "qa")):
@@ -457,6 +476,9 @@ def generate(space, R, QD, NW, nt=False, prio=False):
     a("s_mov_b32 %[qcur], %[qcur0]")
     a(f"s_movk_i32 %[xso0], 0x{R * 1024:x}")
     a("s_add_u32 %[xso1], %[pb], %[xso0]")
+    for m in range(2, MT):
+        a(f"s_mul_i32 %[xso{m}], %[pb], {m}")
+        a(f"s_add_u32 %[xso{m}], %[xso{m}], %[xso0]")
     a("s_cmp_eq_u32 %[nb], 1")
     a("s_cbranch_scc1 .Lsingle_%=")
     out += body_lines(R, QD, KQ, NW, True, False, nt, prio, 0)
@@ -510,17 +532,17 @@ def generate(space, R, QD, NW, nt=False, prio=False):
         ops_out.append(f'[qb{i}] "=&v"(qsb[{i}])')
     for i in range(QD):
         ops_out.append(f'[t{i}] "=&v"(qt[{i}])')
-    for j in range(8):
+    for j in range(4 * MT):
         ops_out.append(f'[r{j}] "=&v"(vr[{j}])')
     if space == "l2":
-        for j in range(8):
+        for j in range(4 * MT):
             ops_out.append(f'[p{j}] "=&v"(vp[{j}])')
-    for j in range(8):
+    for j in range(4 * MT):
         ops_out.append(f'[u{j}] "=&v"(vu[{j}])')
     for j in range(12):
         ops_out.append(f'[e{j}] "=&v"(ve[{j}])')
     ops_out += ['[ldr] "=&v"(ldr)', '[ldw] "=&v"(ldw)']
-    for name in ("xso0", "xso1", "qcur", "cnt", "st0", "tl", "trow", "sn64", "wcnt", "sacc0", "sacc1"):
+    for name in [f"xso{m}" for m in range(MT)] + ["qcur", "cnt", "st0", "tl", "trow", "sn64", "wcnt", "sacc0", "sacc1"]:
         ops_out.append(f'[{name}] "=&s"(s_{name})')
     ops_in += ['[qsrd] "s"(qsrd)', '[lane16] "v"(lane16)', '[qvoff] "v"(qvoff)', '[rnvoff] "v"(rnvoff)',
                '[thra] "v"(thra)', '[c16v] "v"(c16v)', '[crow] "v"(crow)', '[stg] "v"(stg)',
@@ -532,10 +554,10 @@ def generate(space, R, QD, NW, nt=False, prio=False):
                '[ovfb] "s"(ovfb)']
     if space == "l2":
         ops_in.append('[k1] "s"(k1)')
-    clobbers = ['"memory"', '"scc"', '"vcc"'] + [f'"s{i}"' for i in range(60, 80)] + [f'"s{i}"' for i in range(80, 94)] + [f'"a{i}"' for i in range(128)]
+    clobbers = ['"memory"', '"scc"', '"vcc"'] + [f'"s{i}"' for i in range(60, 80)] + [f'"s{i}"' for i in range(80, 94)] + [f'"a{i}"' for i in range(64 * MT)]
 
     text = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.",
-            f"// filter scan body: space {space}, NW={NW} waves, ring R={R} k-steps, B fragments read {QD} ahead"
+            f"// filter scan body: space {space}, NW={NW} waves x {16 * MT} rows, ring R={R} k-steps, B fragments read {QD} ahead"
             f"{', X loads non-temporal' if nt else ''}{', progress-based wave priority' if prio else ''}.",
             "asm volatile("]
     for ln in out:
@@ -547,16 +569,17 @@ def generate(space, R, QD, NW, nt=False, prio=False):
 
 
 # (space, NW, R, nt) instantiated by kernels_filter.hip: the production set, and experiments (cosine only)
-CONFIGS = [(sp, nw, r, True, 4, False) for sp in SPACES for nw in (4, 8) for r in (2, 4)] + [
-    ("cosine", 4, 4, False, 4, False), ("cosine", 8, 4, False, 4, False), ("cosine", 8, 4, True, 4, True)]
+CONFIGS = [(sp, nw, r, True, 4, False, 2) for sp in SPACES for nw in (4, 8) for r in (2, 4)] + [
+    ("cosine", 4, 4, False, 4, False, 2), ("cosine", 8, 4, False, 4, False, 2), ("cosine", 8, 4, True, 4, True, 2)] + [
+    (sp, 4, r, True, 4, False, 4) for sp in SPACES for r in (2, 4)]
 # timing diagnostics (cosine, NW=8, R=4, nt): QD slot carries the knob: 101 = nolds, 102 = nox, 103 = both
 DIAG = {101: {"nolds"}, 102: {"nox"}, 103: {"nolds", "nox"}, 104: {"nolds", "nox", "nobar"},
         107: {"nohit"}, 108: {"stamp"}}
 
 
-def inc_name(space, nw, r, nt, qd, prio):
+def inc_name(space, nw, r, nt, qd, prio, mt):
     return (f"scan_asm_{space}_nw{nw}_r{r}{'_nt' if nt else ''}{'_qd%d' % qd if qd != 4 else ''}"
-            f"{'_pr' if prio else ''}.inc")
+            f"{'_pr' if prio else ''}{'_mt4' if mt == 4 else ''}.inc")
 
 
 def main():
@@ -569,21 +592,21 @@ def main():
         print(" ".join(names))
         return
     for c in CONFIGS:
-        space, nw, r, nt, qd, prio = c
-        (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt, prio))
+        space, nw, r, nt, qd, prio, mt = c
+        (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt, prio, mt))
     for code, knobs in DIAG.items():
         DBG.clear()
         DBG.update(knobs)
         (Path(args.outdir) / f"scan_asm_diag{code}.inc").write_text(generate("cosine", 4, 4, 8, True, False))
         DBG.clear()
-    disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO>."]
-    for i, (space, nw, r, nt, qd, prio) in enumerate(CONFIGS):
+    disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT>."]
+    for i, (space, nw, r, nt, qd, prio, mt) in enumerate(CONFIGS):
         cond = (f"SPACE == {SPACES[space]} && NW == {nw} && R == {r} && NT == {'true' if nt else 'false'} && QD == {qd}"
-                f" && PRIO == {'true' if prio else 'false'}")
+                f" && PRIO == {'true' if prio else 'false'} && MT == {mt}")
         disp.append(("if" if i == 0 else "} else if") + f" constexpr ({cond}) {{")
-        disp.append(f'#include "{inc_name(space, nw, r, nt, qd, prio)}"')
+        disp.append(f'#include "{inc_name(space, nw, r, nt, qd, prio, mt)}"')
     for code in DIAG:
-        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false) {{")
+        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2) {{")
         disp.append(f'#include "scan_asm_diag{code}.inc"')
     disp.append("} else {")
     disp.append('    static_assert(SPACE < 0, "configuration not generated: add it to CONFIGS in tools/gen_scan_asm.py");')
@@ -593,7 +616,8 @@ def main():
         "// GENERATED by tools/gen_scan_asm.py -- do not edit.\n"
         f"constexpr int kAsmWgCap = {WG_CAP};\n"
         f"constexpr int kAsmStageCapNw4 = {lds_stage_cap(4)};  // entries per wave staged in LDS\n"
-        f"constexpr int kAsmStageCapNw8 = {lds_stage_cap(8)};\n")
+        f"constexpr int kAsmStageCapNw8 = {lds_stage_cap(8)};\n"
+        f"constexpr int kAsmStageCapNw4Mt4 = {lds_stage_cap(4, 4)};  // one wave per SIMD, 64 rows per wave\n")
     print("wrote", len(names), "files to", args.outdir)
 
 
