@@ -62,7 +62,7 @@ __global__ __launch_bounds__(NW * 64) void exact_scan_kernel(const ExactArgs a, 
         for (int p = 0; p < PW; ++p) {
             panel[p] = panel_begin + task * PW + p;
             const int64_t pp = panel[p] < panel_end ? panel[p] : panel_begin;  // keep the address valid
-            base[p] = a.X + pp * (int64_t)(kPanelRows * ld) + lane * 4;
+            base[p] = a.X + pp * (int64_t)(kPanelRows * ld) + lane_group_offset(lane);
         }
         double acc[PW][QT];
         double nx[PW];
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(512) void exact_range_kernel(const FilterArgs a, co
         for (int p = 0; p < PW; ++p) {
             panel[p] = task * PW + p;
             const int64_t pp = panel[p] < panel_end ? panel[p] : 0;
-            base[p] = a.X + pp * (int64_t)(kPanelRows * ld) + lane * 4;
+            base[p] = a.X + pp * (int64_t)(kPanelRows * ld) + lane_group_offset(lane);
         }
         double acc[PW][QT];
         double nx[PW];

@@ -310,7 +310,8 @@ __global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(
     // prefetched) plus a 32-bit byte offset of the half-chunk inside the panels.  Everything is
     // advanced incrementally on the scalar unit; no multiplies on the per-step path.
     auto tile_of = [&](int64_t i) __attribute__((always_inline)) { return tile_begin + blockIdx.x + i * gridDim.x; };
-    const uint32_t lane_off16 = lane * 16;  // the only per-lane part of every X address
+    // the only per-lane part of every X address: lane-linear in the bf16 shadow, row r / column quarter g in the fp32 panels
+    const uint32_t lane_off16 = XB ? lane * 16 : lane_group_offset(lane) * 4;
     const uint32_t panel_bytes = (uint32_t)(panel_stride * (XB ? 2 : 4));
     const uint32_t wave_bytes = kMT * panel_bytes;         // this wave's panels of one tile
     const uint32_t row_bytes_in_panel = (uint32_t)ld * (XB ? 32 : 64);  // bytes of one panel (groups of 1 KiB)
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_kernel(cons
         const uint32_t idx = i0 + r;
         const bool have = idx < cnt;
         const int32_t row = have ? list[idx].row : 0;
-        const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 4 + g * 64};
+        const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 16 + g * 4};
         double acc[1][1], nx[1];
         accumulate_rows<SPACE, 1, 1, 8>(base, qs, ld, g, acc, nx);
         const double dist = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
@@ -865,7 +866,7 @@ __global__ __launch_bounds__(256) void range_rescore_kernel(const FilterArgs a, 
         const uint32_t idx = i0 + r;
         const bool have = idx < cnt;
         const int32_t row = have ? list[idx].row : 0;
-        const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 4 + g * 64};
+        const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 16 + g * 4};
         double acc[1][1], nx[1];
         accumulate_rows<SPACE, 1, 1, 4>(base, qs, ld, g, acc, nx);
         const double dist = finish_distance<SPACE>(acc[0][0], nx[0], qinv);

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int nkb = ld >> 4;
     for (int64_t panel = first_panel + wave; panel <= last_panel; panel += nwaves) {
-        const float* base = X + panel * (int64_t)(kPanelRows * ld) + lane * 4;
+        const float* base = X + panel * (int64_t)(kPanelRows * ld) + lane_group_offset(lane);
         double s = 0.0;
         for (int kb = 0; kb < nkb; ++kb) {
             const float4 x = *reinterpret_cast<const float4*>(base + (int64_t)kb * kGroupFloats);

@@ -2,15 +2,17 @@
 //
 // Rows are fp32, padded to ld = round_up(dim, 16) floats.  16 consecutive rows form a
 // PANEL of 16*ld floats.  Inside a panel the 16-column groups follow each other (1 KiB
-// each); inside a group the order is [g = (col%16)/4][r = row%16][col%4]:
+// each); inside a group the rows follow each other, 16 columns = 64 bytes per row:
 //
-//     offset(row, col) = (row/16)*16*ld + (col/16)*256 + ((col%16)/4)*64 + (row%16)*4 + col%4
+//     offset(row, col) = (row/16)*16*ld + (col/16)*256 + (row%16)*16 + col%16
 //
-// Why: lane l = 16*g + r of a wavefront that loads a float4 at group_base + 4*l touches
-// one fully contiguous, lane-linear 1 KiB burst, and what it receives -- 4 consecutive
-// columns of row r -- is exactly its share of the A operand of v_mfma_f32_16x16x32_bf16
-// (row = lane & 15, k-slice = lane >> 4).  The exact (fp64) kernels use the same mapping,
-// so a row's dot product needs a 2-step cross-lane reduction instead of 6.
+// Why: lane l = 16*g + r of a wavefront that loads a float4 at group_base + lane_group_offset(l)
+// takes part in one fully contiguous 1 KiB burst, and what it receives -- columns 4g..4g+3 of
+// row r -- is exactly its share of the A operand of v_mfma_f32_16x16x32_bf16 (row = lane & 15,
+// k-slice = lane >> 4).  The exact (fp64) kernels use the same mapping, so a row's dot product
+// needs a 2-step cross-lane reduction instead of 6.  A single row is a sequence of whole 64-byte
+// pieces (one per group, 1 KiB apart), so the rescoring kernels' row gathers use every byte of
+// the sectors they touch (with the groups split by column quarter they used a quarter).
 #pragma once
 #include <stdint.h>
 
@@ -29,9 +31,11 @@ constexpr int kTileRows = 768;     // capacity granule: a multiple of every kern
 MLVDB_HD int32_t layout_ld(int32_t dim) { return (dim + 15) & ~15; }
 
 MLVDB_HD int64_t layout_offset(int64_t row, int32_t col, int32_t ld) {
-    return (row >> 4) * (int64_t)(kPanelRows * ld) + (int64_t)(col >> 4) * kGroupFloats + ((col & 15) >> 2) * 64 +
-           (row & 15) * 4 + (col & 3);
+    return (row >> 4) * (int64_t)(kPanelRows * ld) + (int64_t)(col >> 4) * kGroupFloats + (row & 15) * 16 + (col & 15);
 }
+
+// float offset, inside a group, of the float4 that lane l = 16*g + r owns (row r, columns 4g..4g+3)
+MLVDB_HD int32_t lane_group_offset(int32_t lane) { return (lane & 15) * 16 + (lane >> 4) * 4; }
 
 // bf16 shadow of the corpus (filter scans only): same 16-row panels, 32-column groups of 1 KiB,
 // inside a group [g = (col%32)/8][r = row%16][col%8]: lane 16*g + r of a wave reads 16 contiguous

@@ -59,7 +59,7 @@ def test_no_device_is_a_loud_error_not_a_fallback(gpu_available):
 
 
 def test_panel_layout_restatement():
-    """layout.h: offset(row, col) = (row/16)*16*ld + (col/16)*256 + ((col%16)/4)*64 + (row%16)*4 + col%4."""
+    """layout.h: offset(row, col) = (row/16)*16*ld + (col/16)*256 + (row%16)*16 + col%16."""
     lib = _native.load()
     for dim in (1, 3, 16, 17, 100, 128, 768, 1000):
         ld = lib.mlvdb_layout_ld(dim)
@@ -69,12 +69,17 @@ def test_panel_layout_restatement():
         seen = set()
         for r in rows:
             for c in cols[:: max(1, ld // 40)]:
-                want = (r // 16) * 16 * ld + (c // 16) * 256 + ((c % 16) // 4) * 64 + (r % 16) * 4 + c % 4
+                want = (r // 16) * 16 * ld + (c // 16) * 256 + (r % 16) * 16 + c % 16
                 got = lib.mlvdb_layout_offset(int(r), int(c), ld)
                 assert got == want
                 seen.add(got)
-        # a wave's load: lane l = 16*g + r reads the float4 at group_base + 4*l  (lane-linear 1 KiB)
+        # a wave's load: lane l = 16*g + r reads the float4 of row r, columns 4g..4g+3 of a group; the 64
+        # float4 tile one 1 KiB group exactly, and a row's 16 columns are one contiguous 64-byte piece
         base = lib.mlvdb_layout_offset(32, 16, ld)
+        offs = set()
         for lane in range(64):
             g, r = divmod(lane, 16)
-            assert lib.mlvdb_layout_offset(32 + r, 16 + 4 * g, ld) == base + 4 * lane
+            o = lib.mlvdb_layout_offset(32 + r, 16 + 4 * g, ld)
+            assert o == base + 16 * r + 4 * g
+            offs.update(range(o - base, o - base + 4))
+        assert offs == set(range(256))
