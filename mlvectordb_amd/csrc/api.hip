@@ -298,8 +298,7 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
     // the update kernel turns them into thresholds; the remaining rows follow in rounds of growing
     // size so that thresholds tighten early
     const int64_t n_seed = std::min<int64_t>(h->total, kSeedRows);
-    HIP_TRY(h, launch_filter_seed_scan(fa, n_seed, s));
-    HIP_TRY(h, launch_filter_update(fa, k, s));
+    HIP_TRY(h, launch_filter_seed_scan(fa, n_seed, k, s));  // includes the first threshold update
     const int64_t bounds[] = {kSeedRows, (int64_t)kFilterTile * 64, (int64_t)kFilterTile * 2048, h->total};
     for (int r = 0; r < 3; ++r) {
         const int64_t b = std::min(bounds[r], h->total), e = std::min(bounds[r + 1], h->total);

@@ -113,9 +113,9 @@ hipError_t launch_filter_prep(const FilterArgs& a, hipStream_t s);
 // seed thresholds from exact kNN distances of a prefix of the corpus: seed_d64[q][k]
 hipError_t launch_filter_seed_thr(const FilterArgs& a, const double* seed_d64, int32_t k, hipStream_t s);
 hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s);
-// dense seeding pass over rows [0,row_end), row_end <= kSeedRows: all bounds -> candidate lists, cnt set
+// dense seeding pass over rows [0,row_end), row_end <= kSeedRows: all bounds -> candidate lists -> thresholds (update)
 constexpr int kSeedRows = 3840;  // a multiple of every scan tile (128, 192) and <= kCandCap
-hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, hipStream_t s);
+hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t k, hipStream_t s);
 hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s);
 hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
                                  int32_t* out_counts, double* out_d64, unsigned long long* rescored, hipStream_t s);

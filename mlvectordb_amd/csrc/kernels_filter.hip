@@ -618,15 +618,16 @@ __device__ __forceinline__ float float_from_order_key(uint32_t k) {
 // u < thr are dropped.  The k-th largest lower bound is found by a 4-pass radix select on the order
 // keys through an LDS histogram (no shuffles, 8 barriers), then the list is compacted through LDS.
 constexpr int kUpdThreads = 256;
-__global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const FilterArgs a, const int32_t k, const float e1) {
+__global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const FilterArgs a, const int32_t k, const float e1,
+                                                                      const int32_t forced_cnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     CandEntry* stage = reinterpret_cast<CandEntry*>(smem);                                   // [kCandCap]
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem + kCandCap * sizeof(CandEntry));       // [kCandCap]
     uint32_t* hist = keys + kCandCap;                                                        // [256]
-    uint32_t* s_scan = hist + 256;                                                           // [8]
+    uint32_t* s_scan = hist + 256;                                                           // [16]
     const int q = blockIdx.x;
     if (q >= a.nq || a.overflow[q]) return;
-    const uint32_t cnt = a.cnt[q];
+    const uint32_t cnt = forced_cnt >= 0 ? (uint32_t)forced_cnt : a.cnt[q];  // after the dense seeding pass: every slot
     if (cnt > (uint32_t)kCandCap) {  // cannot happen without the flag, but never index past the list
         if (threadIdx.x == 0) a.overflow[q] = 1u;
         return;
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const Filter
     const bool need_norm = a.space != kSpaceCosine;
     float thr = a.thr[q];
     // order keys of the lower bounds (0 = not a candidate: NaN bound of a tombstoned / padding row)
-    uint32_t n_valid = 0;
+    uint32_t n_valid = 0, kmin = 0xffffffffu, kmax = 0;
     for (uint32_t idx = threadIdx.x; idx < cnt; idx += kUpdThreads) {
         const CandEntry e = list[idx];
         stage[idx] = e;
@@ -649,54 +650,81 @@ __global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const Filter
             key = float_order_key(l);
             if (key == 0) key = 1;
             ++n_valid;
+            kmin = min(kmin, key);
+            kmax = max(kmax, key);
         }
         keys[idx] = key;
     }
-    for (int off = 32; off > 0; off >>= 1) n_valid += __shfl_xor(n_valid, off);
-    if (lane == 0) s_scan[wave] = n_valid;
+    for (int off = 32; off > 0; off >>= 1) {
+        n_valid += __shfl_xor(n_valid, off);
+        kmin = min(kmin, (uint32_t)__shfl_xor(kmin, off));
+        kmax = max(kmax, (uint32_t)__shfl_xor(kmax, off));
+    }
+    if (lane == 0) {
+        s_scan[wave] = n_valid;
+        s_scan[8 + wave] = kmin;
+        s_scan[12 + wave] = kmax;
+    }
     __syncthreads();
     n_valid = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    kmin = min(min(s_scan[8], s_scan[9]), min(s_scan[10], s_scan[11]));
+    kmax = max(max(s_scan[12], s_scan[13]), max(s_scan[14], s_scan[15]));
     if (n_valid >= (uint32_t)k) {
-        // radix select, most significant byte first: prefix/mask narrow the keys, `want` = rank still wanted
-        uint32_t prefix = 0, mask = 0, want = (uint32_t)k;
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            __syncthreads();
-            hist[threadIdx.x] = 0;
-            __syncthreads();
-            for (uint32_t idx = threadIdx.x; idx < cnt; idx += kUpdThreads) {
-                const uint32_t key = keys[idx];
-                if (key != 0 && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        // Radix select, most significant digit first: prefix/mask narrow the keys, `want` = rank still
+        // wanted.  The keys of one list are floats of similar size: their leading bits are all equal, and a
+        // histogram over those bits would be 256 threads adding to one LDS word (measured: the bulk of the
+        // kernel).  So the first digit starts at the highest bit in which any two keys differ.
+        const uint32_t diff = kmin ^ kmax;
+        uint32_t prefix = kmax, mask = 0xffffffffu, want = (uint32_t)k;  // all keys equal: the answer is that key
+        if (diff != 0) {
+            const int hb = 31 - __builtin_clz(diff);
+            mask = hb == 31 ? 0u : ~((2u << hb) - 1u);
+            prefix = kmax & mask;
+            int shift = hb >= 7 ? hb - 7 : 0, width = hb - shift + 1;
+            for (;;) {
+                __syncthreads();
+                hist[threadIdx.x] = 0;
+                __syncthreads();
+                const uint32_t dmask = (1u << width) - 1u;
+                for (uint32_t idx = threadIdx.x; idx < cnt; idx += kUpdThreads) {
+                    const uint32_t key = keys[idx];
+                    if (key != 0 && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & dmask], 1u);
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    // suffix sums over the 256 bins: lane owns bins 4*lane .. 4*lane+3
+                    const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                    uint32_t above = h0 + h1 + h2 + h3;  // becomes the count in bins of higher lanes
+                    uint32_t run = above;
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t v = __shfl_down(run, off);
+                        if (lane + off < 64) run += v;
+                    }
+                    above = run - above;  // keys in bins > 4*lane+3
+                    // the wanted bin is the highest bin b with (count in bins >= b) >= want
+                    const uint32_t c3 = above + h3, c2 = c3 + h2, c1 = c2 + h1, c0 = c1 + h0;
+                    int bin = -1;
+                    uint32_t before = 0;  // keys in bins strictly above the chosen one
+                    if (above < want && c0 >= want) {
+                        if (c3 >= want) { bin = 4 * lane + 3; before = above; }
+                        else if (c2 >= want) { bin = 4 * lane + 2; before = c3; }
+                        else if (c1 >= want) { bin = 4 * lane + 1; before = c2; }
+                        else { bin = 4 * lane; before = c1; }
+                    }
+                    if (bin >= 0) {
+                        s_scan[4] = (uint32_t)bin;
+                        s_scan[5] = before;
+                    }
+                }
+                __syncthreads();
+                prefix |= s_scan[4] << shift;
+                mask |= dmask << shift;
+                want -= s_scan[5];
+                if (shift == 0) break;
+                const int next = shift >= 8 ? shift - 8 : 0;
+                width = shift - next;
+                shift = next;
             }
-            __syncthreads();
-            if (wave == 0) {
-                // suffix sums over the 256 bins: lane owns bins 4*lane .. 4*lane+3
-                const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
-                uint32_t above = h0 + h1 + h2 + h3;  // becomes the count in bins of higher lanes
-                uint32_t run = above;
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t v = __shfl_down(run, off);
-                    if (lane + off < 64) run += v;
-                }
-                above = run - above;  // keys in bins > 4*lane+3
-                // the wanted bin is the highest bin b with (count in bins >= b) >= want
-                const uint32_t c3 = above + h3, c2 = c3 + h2, c1 = c2 + h1, c0 = c1 + h0;
-                int bin = -1;
-                uint32_t before = 0;  // keys in bins strictly above the chosen one
-                if (above < want && c0 >= want) {
-                    if (c3 >= want) { bin = 4 * lane + 3; before = above; }
-                    else if (c2 >= want) { bin = 4 * lane + 2; before = c3; }
-                    else if (c1 >= want) { bin = 4 * lane + 1; before = c2; }
-                    else { bin = 4 * lane; before = c1; }
-                }
-                if (bin >= 0) {
-                    s_scan[4] = (uint32_t)bin;
-                    s_scan[5] = before;
-                }
-            }
-            __syncthreads();
-            prefix |= s_scan[4] << shift;
-            mask |= 255u << shift;
-            want -= s_scan[5];
         }
         const float lk = float_from_order_key(prefix);
         if (lk > thr) thr = lk;
@@ -1068,14 +1096,12 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
     return launch_scan_one<SPACE, 2, 2, false>(a, row_begin, row_end, s);
 }
 
-// Seeding pass over rows [0, row_end): every bound goes into the candidate lists (slot = row).
-// row_end <= kCandCap; the caller then sets cnt[q] = row_end rounded up to the tile and runs the
-// update kernel, which turns the lists into thresholds and drops what is below them.
-__global__ __launch_bounds__(256) void filter_set_cnt_kernel(const FilterArgs a, uint32_t value) {
-    if ((int)threadIdx.x < a.nq) a.cnt[threadIdx.x] = value;
-}
+// Seeding pass over rows [0, row_end): every bound goes into the candidate lists (slot = row),
+// row_end <= kCandCap; then the update kernel (told that every list holds row_end rounded up to
+// the tile entries) turns the lists into thresholds and drops what is below them.
+static hipError_t launch_update(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s);
 
-hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, hipStream_t s) {
+hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t k, hipStream_t s) {
     const int64_t rows = (row_end + kSeedTileRows - 1) / kSeedTileRows * kSeedTileRows;
     hipError_t e;
     const bool xb = a.Xb != nullptr;
@@ -1094,8 +1120,7 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, hipStre
             break;
     }
     if (e != hipSuccess) return e;
-    filter_set_cnt_kernel<<<1, 256, 0, s>>>(a, (uint32_t)rows);
-    return hipGetLastError();
+    return launch_update(a, k, (int32_t)rows, s);  // lists -> thresholds; cnt[q] = survivors
 }
 
 hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
@@ -1106,8 +1131,8 @@ hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t ro
     }
 }
 
-hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s) {
-    const size_t lds = (size_t)kCandCap * (sizeof(CandEntry) + sizeof(uint32_t)) + 256 * 4 + 64;
+static hipError_t launch_update(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s) {
+    const size_t lds = (size_t)kCandCap * (sizeof(CandEntry) + sizeof(uint32_t)) + 256 * 4 + 64;  // hist + s_scan[16]
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_update_kernel),
@@ -1115,9 +1140,11 @@ hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s) {
         if (e != hipSuccess) return e;
         configured = true;
     }
-    filter_update_kernel<<<a.nq, kUpdThreads, lds, s>>>(a, k, filter_e1(a.ld));
+    filter_update_kernel<<<a.nq, kUpdThreads, lds, s>>>(a, k, filter_e1(a.ld), forced_cnt);
     return hipGetLastError();
 }
+
+hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s) { return launch_update(a, k, -1, s); }
 
 hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
                                  int32_t* out_counts, double* out_d64, unsigned long long* rescored, hipStream_t s) {
