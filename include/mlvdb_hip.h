@@ -41,6 +41,7 @@ extern "C" {
 #define MLVDB_ERR_HIP 4           /* a HIP runtime call failed; see mlvdb_last_error */
 #define MLVDB_ERR_OUT_OF_MEMORY 5
 #define MLVDB_ERR_UNSUPPORTED 6   /* e.g. top_k above MLVDB_MAX_TOPK */
+#define MLVDB_ERR_INTERNAL 8      /* an internal consistency check failed */
 #define MLVDB_ERR_OVERFLOW 7      /* range query: some query had more hits than `capacity` (counts still exact) */
 
 /* distance spaces; replaces hnswlib.Index(space=...) at index.py:36 */
@@ -105,6 +106,15 @@ int mlvdb_index_append_device(mlvdb_index* h, const float* rows_device, int64_t 
  * labels are ignored; *newly_deleted receives how many rows changed state.
  */
 int mlvdb_index_tombstone(mlvdb_index* h, const int64_t* labels, int64_t n, int64_t* newly_deleted);
+
+/*
+ * Drop the tombstoned rows on the device: the live rows keep their order and become labels
+ * 0..live-1, exactly the labels a rebuild from the surviving vectors in insertion order would
+ * assign (Index.rebuild: index.py:145-162; QueryProcessor.delete's trigger: query_processor.py:58-61)
+ * -- without sending the corpus over PCIe again.  old_labels[i] receives the former label of new
+ * label i (capacity >= total - deleted entries), *live the new total.
+ */
+int mlvdb_index_compact(mlvdb_index* h, int64_t* old_labels, int64_t capacity, int64_t* live);
 
 /* total rows ever appended, and how many of them are tombstoned (index.py:27-28,103). */
 int mlvdb_index_counts(const mlvdb_index* h, int64_t* total, int64_t* deleted);

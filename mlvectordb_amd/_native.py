@@ -45,6 +45,7 @@ SIGNATURES = {
     "mlvdb_index_append": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "mlvdb_index_append_device": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "mlvdb_index_tombstone": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "mlvdb_index_compact": (C.c_int, [_P, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "mlvdb_index_counts": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mlvdb_index_reset": (C.c_int, [_P, C.c_int32]),
     "mlvdb_index_get_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),

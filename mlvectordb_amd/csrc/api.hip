@@ -588,6 +588,62 @@ int mlvdb_index_tombstone(mlvdb_index* h, const int64_t* labels, int64_t n, int6
     return MLVDB_OK;
 }
 
+int mlvdb_index_compact(mlvdb_index* h, int64_t* old_labels, int64_t capacity, int64_t* live_out) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    const int64_t want = h->total - h->deleted;
+    if (capacity < want || (want > 0 && !old_labels)) return fail(h, MLVDB_ERR_INVALID_ARG, "old_labels too small");
+    if (live_out) *live_out = want;
+    if (h->deleted == 0) {  // nothing to drop: identity
+        for (int64_t i = 0; i < want; ++i) old_labels[i] = i;
+        return MLVDB_OK;
+    }
+    hipStream_t s = h->stream;
+    const int64_t nblocks = (h->total + 1023) / 1024;
+    HIP_TRY(h, h->partial.ensure((size_t)nblocks * sizeof(uint32_t) + 64));
+    HIP_TRY(h, h->labels_in.ensure((size_t)std::max<int64_t>(want, 1) * sizeof(int32_t)));
+    uint32_t* scratch = h->partial.as<uint32_t>();
+    int32_t* old_of_new = h->labels_in.as<int32_t>();
+    unsigned long long* live_d = h->counters.as<unsigned long long>();
+    HIP_TRY(h, launch_compact_map(h->rn, h->total, scratch, live_d, old_of_new, s));
+    unsigned long long live = 0;
+    HIP_TRY(h, hipMemcpyAsync(&live, live_d, sizeof live, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    if ((int64_t)live != want) return fail(h, MLVDB_ERR_INTERNAL, "live-row count disagrees with the tombstone accounting");
+    // new buffers sized for the live rows (zero / NaN filled), gather, swap
+    const int64_t cap = round_up_rows(std::max<int64_t>(want, 1));
+    float* nX = nullptr;
+    float* nrn = nullptr;
+    void* nXb = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&nX), (size_t)cap * h->ld * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&nrn), (size_t)cap * sizeof(float));
+    if (e == hipSuccess && h->Xb) e = hipMalloc(&nXb, (size_t)cap * h->ld * 2);
+    if (e != hipSuccess) {
+        if (nX) (void)hipFree(nX);
+        if (nrn) (void)hipFree(nrn);
+        return fail(h, MLVDB_ERR_OUT_OF_MEMORY, "hipMalloc(compaction buffers)", e);
+    }
+    HIP_TRY(h, hipMemsetAsync(nX, 0, (size_t)cap * h->ld * sizeof(float), s));
+    HIP_TRY(h, hipMemsetAsync(nrn, 0xFF, (size_t)cap * sizeof(float), s));  // NaN = not a row
+    if (nXb) HIP_TRY(h, hipMemsetAsync(nXb, 0, (size_t)cap * h->ld * 2, s));
+    HIP_TRY(h, launch_compact_rows(h->X, nX, h->Xb, nXb, h->rn, nrn, old_of_new, want, h->ld, s));
+    std::vector<int32_t> host_map((size_t)want);
+    if (want > 0)
+        HIP_TRY(h, hipMemcpyAsync(host_map.data(), old_of_new, (size_t)want * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    for (int64_t i = 0; i < want; ++i) old_labels[i] = host_map[(size_t)i];
+    (void)hipFree(h->X);
+    (void)hipFree(h->rn);
+    if (h->Xb) (void)hipFree(h->Xb);
+    h->X = nX;
+    h->rn = nrn;
+    h->Xb = nXb;
+    h->capacity = cap;
+    h->total = want;
+    h->deleted = 0;
+    return MLVDB_OK;
+}
+
 int mlvdb_index_counts(const mlvdb_index* h, int64_t* total, int64_t* deleted) {
     if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");
     if (total) *total = h->total;

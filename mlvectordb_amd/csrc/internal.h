@@ -26,6 +26,13 @@ hipError_t launch_gather_rows(const float* X, float* out, int64_t first_row, int
 // rn[label] = NaN for each valid, live label; *changed += number of rows that changed state
 hipError_t launch_tombstone(float* rn, const int64_t* labels, int64_t n, int64_t total, unsigned long long* changed,
                             hipStream_t s);
+// compaction: old_of_new[new label] = old label of the live rows (rn == rn) in order, *live = their count;
+// block_scratch holds ceil(total / 1024) words
+hipError_t launch_compact_map(const float* rn, int64_t total, uint32_t* block_scratch, unsigned long long* live,
+                              int32_t* old_of_new, hipStream_t s);
+// gather the live rows (fp32 panels, bf16 shadow when Xb != nullptr, norms) into freshly zeroed / NaN-filled buffers
+hipError_t launch_compact_rows(const float* X, float* nX, const void* Xb, void* nXb, const float* rn, float* nrn,
+                               const int32_t* old_of_new, int64_t live, int32_t ld, hipStream_t s);
 // Qpad[q][0..ld) = queries[q][0..dim) zero padded; qaux[q] = 1/(|q|+1e-30) (cosine) or |q| (l2, ip)
 hipError_t launch_query_prep(const float* queries, int32_t nq, int32_t dim, int32_t ld, int32_t space, float* Qpad,
                              double* qaux, hipStream_t s);

@@ -1,6 +1,8 @@
 // Corpus maintenance kernels: row-major <-> panel layout, row norms, tombstones, query prep.
 // Reference roles: hnswlib add_items / mark_deleted as called from
 // src/mlvectordb/implementations/index.py:65,80,158 (the index copies and owns the rows).
+#include <algorithm>
+
 #include "internal.h"
 
 namespace mlvdb {
@@ -165,6 +167,132 @@ hipError_t launch_query_prep(const float* queries, int32_t nq, int32_t dim, int3
                              double* qaux, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
     query_prep_kernel<<<nq, 256, 0, s>>>(queries, dim, ld, space, Qpad, qaux);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ compaction (drop tombstoned rows)
+// Live rows (rn == rn) keep their order and move to labels 0..live-1.  Three small passes build
+// old_of_new[new label] = old label (block counts -> one-block scan -> per-block ranks), then one
+// wave per destination panel gathers the fp32 rows (whole 64-byte pieces, layout.h), the bf16 shadow
+// pieces and the norms.
+constexpr int kCompactRowsPerBlock = 1024;  // 256 threads x 4 rows
+
+__global__ __launch_bounds__(256) void compact_count_kernel(const float* __restrict__ rn, int64_t total,
+                                                            uint32_t* __restrict__ block_counts) {
+    __shared__ uint32_t wsum[4];
+    const int64_t r0 = (int64_t)blockIdx.x * kCompactRowsPerBlock + threadIdx.x * 4;
+    uint32_t c = 0;
+    for (int i = 0; i < 4; ++i)
+        if (r0 + i < total) {
+            const float v = rn[r0 + i];
+            c += v == v ? 1u : 0u;
+        }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// one block: block_counts -> exclusive offsets in place; *live = total count
+__global__ __launch_bounds__(1024) void compact_scan_kernel(uint32_t* __restrict__ block_counts, int64_t nblocks,
+                                                            unsigned long long* __restrict__ live) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = 0; base < nblocks; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_counts[i] : 0u;
+        uint32_t incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (i < nblocks) block_counts[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *live = carry_s;
+}
+
+__global__ __launch_bounds__(256) void compact_map_kernel(const float* __restrict__ rn, int64_t total,
+                                                          const uint32_t* __restrict__ block_offsets,
+                                                          int32_t* __restrict__ old_of_new) {
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * kCompactRowsPerBlock + threadIdx.x * 4;
+    bool alive[4];
+    uint32_t c = 0;
+    for (int i = 0; i < 4; ++i) {
+        const float v = r0 + i < total ? rn[r0 + i] : __builtin_nanf("");
+        alive[i] = v == v;
+        c += alive[i] ? 1u : 0u;
+    }
+    uint32_t incl = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t pos = block_offsets[blockIdx.x] + incl - c;
+    for (int w = 0; w < wave; ++w) pos += wsum[w];
+    for (int i = 0; i < 4; ++i)
+        if (alive[i]) old_of_new[pos++] = (int32_t)(r0 + i);
+}
+
+// one wave per destination panel
+__global__ __launch_bounds__(256) void compact_rows_kernel(const float* __restrict__ X, float* __restrict__ nX,
+                                                           const char* __restrict__ Xb, char* __restrict__ nXb,
+                                                           const float* __restrict__ rn, float* __restrict__ nrn,
+                                                           const int32_t* __restrict__ old_of_new, int64_t live, int32_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, g = lane >> 4;
+    const int64_t npanels = (live + 15) >> 4;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t panel_floats = (int64_t)kPanelRows * ld;
+    for (int64_t panel = wave; panel < npanels; panel += nwaves) {
+        const int64_t dst_row = panel * 16 + r;
+        const bool have = dst_row < live;
+        const int64_t src = have ? old_of_new[dst_row] : 0;
+        const float* sp = X + (src >> 4) * panel_floats + (src & 15) * 16 + g * 4;
+        float* dp = nX + panel * panel_floats + r * 16 + g * 4;
+        for (int kb = 0; kb < (ld >> 4); ++kb)
+            if (have) *reinterpret_cast<float4*>(dp + (int64_t)kb * kGroupFloats) = *reinterpret_cast<const float4*>(sp + (int64_t)kb * kGroupFloats);
+        if (Xb) {  // shadow: 32-column groups of 1 KiB, [g][r][8 bf16]
+            const char* sb = Xb + ((src >> 4) * panel_floats) * 2 + g * 256 + (src & 15) * 16;
+            char* db = nXb + (panel * panel_floats) * 2 + g * 256 + r * 16;
+            for (int kb = 0; kb < (ld >> 5); ++kb)
+                if (have) *reinterpret_cast<uint4*>(db + (int64_t)kb * 1024) = *reinterpret_cast<const uint4*>(sb + (int64_t)kb * 1024);
+        }
+        if (have && g == 0) nrn[dst_row] = rn[src];
+    }
+}
+
+hipError_t launch_compact_map(const float* rn, int64_t total, uint32_t* block_scratch, unsigned long long* live,
+                              int32_t* old_of_new, hipStream_t s) {
+    const int64_t nblocks = (total + kCompactRowsPerBlock - 1) / kCompactRowsPerBlock;
+    if (nblocks == 0) return hipMemsetAsync(live, 0, sizeof(unsigned long long), s);
+    compact_count_kernel<<<(unsigned)nblocks, 256, 0, s>>>(rn, total, block_scratch);
+    compact_scan_kernel<<<1, 1024, 0, s>>>(block_scratch, nblocks, live);
+    compact_map_kernel<<<(unsigned)nblocks, 256, 0, s>>>(rn, total, block_scratch, old_of_new);
+    return hipGetLastError();
+}
+
+hipError_t launch_compact_rows(const float* X, float* nX, const void* Xb, void* nXb, const float* rn, float* nrn,
+                               const int32_t* old_of_new, int64_t live, int32_t ld, hipStream_t s) {
+    const int64_t npanels = (live + 15) >> 4;
+    if (npanels == 0) return hipSuccess;
+    const int64_t blocks = std::min<int64_t>((npanels + 3) / 4, 256 * 8);
+    compact_rows_kernel<<<(unsigned)blocks, 256, 0, s>>>(X, nX, static_cast<const char*>(Xb), static_cast<char*>(nXb), rn, nrn,
+                                                          old_of_new, live, ld);
     return hipGetLastError();
 }
 

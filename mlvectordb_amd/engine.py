@@ -27,6 +27,8 @@ class ScanEngine(Protocol):
 
     def counts(self) -> Tuple[int, int]: ...
 
+    def compact(self) -> np.ndarray: ...
+
     def search(self, queries: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]: ...
 
     def range(self, queries: np.ndarray, radius: float, capacity: int) -> List[Tuple[np.ndarray, np.ndarray]]: ...
@@ -104,6 +106,15 @@ class HipScanEngine:
         total, deleted = C.c_int64(0), C.c_int64(0)
         self._check(self._lib.mlvdb_index_counts(self._h, C.byref(total), C.byref(deleted)), "counts")
         return int(total.value), int(deleted.value)
+
+    def compact(self) -> np.ndarray:
+        """Drop the tombstoned rows on the device; returns old_labels with old_labels[new] = old."""
+        total, deleted = self.counts()
+        old = np.empty(max(total - deleted, 1), dtype=np.int64)
+        live = C.c_int64(0)
+        self._check(self._lib.mlvdb_index_compact(self._h, old.ctypes.data_as(C.c_void_p), old.size, C.byref(live)),
+                    "mlvdb_index_compact")
+        return old[: live.value]
 
     def reset(self, space: str | None = None) -> None:
         code = -1 if space is None else _native.SPACE_CODES[space]

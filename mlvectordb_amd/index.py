@@ -158,6 +158,28 @@ class Index:
         ns = self._ns.get(namespace)
         return bool(ns and ns.rebuild_required)
 
+    def compact(self, namespace: str) -> bool:
+        """Additive: what ``rebuild`` from this namespace's surviving vectors (in insertion order) leaves
+        behind -- labels renumbered from 0, tombstones gone, flag cleared (index.py:145-162) -- computed on
+        the device from the rows the index already owns, touching no other namespace (quirk Q4) and moving
+        nothing over PCIe.  Returns False when the namespace is unknown."""
+        ns = self._ns.get(namespace)
+        if ns is None:
+            return False
+        old = ns.engine.compact()  # old[new label] = old label
+        new_l2u: Dict[int, UUID] = {}
+        for new, prev in enumerate(old.tolist()):
+            uid = ns.label_to_uuid.get(prev)
+            if uid is None:
+                raise RuntimeError(f"compaction kept label {prev}, which the host maps do not know")
+            new_l2u[new] = uid
+        ns.label_to_uuid = new_l2u
+        ns.uuid_to_label = {uid: label for label, uid in new_l2u.items()}
+        ns.total = len(new_l2u)
+        ns.deleted = 0
+        ns.rebuild_required = False
+        return True
+
     # ------------------------------------------------------------------ additive: batches and ranges
     def search_many(self, queries, top_k: int, namespace: str, metric: str) -> List[List[SearchResult]]:
         """kNN for a batch of queries in one corpus scan.

@@ -76,6 +76,9 @@ class QueryProcessor:
         self._index.remove(ids, namespace)
         probe = getattr(self._index, "is_rebuild_required", None)
         if probe and probe(namespace):
+            compact = getattr(self._index, "compact", None)
+            if compact and self._rebuild_scope != "namespace" and compact(namespace):
+                return removed  # same end state as the rebuild below, computed on the device
             full = self._storage.namespace_map
             if self._rebuild_scope == "namespace":
                 source = {namespace: full.get(namespace, [])}

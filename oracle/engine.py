@@ -41,6 +41,12 @@ class OracleScanEngine:
     def counts(self):
         return int(self._rows.shape[0]), int(self._deleted.sum())
 
+    def compact(self) -> np.ndarray:
+        old = np.nonzero(~self._deleted)[0].astype(np.int64)
+        self._rows = np.ascontiguousarray(self._rows[old])
+        self._deleted = np.zeros(old.size, dtype=bool)
+        return old
+
     def search(self, queries: np.ndarray, k: int):
         return exact_scan.knn(queries, self._rows, k, self.space, deleted=self._deleted)
 

@@ -276,3 +276,36 @@ def test_scan_kernel_variants_agree_with_oracle(variant, space, d, monkeypatch):
     got, stats = run_hip(rows, qs, 10, space, "filter", deleted, append_chunks=3)
     assert stats["strategy_used"] == 2 and stats["fallback_queries"] == 0
     assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"variant {variant}/{space}/d{d}")
+
+
+@pytest.mark.parametrize("space,d,strategy", [("cosine", 128, "filter"), ("l2", 20, "exact"), ("ip", 192, "filter")])
+def test_device_compaction_equals_a_fresh_index_of_the_survivors(space, d, strategy):
+    """mlvdb_index_compact: live rows keep their order, labels renumber from 0, rows / shadow / norms move with
+    them (searches on the compacted index == oracle on the surviving rows; get_rows returns them bit for bit),
+    appends continue after them, and compacting twice or with nothing deleted is the identity."""
+    n = 20_011
+    rows, qs = make_case(500 + d, n, d, 24, dup=True)
+    deleted = deleted_mask(3, n, 0.37)
+    eng = HipScanEngine(d, space, device=0, strategy=strategy)
+    try:
+        for part in np.array_split(rows, 3):
+            eng.append(part)
+        eng.tombstone(np.nonzero(deleted)[0])
+        old = eng.compact()
+        keep = np.nonzero(~deleted)[0]
+        assert np.array_equal(old, keep)
+        assert eng.counts() == (keep.size, 0)
+        assert np.array_equal(eng.get_rows(0, keep.size), rows[keep])
+        got = eng.search(qs, 10)
+        assert_knn_matches(got, oracle_knn(qs, rows[keep], 10, space), f"compacted/{space}")
+        assert np.array_equal(eng.compact(), np.arange(keep.size))       # nothing deleted: identity
+        extra, _ = make_case(77, 1000, d, 1)
+        assert eng.append(extra) == keep.size                            # labels continue
+        eng.tombstone(np.arange(0, keep.size, 2))                        # second generation of tombstones
+        old2 = eng.compact()
+        live2 = np.concatenate([np.arange(1, keep.size, 2), np.arange(keep.size, keep.size + 1000)])
+        assert np.array_equal(old2, live2)
+        both = np.concatenate([rows[keep], extra])[live2]
+        assert_knn_matches(eng.search(qs, 10), oracle_knn(qs, both, 10, space), f"compacted twice/{space}")
+    finally:
+        eng.close()

@@ -148,3 +148,51 @@ def test_range_search_and_euclidean_alias():
     assert [h.score for h in hits] == [0.0, 5.0]
     assert [h.score for h in i.search(VectorDTO([0, 0], {}), 3, "ns", "euclidean")] == [0.0, 5.0, 10.0]
     assert [h.score for h in i.search(VectorDTO([0, 0], {}), 3, "ns", "l2")] == [0.0, 25.0, 100.0]
+
+
+def test_compact_equals_rebuild_from_the_survivors():
+    """Index.compact (device-side in the product) leaves what a rebuild from the surviving vectors leaves:
+    labels renumbered from 0 in insertion order, tombstones and the rebuild flag gone, other namespaces intact."""
+    v = vecs(30, d=6, seed=5)
+    other = vecs(4, d=6, seed=6)
+    a, b = idx("l2", rebuild_threshold=0.2), idx("l2", rebuild_threshold=0.2)
+    for i in (a, b):
+        i.add(v, "ns")
+        i.add(other, "other")
+        i.remove([v[k].id for k in (0, 3, 4, 11, 17, 29)], "ns")
+        assert i.is_rebuild_required("ns")
+    survivors = [x for k, x in enumerate(v) if k not in (0, 3, 4, 11, 17, 29)]
+    assert a.compact("ns") and not a.compact("unknown")
+    b.rebuild({"ns": survivors, "other": other}, metric="l2")
+    assert a.namespace_counts("ns") == b.namespace_counts("ns") == (24, 0)
+    assert not a.is_rebuild_required("ns")
+    assert a._ns["ns"].uuid_to_label == b._ns["ns"].uuid_to_label
+    rng = np.random.default_rng(9)
+    for _ in range(5):
+        q = VectorDTO(values=rng.standard_normal(6).tolist(), metadata={})
+        assert a.search(q, 7, "ns", "l2") == b.search(q, 7, "ns", "l2")
+        assert a.search(q, 2, "other", "l2") == b.search(q, 2, "other", "l2")
+    more = vecs(3, d=6, seed=7)  # labels continue after the compacted rows
+    a.add(more, "ns")
+    assert sorted(a._ns["ns"].uuid_to_label[m.id] for m in more) == [24, 25, 26]
+
+
+def test_query_processor_delete_compacts_instead_of_rebuilding():
+    calls = []
+
+    class Spy(Index):
+        def rebuild(self, source, metric):
+            calls.append("rebuild")
+            return super().rebuild(source, metric)
+
+        def compact(self, namespace):
+            calls.append("compact")
+            return super().compact(namespace)
+
+    qp = QueryProcessor(InMemoryStorage(), Spy(space="cosine", engine_factory=OracleScanEngine))
+    qp.upsert_many([VectorDTO([1, 0], {"l": "a1"}), VectorDTO([0, 1], {"l": "a2"}), VectorDTO([1, 1], {"l": "a3"})], namespace="A")
+    victim = qp.find_similar(VectorDTO([1, 0], {}), 1, namespace="A")[0]["id"]
+    assert qp.delete([victim], namespace="A") == [victim]      # 1/3 >= 0.2: the rebuild trigger fires
+    assert calls == ["compact"]
+    hits = qp.find_similar(VectorDTO([1, 0], {}), 3, namespace="A")
+    assert [h["metadata"]["l"] for h in hits] == ["a3", "a2"]
