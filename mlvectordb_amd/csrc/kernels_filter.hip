@@ -30,16 +30,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// In-place accumulate with the accumulator tied to the destination.  Used in the 2-waves-per-SIMD
-// geometry, where hipcc keeps the accumulators in plain VGPRs, is free to pick dst != srcC for
-// the builtin, and then rotates (and spills) them.  The s_nop covers the VALU-write -> MFMA-read
-// wait states for A fragments that were converted just before (hipcc pads nothing inside asm).
-template <bool PAD>
-__device__ __forceinline__ void mfma_tied(f32x4& acc, const bf16x8& a, const bf16x8& b) {
-    if (PAD) asm("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-    else asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-}
-
 // 16-byte buffer load: wave-uniform descriptor + scalar byte offset, one VGPR of lane offset.
 // Keeps the streaming loads' address arithmetic on the scalar unit (no 64-bit VGPR adds).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
@@ -251,27 +241,24 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
     }
 }
 
-// One workgroup = 4 waves (one per SIMD, so each wave may use the whole 512-entry register
-// file) = one 192-row tile (12 panels) against all 256 queries; wave w owns panels 3w..3w+2,
-// i.e. a 48 x 256 block of scores in 192 accumulator registers (AGPRs).  (64 rows per wave
-// would fill the 256-entry AGPR file exactly, and hipcc then shuffles and spills.)
-//   X   HBM -> registers: each wave load is one lane-linear 1 KiB burst of one panel
-//       (layout.h) and is already the MFMA A fragment; nobody else needs those rows, so no LDS.
-//       R register buffers of one 32-column half-chunk each (8 KiB per wave) rotate, so
-//       (R-1)..R half-chunks per wave stay in flight under the MFMAs.  The rotation is static
-//       (the step loop is unrolled lcm(R,2) times): a run-time rotation makes hipcc copy
-//       registers that are targets of in-flight loads, which drains the prefetch.
+// The compiler-scheduled scan (hipcc builtins).  Serves corpora without bf16 shadow (XB = false: fp32
+// rows converted in registers), the dense seeding pass (DENSE) and the A/B reference of the assembly
+// body below, which has the same geometry and data flow per tile:
+// one workgroup = 4 waves = one 128-row tile against all 256 queries, two workgroups per CU; wave w owns
+// panels 2w, 2w+1, i.e. a 32 x 256 block of scores in 128 accumulator registers.
+//   X   HBM -> registers: each wave load is one 1 KiB burst of one panel (layout.h) and is already
+//       the MFMA A fragment; nobody else needs those rows, so no LDS.  Two register buffers of one
+//       32-column k-step each rotate statically (the step loop is unrolled twice: a run-time rotation
+//       makes hipcc copy registers that are targets of in-flight loads, which drains the prefetch).
 //   Q   the bf16 query image (L2 resident) goes registers -> LDS in 64-column chunks, double
 //       buffered, one barrier per chunk, and is read back as ready-made B fragments
-//       (ds_read_b128, lane-linear, conflict free).  Each B fragment feeds 4 MFMAs.
-//       Chunk c+1 is loaded right after barrier(c) and written just before barrier(c+1): the
-//       loads are older than the X prefetches issued meanwhile, so waiting for them (in-order
-//       vmcnt) never drains those.
+//       (ds_read_b128, lane-linear, conflict free).  Each B fragment feeds 2 MFMAs.
 // All loads are ordinary loads on purpose: hipcc then tracks them with counted s_waitcnt.
-template <int SPACE, int R, int QD, bool PIN, int kMT, int NW, bool XB, bool DENSE>
-__global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(const FilterArgs a, const int64_t tile_begin,
+template <int SPACE, bool XB, bool DENSE>
+__global__ __launch_bounds__(256, 2) void filter_scan_kernel(const FilterArgs a, const int64_t tile_begin,
                                                                         const int64_t tile_end, const float e1) {
-    constexpr int U = (R % 2 == 0) ? R : 2 * R;  // steps per unrolled body
+    constexpr int R = 2, QD = 2, kMT = 2, NW = 4;  // ring depth, B read-ahead, panels per wave, waves (measured best for hipcc's schedule)
+    constexpr int U = R;                          // steps per unrolled body
     constexpr int kThreads = NW * 64;
     constexpr int kQPer = 1024 / kThreads;                 // uint4 of a Q half-chunk moved per thread
     constexpr int kFilterTileRows = NW * 16 * kMT;  // rows per workgroup tile
@@ -366,7 +353,6 @@ __global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(
     for (int b = 0; b < R; ++b) load_x(xr[b]);
 
     auto epilogue = [&](const int64_t ti) __attribute__((always_inline)) {
-        if (kMT == 2 && R > 2) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // XDL write -> VALU read wait states
         scan_epilogue<SPACE, kMT, DENSE>(a, acc, rnv, (int32_t)(tile_of(ti) * kFilterTileRows) + wave * (16 * kMT) + g * 4,
                                          (int32_t)(tile_begin * kFilterTileRows), e1, thr_l, sq_l,
                                          hit_l + wave * (4 * kMT * 64) + lane, c16);
@@ -428,18 +414,7 @@ __global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(
                     const bf16x8 qb = __builtin_bit_cast(bf16x8, qraw[n % QD]);
 #pragma unroll
                     for (int m = 0; m < kMT; ++m) {
-                        if (kMT == 2 && R > 2) mfma_tied<!XB>(acc[m][n], xa[m], qb);  // A from loads: no VALU write to pad
-                        else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[m], qb, acc[m][n], 0, 0, 0);
-                    }
-                }
-                if (kMT == 2 && R > 2) __builtin_amdgcn_sched_barrier(0);  // no code motion across steps: caps live ranges
-                if (PIN) {
-                    // pin the interleave: QD-1 reads up front, then one read per group of kMT MFMAs
-                    __builtin_amdgcn_sched_group_barrier(0x100, QD - 1, 0);
-#pragma unroll
-                    for (int n = 0; n < 16; ++n) {
-                        if (n + QD - 1 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, kMT, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[m], qb, acc[m][n], 0, 0, 0);
                     }
                 }
             }
@@ -455,12 +430,16 @@ __global__ __launch_bounds__(NW * 64, kMT == 3 ? 1 : 2) void filter_scan_kernel(
 // atomic on 256 hot counters cost ~90 us per launch).
 __global__ __launch_bounds__(256) void filter_scatter_kernel(const FilterArgs a, const int cap, const int nw, const int dbg) {
     __shared__ uint32_t hist[kFilterQueries], base[kFilterQueries];
+#ifdef MLVDB_SCAN_DIAGNOSTICS
     if (dbg && threadIdx.x < (unsigned)nw && (blockIdx.x % 64) == 0) {  // MLVDB_SCAN_DIAG=108: in-kernel cycle stamps
         const uint32_t* bq = reinterpret_cast<const uint32_t*>(
             reinterpret_cast<const char*>(a.wgbuf + (size_t)(blockIdx.x * nw + threadIdx.x) * cap) + (size_t)cap * 8);
         printf("stamp wg %d wave %d: barrier-parked %u of %u cycles, entries %u\n", (int)blockIdx.x, (int)threadIdx.x,
                bq[cap - 2], bq[cap - 1], a.wgcnt[blockIdx.x * nw + threadIdx.x]);
     }
+#else
+    (void)dbg;
+#endif
     hist[threadIdx.x] = 0;
     __syncthreads();
     for (int w = 0; w < nw; ++w) {
@@ -990,10 +969,10 @@ static int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
-template <int SPACE, int R, int MT, bool XB, bool DENSE = false>
+template <int SPACE, bool XB, bool DENSE = false>
 static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s,
                                   ScanInfo* info = nullptr) {
-    constexpr int NW = 4;
+    constexpr int NW = 4, MT = 2;
     constexpr int tile_rows = NW * 16 * MT;
     const int64_t tile_begin = row_begin / tile_rows;
     const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
@@ -1001,9 +980,9 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
     const size_t lds = 2 * kChunkVec * sizeof(uint4) + 2 * kFilterQueries * sizeof(float) +
                        (size_t)NW * 4 * MT * 64 * sizeof(float);
     const int64_t ntiles = tile_end - tile_begin;
-    const int max_grid = 256 * (MT == 3 ? 1 : 2);  // workgroups resident per launch
+    const int max_grid = 256 * 2;  // workgroups resident per launch
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
-    auto kern = filter_scan_kernel<SPACE, R, 2, false, MT, NW, XB, DENSE>;
+    auto kern = filter_scan_kernel<SPACE, XB, DENSE>;
     static bool configured = false;  // per instantiation
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1041,13 +1020,10 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     return hipGetLastError();
 }
 
-// Geometry: 2 panels per wave (128 accumulators), two 4-wave workgroups per CU.  Scanning the
-// bf16 shadow needs 4 VGPRs per k-step in flight, so 4-8 k-steps rotate; scanning fp32 needs 16,
-// so only 2 fit (3 panels x 3 k-steps at one workgroup per CU is kept for comparison).
-// MLVDB_SCAN_R / MLVDB_SCAN_MT override the choice for experiments (read per launch).
+// Picks the scan kernel for a launch: the assembly body whenever the bf16 shadow exists (variants by
+// environment variable, read per launch, for tuning), else the compiler-scheduled kernel.
 template <int SPACE>
 static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info) {
-    // steps per tile = 2 * (ld / 64) must be a multiple of lcm(R, 2)
     const int nkc = a.ld / kFilterChunkK;
     if (a.Xb && env_int("MLVDB_SCAN_ASM", 1)) {
         // hand-written body (tools/gen_scan_asm.py).  Default: one 8-wave workgroup per CU (256-row tiles:
@@ -1065,6 +1041,7 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
             if (nkc % 2 == 0 && env_int("MLVDB_SCAN_NT", 1) == 0)
                 return nw == 8 ? launch_scan_asm<SPACE, 4, 8, false>(a, row_begin, row_end, s, info)
                                : launch_scan_asm<SPACE, 4, 4, false>(a, row_begin, row_end, s, info);
+#ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: timing diagnostics (tools/scan_ab.py --no-check), wrong results by design
             switch (nw == 8 && nkc % 2 == 0 ? env_int("MLVDB_SCAN_DIAG", 0) : 0) {  // timing diagnostics, wrong results
                 case 101: return launch_scan_asm<SPACE, 4, 8, true, 101>(a, row_begin, row_end, s, info);
                 case 102: return launch_scan_asm<SPACE, 4, 8, true, 102>(a, row_begin, row_end, s, info);
@@ -1074,6 +1051,7 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                 case 108: return launch_scan_asm<SPACE, 4, 8, true, 108>(a, row_begin, row_end, s, info);
                 default: break;
             }
+#endif
         }
         if (nw == 8) {
             if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8, true>(a, row_begin, row_end, s, info);
@@ -1082,19 +1060,9 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
         if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true>(a, row_begin, row_end, s, info);
         return launch_scan_asm<SPACE, 2, 4, true>(a, row_begin, row_end, s, info);
     }
-    if (a.Xb) {
-        const int want_r = env_int("MLVDB_SCAN_R", 2);
-        if (env_int("MLVDB_SCAN_MT", 2) == 3) {
-            if (want_r >= 8 && nkc % 4 == 0) return launch_scan_one<SPACE, 8, 3, true>(a, row_begin, row_end, s, info);
-            if (want_r >= 4 && nkc % 2 == 0) return launch_scan_one<SPACE, 4, 3, true>(a, row_begin, row_end, s, info);
-            return launch_scan_one<SPACE, 2, 3, true>(a, row_begin, row_end, s, info);
-        }
-        if (want_r >= 8 && nkc % 4 == 0) return launch_scan_one<SPACE, 8, 2, true>(a, row_begin, row_end, s, info);
-        if (want_r >= 4 && nkc % 2 == 0) return launch_scan_one<SPACE, 4, 2, true>(a, row_begin, row_end, s, info);
-        return launch_scan_one<SPACE, 2, 2, true>(a, row_begin, row_end, s, info);
-    }
-    if (env_int("MLVDB_SCAN_MT", 2) == 3 && nkc % 3 == 0) return launch_scan_one<SPACE, 3, 3, false>(a, row_begin, row_end, s, info);
-    return launch_scan_one<SPACE, 2, 2, false>(a, row_begin, row_end, s, info);
+    // compiler-scheduled kernel: corpora without shadow (fp32 rows converted in registers), and the A/B reference
+    if (a.Xb) return launch_scan_one<SPACE, true>(a, row_begin, row_end, s, info);
+    return launch_scan_one<SPACE, false>(a, row_begin, row_end, s, info);
 }
 
 // Seeding pass over rows [0, row_end): every bound goes into the candidate lists (slot = row),
@@ -1108,16 +1076,16 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
     const bool xb = a.Xb != nullptr;
     switch (a.space) {
         case kSpaceL2:
-            e = xb ? launch_scan_one<kSpaceL2, 2, 2, true, true>(a, 0, rows, s)
-                   : launch_scan_one<kSpaceL2, 2, 2, false, true>(a, 0, rows, s);
+            e = xb ? launch_scan_one<kSpaceL2, true, true>(a, 0, rows, s)
+                   : launch_scan_one<kSpaceL2, false, true>(a, 0, rows, s);
             break;
         case kSpaceCosine:
-            e = xb ? launch_scan_one<kSpaceCosine, 2, 2, true, true>(a, 0, rows, s)
-                   : launch_scan_one<kSpaceCosine, 2, 2, false, true>(a, 0, rows, s);
+            e = xb ? launch_scan_one<kSpaceCosine, true, true>(a, 0, rows, s)
+                   : launch_scan_one<kSpaceCosine, false, true>(a, 0, rows, s);
             break;
         default:
-            e = xb ? launch_scan_one<kSpaceIp, 2, 2, true, true>(a, 0, rows, s)
-                   : launch_scan_one<kSpaceIp, 2, 2, false, true>(a, 0, rows, s);
+            e = xb ? launch_scan_one<kSpaceIp, true, true>(a, 0, rows, s)
+                   : launch_scan_one<kSpaceIp, false, true>(a, 0, rows, s);
             break;
     }
     if (e != hipSuccess) return e;

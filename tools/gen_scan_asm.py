@@ -605,9 +605,11 @@ def main():
                 f" && PRIO == {'true' if prio else 'false'} && MT == {mt}")
         disp.append(("if" if i == 0 else "} else if") + f" constexpr ({cond}) {{")
         disp.append(f'#include "{inc_name(space, nw, r, nt, qd, prio, mt)}"')
+    disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
     for code in DIAG:
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2) {{")
         disp.append(f'#include "scan_asm_diag{code}.inc"')
+    disp.append("#endif")
     disp.append("} else {")
     disp.append('    static_assert(SPACE < 0, "configuration not generated: add it to CONFIGS in tools/gen_scan_asm.py");')
     disp.append("}")
