@@ -147,6 +147,15 @@ int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64
                               int32_t* out_counts_device, double* out_dist64_device, void* stream);
 
 /*
+ * mlvdb_search_batch restricted to the rows with row_mask[label] != 0 (host, `total` bytes): the
+ * pre-computed row mask of a metadata-filtered search (README.md:121,130,252,274: intent only, no
+ * reference code).  A masked-out row is treated exactly like a tombstoned one for this call;
+ * results are the exact k nearest allowed live rows.  row_mask == NULL: no restriction.
+ */
+int mlvdb_search_batch_filtered(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, const uint8_t* row_mask,
+                                int64_t* out_labels, float* out_dist, int32_t* out_counts);
+
+/*
  * Batched range query: every live row with distance <= radius (distance in the
  * index's space, so squared radius for l2), nearest first, ties by ascending label.
  * No reference implementation exists (README-only); semantics defined in DESIGN.md.

@@ -50,6 +50,7 @@ SIGNATURES = {
     "mlvdb_index_reset": (C.c_int, [_P, C.c_int32]),
     "mlvdb_index_get_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
     "mlvdb_search_batch": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
+    "mlvdb_search_batch_filtered": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
     "mlvdb_search_batch_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
     "mlvdb_range_batch": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int64, _P, _P, _P]),
     "mlvdb_index_set_strategy": (C.c_int, [_P, C.c_int32]),

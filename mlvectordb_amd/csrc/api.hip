@@ -58,6 +58,7 @@ struct mlvdb_index {
     hipStream_t stream = nullptr;
     // workspaces (grow only)
     DevBuf stage, qpad, qaux, partial, qsel, seed_lab, seed_dist, seed_cnt, seed_d64;
+    DevBuf row_mask, rn_masked;  // filtered search
     DevBuf qimg, fmisc, cand, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, counters, labels_in;
     DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
     uint32_t* host_flags = nullptr;  // pinned, kFilterQueries words
@@ -512,7 +513,7 @@ int mlvdb_index_destroy(mlvdb_index* h) {
     if (h->rn) (void)hipFree(h->rn);
     if (h->Xb) (void)hipFree(h->Xb);
     for (DevBuf* b : {&h->stage, &h->qpad, &h->qaux, &h->partial, &h->qsel, &h->seed_lab, &h->seed_dist, &h->seed_cnt,
-                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->wgbuf, &h->wgcnt, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt,
+                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt,
                       &h->counters, &h->labels_in, &h->page_lab, &h->page_dist, &h->page_cnt, &h->page_d64, &h->cur_d,
                       &h->cur_l})
         b->release();
@@ -755,6 +756,23 @@ int mlvdb_search_batch(mlvdb_index* h, const float* queries, int64_t nq, int32_t
     HIP_TRY(h, hipMemcpyAsync(out_counts, h->io_cnt.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MLVDB_OK;
+}
+
+int mlvdb_search_batch_filtered(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, const uint8_t* row_mask,
+                                int64_t* out_labels, float* out_dist, int32_t* out_counts) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (!row_mask) return mlvdb_search_batch(h, queries, nq, k, out_labels, out_dist, out_counts);
+    if (h->total == 0) return mlvdb_search_batch(h, queries, nq, k, out_labels, out_dist, out_counts);
+    HIP_TRY(h, h->row_mask.ensure((size_t)h->total));
+    HIP_TRY(h, h->rn_masked.ensure((size_t)h->capacity * sizeof(float)));
+    HIP_TRY(h, hipMemcpyAsync(h->row_mask.p, row_mask, (size_t)h->total, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, launch_mask_norms(h->rn, h->row_mask.as<uint8_t>(), h->rn_masked.as<float>(), h->total, h->capacity, h->stream));
+    float* const all_rows = h->rn;  // every kernel of the call reads the masked norms instead
+    h->rn = h->rn_masked.as<float>();
+    rc = mlvdb_search_batch(h, queries, nq, k, out_labels, out_dist, out_counts);
+    h->rn = all_rows;
+    return rc;
 }
 
 int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float radius, int64_t capacity,

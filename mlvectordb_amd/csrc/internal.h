@@ -33,6 +33,8 @@ hipError_t launch_compact_map(const float* rn, int64_t total, uint32_t* block_sc
 // gather the live rows (fp32 panels, bf16 shadow when Xb != nullptr, norms) into freshly zeroed / NaN-filled buffers
 hipError_t launch_compact_rows(const float* X, float* nX, const void* Xb, void* nXb, const float* rn, float* nrn,
                                const int32_t* old_of_new, int64_t live, int32_t ld, hipStream_t s);
+// out[i] = mask[i] ? rn[i] : NaN (i < total), NaN up to capacity: a masked-out row looks tombstoned to every scan
+hipError_t launch_mask_norms(const float* rn, const uint8_t* mask, float* out, int64_t total, int64_t capacity, hipStream_t s);
 // Qpad[q][0..ld) = queries[q][0..dim) zero padded; qaux[q] = 1/(|q|+1e-30) (cosine) or |q| (l2, ip)
 hipError_t launch_query_prep(const float* queries, int32_t nq, int32_t dim, int32_t ld, int32_t space, float* Qpad,
                              double* qaux, hipStream_t s);

@@ -296,4 +296,20 @@ hipError_t launch_compact_rows(const float* X, float* nX, const void* Xb, void* 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ per-call row mask (filtered search)
+// out[i] = mask[i] ? rn[i] : NaN for i < total, NaN beyond: every scan kernel then treats a masked-out row
+// exactly like a tombstoned one (seeding, thresholds, admission, rescoring), with no kernel knowing about masks.
+__global__ __launch_bounds__(256) void mask_norms_kernel(const float* __restrict__ rn, const uint8_t* __restrict__ mask,
+                                                         float* __restrict__ out, int64_t total, int64_t capacity) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (i < total && mask[i]) ? rn[i] : __builtin_nanf("");
+}
+
+hipError_t launch_mask_norms(const float* rn, const uint8_t* mask, float* out, int64_t total, int64_t capacity, hipStream_t s) {
+    if (capacity == 0) return hipSuccess;
+    const int64_t blocks = std::min<int64_t>((capacity + 255) / 256, 256 * 16);
+    mask_norms_kernel<<<(unsigned)blocks, 256, 0, s>>>(rn, mask, out, total, capacity);
+    return hipGetLastError();
+}
+
 }  // namespace mlvdb

@@ -29,7 +29,8 @@ class ScanEngine(Protocol):
 
     def compact(self) -> np.ndarray: ...
 
-    def search(self, queries: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]: ...
+    def search(self, queries: np.ndarray, k: int, mask: np.ndarray | None = None
+               ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]: ...
 
     def range(self, queries: np.ndarray, radius: float, capacity: int) -> List[Tuple[np.ndarray, np.ndarray]]: ...
 
@@ -127,7 +128,8 @@ class HipScanEngine:
         self._check(self._lib.mlvdb_index_get_rows(self._h, int(first), int(n), out.ctypes.data), "get_rows")
         return out
 
-    def search(self, queries: np.ndarray, k: int):
+    def search(self, queries: np.ndarray, k: int, mask: np.ndarray | None = None):
+        """kNN; ``mask`` (optional, one byte per row, non-zero = allowed) restricts the search to those rows."""
         queries = np.ascontiguousarray(queries, dtype=np.float32)
         if queries.ndim != 2 or queries.shape[1] != self.dim:
             raise RuntimeError(f"Wrong dimensionality of the vectors: got {queries.shape}, index dim {self.dim}")
@@ -135,8 +137,16 @@ class HipScanEngine:
         labels = np.empty((nq, k), dtype=np.int64)
         dist = np.empty((nq, k), dtype=np.float32)
         counts = np.empty(nq, dtype=np.int32)
-        self._check(self._lib.mlvdb_search_batch(self._h, queries.ctypes.data, nq, int(k), labels.ctypes.data,
-                                                 dist.ctypes.data, counts.ctypes.data), "search_batch")
+        if mask is None:
+            self._check(self._lib.mlvdb_search_batch(self._h, queries.ctypes.data, nq, int(k), labels.ctypes.data,
+                                                     dist.ctypes.data, counts.ctypes.data), "search_batch")
+        else:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            if mask.shape != (self.counts()[0],):
+                raise RuntimeError(f"row mask has shape {mask.shape}, the index holds {self.counts()[0]} rows")
+            self._check(self._lib.mlvdb_search_batch_filtered(self._h, queries.ctypes.data, nq, int(k), mask.ctypes.data,
+                                                              labels.ctypes.data, dist.ctypes.data, counts.ctypes.data),
+                        "search_batch_filtered")
         return labels, dist, counts
 
     def search_device(self, q_ptr: int, nq: int, k: int, labels_ptr: int, dist_ptr: int, counts_ptr: int,

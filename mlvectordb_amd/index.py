@@ -181,11 +181,14 @@ class Index:
         return True
 
     # ------------------------------------------------------------------ additive: batches and ranges
-    def search_many(self, queries, top_k: int, namespace: str, metric: str) -> List[List[SearchResult]]:
+    def search_many(self, queries, top_k: int, namespace: str, metric: str,
+                    allowed_ids: Optional[Iterable[UUID]] = None) -> List[List[SearchResult]]:
         """kNN for a batch of queries in one corpus scan.
 
         ``queries`` is an ``[nq, dim]`` array or a sequence of ``VectorDTO``.  Each entry of
-        the result is what ``search`` would return for that query.
+        the result is what ``search`` would return for that query.  ``allowed_ids`` (additive: the
+        row mask of a metadata-filtered search, README.md:121,130 intent) restricts the search to
+        those vectors; the answer is the exact top-k among them.
         """
         q = self._coerce_queries(queries)
         nq = q.shape[0]
@@ -197,8 +200,16 @@ class Index:
             return [[] for _ in range(nq)]
         if q.shape[1] != ns.dim:
             return [[] for _ in range(nq)]  # reference: RuntimeError swallowed at index.py:110-119
+        mask = None
+        if allowed_ids is not None:
+            mask = np.zeros(ns.total, dtype=np.uint8)
+            picked = [ns.uuid_to_label[u] for u in allowed_ids if u in ns.uuid_to_label]
+            if not picked:
+                return [[] for _ in range(nq)]
+            mask[np.asarray(picked, dtype=np.int64)] = 1
+            active = int(mask.sum())
         k = min(int(top_k), active)
-        labels, dist, counts = self._search_engine(ns, q, k)
+        labels, dist, counts = self._search_engine(ns, q, k, mask)
         sqrt_score = metric == "euclidean"
         out: List[List[SearchResult]] = []
         for i in range(nq):
@@ -266,9 +277,9 @@ class Index:
         return np.ascontiguousarray(q)
 
     @staticmethod
-    def _search_engine(ns: _Namespace, q: np.ndarray, k: int):
+    def _search_engine(ns: _Namespace, q: np.ndarray, k: int, mask=None):
         """Engines select at most ``max_topk`` per scan; larger k is served in rank-ordered pages."""
-        return ns.engine.search(q, k)
+        return ns.engine.search(q, k) if mask is None else ns.engine.search(q, k, mask)
 
     def namespace_counts(self, namespace: str):
         ns = self._ns.get(namespace)

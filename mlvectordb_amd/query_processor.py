@@ -15,6 +15,7 @@ to reproduce the reference byte for byte.
 """
 from __future__ import annotations
 
+import numpy as np
 from typing import Any, Dict, Iterable, List, Sequence
 from uuid import UUID
 
@@ -59,10 +60,28 @@ class QueryProcessor:
         return self._enrich(hits, namespace)
 
     def find_similar_many(self, queries, top_k: int, namespace: str = "default",
-                          metric: str = "cosine") -> List[List[dict]]:
-        """Batched ``find_similar``: ``queries`` is an [nq, dim] array or a sequence of VectorDTO."""
-        per_query = self._index.search_many(queries, top_k=top_k, namespace=namespace, metric=metric)
+                          metric: str = "cosine", where=None) -> List[List[dict]]:
+        """Batched ``find_similar``: ``queries`` is an [nq, dim] array or a sequence of VectorDTO.
+
+        ``where`` (additive; README.md:121,130,252,274 intent, no reference code): a predicate over a stored
+        vector's metadata dict.  It is evaluated once over the namespace's stored vectors and handed to the
+        index as a row mask, so the answer is the exact top-k among the matching vectors (not a post-filter of
+        an unrestricted top-k)."""
+        if where is None:
+            per_query = self._index.search_many(queries, top_k=top_k, namespace=namespace, metric=metric)
+        else:
+            allowed = [v.id for v in self._storage.namespace_map.get(namespace, []) if where(v.metadata)]
+            per_query = self._index.search_many(queries, top_k=top_k, namespace=namespace, metric=metric,
+                                                allowed_ids=allowed)
         return [self._enrich(hits, namespace) for hits in per_query]
+
+    def find_similar_where(self, query: VectorDTO, top_k: int, where, namespace: str = "default",
+                           metric: str = "cosine") -> List[dict]:
+        """``find_similar`` restricted to the vectors whose metadata satisfies ``where``."""
+        values = np.asarray(query.values, dtype=np.float32)
+        if values.ndim != 1:
+            return []
+        return self.find_similar_many(values[None, :], top_k, namespace, metric, where=where)[0]
 
     def find_in_radius(self, query: VectorDTO, radius: float, namespace: str = "default",
                        metric: str = "cosine", max_results: int = 1024) -> List[dict]:

@@ -47,8 +47,9 @@ class OracleScanEngine:
         self._deleted = np.zeros(old.size, dtype=bool)
         return old
 
-    def search(self, queries: np.ndarray, k: int):
-        return exact_scan.knn(queries, self._rows, k, self.space, deleted=self._deleted)
+    def search(self, queries: np.ndarray, k: int, mask=None):
+        deleted = self._deleted if mask is None else (self._deleted | (np.asarray(mask) == 0))
+        return exact_scan.knn(queries, self._rows, k, self.space, deleted=deleted)
 
     def range(self, queries: np.ndarray, radius: float, capacity: int):
         return exact_scan.range_query(queries, self._rows, radius, self.space, deleted=self._deleted)

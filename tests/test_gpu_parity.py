@@ -309,3 +309,27 @@ def test_device_compaction_equals_a_fresh_index_of_the_survivors(space, d, strat
         assert_knn_matches(eng.search(qs, 10), oracle_knn(qs, both, 10, space), f"compacted twice/{space}")
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+@pytest.mark.parametrize("strategy,n,d,nq", [("filter", 60_000, 128, 40), ("exact", 3000, 20, 5), ("filter", 9000, 768, 300)])
+def test_row_mask_search_matches_oracle(space, strategy, n, d, nq):
+    """mlvdb_search_batch_filtered: the exact top-k among the allowed, live rows (mask of a metadata filter),
+    including masks that allow fewer than k rows and masks that allow nothing; the index itself is unchanged."""
+    rows, qs = make_case(900 + d, n, d, nq, dup=True)
+    deleted = deleted_mask(11, n, 0.1)
+    rng = np.random.default_rng(5)
+    eng = HipScanEngine(d, space, device=0, strategy=strategy)
+    try:
+        eng.append(rows)
+        eng.tombstone(np.nonzero(deleted)[0])
+        for frac in (0.5, 0.01, 3.0 / n, 0.0):
+            mask = (rng.random(n) < frac).astype(np.uint8)
+            got = eng.search(qs, 10, mask=mask)
+            want = oracle_knn(qs, rows, 10, space, deleted | (mask == 0))
+            assert_knn_matches(got, want, f"masked {frac}/{strategy}/{space}")
+        assert_knn_matches(eng.search(qs, 10), oracle_knn(qs, rows, 10, space, deleted), "unmasked afterwards")
+        with pytest.raises(RuntimeError):
+            eng.search(qs, 10, mask=np.ones(n - 1, np.uint8))
+    finally:
+        eng.close()

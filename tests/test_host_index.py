@@ -196,3 +196,22 @@ def test_query_processor_delete_compacts_instead_of_rebuilding():
     assert calls == ["compact"]
     hits = qp.find_similar(VectorDTO([1, 0], {}), 3, namespace="A")
     assert [h["metadata"]["l"] for h in hits] == ["a3", "a2"]
+
+
+def test_metadata_filtered_search_is_exact_among_the_matching_vectors():
+    rng = np.random.default_rng(21)
+    qp = QueryProcessor(InMemoryStorage(), idx("cosine"))
+    rows = rng.standard_normal((200, 10)).astype(np.float32)
+    qp.upsert_many([VectorDTO(r.tolist(), {"colour": "red" if i % 3 == 0 else "blue", "i": i}) for i, r in enumerate(rows)])
+    q = VectorDTO(rng.standard_normal(10).tolist(), {})
+    red = qp.find_similar_where(q, 5, where=lambda m: m["colour"] == "red")
+    assert len(red) == 5 and all(h["metadata"]["colour"] == "red" for h in red)
+    cos = rows @ np.asarray(q.values, np.float32) / np.linalg.norm(rows, axis=1) / np.linalg.norm(q.values)
+    want = [i for i in np.argsort(-cos) if i % 3 == 0][:5]
+    assert [h["metadata"]["i"] for h in red] == want                       # not a post-filter of the global top-5
+    assert qp.find_similar_where(q, 5, where=lambda m: False) == []
+    few = qp.find_similar_where(q, 50, where=lambda m: m["i"] < 7)        # k clamps to the matching count
+    assert sorted(h["metadata"]["i"] for h in few) == list(range(7))
+    qp.delete([red[0]["id"]])
+    again = qp.find_similar_where(q, 5, where=lambda m: m["colour"] == "red")
+    assert red[0]["id"] not in [h["id"] for h in again] and len(again) == 5
