@@ -415,6 +415,17 @@ __global__ void range_fallback_commit_kernel(const int32_t* qsel, const uint32_t
     if (threadIdx.x == 0) out_counts[q0 + q] = n;
 }
 
+// valid prefixes of the dense per-query result rows -> one packed array (offsets from the host)
+__global__ void range_pack_kernel(const int64_t* lab, const float* dist, const int64_t* offsets, int64_t cap_eff, int64_t* plab,
+                                  float* pdist) {
+    const int64_t q = blockIdx.x;
+    const int64_t o = offsets[q], n = offsets[q + 1] - o;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        plab[o + i] = lab[q * cap_eff + i];
+        pdist[o + i] = dist[q * cap_eff + i];
+    }
+}
+
 __global__ void range_reset_kernel(uint32_t* cnt, const int32_t* qsel) { cnt[qsel[threadIdx.x]] = 0; }
 __global__ void range_resolve_kernel(uint32_t* overflow, const uint32_t* cnt, const int32_t* qsel) {
     const int q = qsel[threadIdx.x];
@@ -870,14 +881,42 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
         HIP_TRY(h, launch_range_rescore(fa, radius, (int32_t)q0, cap_eff, h->io_lab.as<int64_t>(),
                                         h->io_dist.as<float>(), h->io_cnt.as<int64_t>(), s));
     }
-    // copy back (rows of cap_eff entries into rows of `capacity` entries)
+    // copy back.  Hit counts vary by orders of magnitude between queries, so the dense [nq, cap_eff] device
+    // arrays are mostly padding: when the hits are a small part of them, pack the rows' valid prefixes on the
+    // device and send only those (25 MB -> 0.4 MB at 256 queries x 8192 slots with 128 hits on average).
     std::vector<int64_t> counts(nq);
     HIP_TRY(h, hipMemcpyAsync(counts.data(), h->io_cnt.p, (size_t)nq * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemcpy2DAsync(out_labels, (size_t)capacity * sizeof(int64_t), h->io_lab.p, (size_t)cap_eff * sizeof(int64_t),
-                                (size_t)cap_eff * sizeof(int64_t), (size_t)nq, hipMemcpyDeviceToHost, s));
-    HIP_TRY(h, hipMemcpy2DAsync(out_dist, (size_t)capacity * sizeof(float), h->io_dist.p, (size_t)cap_eff * sizeof(float),
-                                (size_t)cap_eff * sizeof(float), (size_t)nq, hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
+    std::vector<int64_t> offsets((size_t)nq + 1, 0);
+    for (int64_t i = 0; i < nq; ++i) offsets[(size_t)i + 1] = offsets[(size_t)i] + std::min<int64_t>(std::max<int64_t>(counts[i], 0), cap_eff);
+    const int64_t total_hits = offsets[(size_t)nq];
+    if (total_hits * 4 < nq * cap_eff) {
+        if (total_hits > 0) {
+            HIP_TRY(h, h->labels_in.ensure(((size_t)nq + 1) * sizeof(int64_t)));
+            HIP_TRY(h, h->seed_lab.ensure((size_t)total_hits * sizeof(int64_t)));
+            HIP_TRY(h, h->seed_dist.ensure((size_t)total_hits * sizeof(float)));
+            HIP_TRY(h, hipMemcpyAsync(h->labels_in.p, offsets.data(), ((size_t)nq + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            range_pack_kernel<<<(unsigned)nq, 256, 0, s>>>(h->io_lab.as<int64_t>(), h->io_dist.as<float>(), h->labels_in.as<int64_t>(),
+                                                           cap_eff, h->seed_lab.as<int64_t>(), h->seed_dist.as<float>());
+            HIP_TRY(h, hipGetLastError());
+            std::vector<int64_t> pl((size_t)total_hits);
+            std::vector<float> pd((size_t)total_hits);
+            HIP_TRY(h, hipMemcpyAsync(pl.data(), h->seed_lab.p, (size_t)total_hits * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipMemcpyAsync(pd.data(), h->seed_dist.p, (size_t)total_hits * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+            for (int64_t i = 0; i < nq; ++i) {
+                const int64_t n = offsets[(size_t)i + 1] - offsets[(size_t)i];
+                std::memcpy(out_labels + (size_t)i * capacity, pl.data() + offsets[(size_t)i], (size_t)n * sizeof(int64_t));
+                std::memcpy(out_dist + (size_t)i * capacity, pd.data() + offsets[(size_t)i], (size_t)n * sizeof(float));
+            }
+        }
+    } else {
+        HIP_TRY(h, hipMemcpy2DAsync(out_labels, (size_t)capacity * sizeof(int64_t), h->io_lab.p, (size_t)cap_eff * sizeof(int64_t),
+                                    (size_t)cap_eff * sizeof(int64_t), (size_t)nq, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipMemcpy2DAsync(out_dist, (size_t)capacity * sizeof(float), h->io_dist.p, (size_t)cap_eff * sizeof(float),
+                                    (size_t)cap_eff * sizeof(float), (size_t)nq, hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+    }
     bool over = false, hard = false;
     for (int64_t i = 0; i < nq; ++i) {
         out_counts[i] = counts[i];

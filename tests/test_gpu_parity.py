@@ -263,14 +263,14 @@ SCAN_VARIANTS = [
 
 
 @pytest.mark.parametrize("variant", SCAN_VARIANTS, ids=lambda v: ",".join(f"{k[11:]}={x}" for k, x in v.items()))
-@pytest.mark.parametrize("space,d", [("cosine", 128), ("l2", 192), ("ip", 64), ("cosine", 768)])
+@pytest.mark.parametrize("space,d", [("cosine", 128), ("l2", 192), ("ip", 64), ("cosine", 768), ("l2", 1536)])
 def test_scan_kernel_variants_agree_with_oracle(variant, space, d, monkeypatch):
     """Every generated geometry of the filter scan (the variable is read per launch), on corpora with more
     tiles than resident workgroups (persistent tile loop, prefetch across tile boundaries), ragged last
     tile, tombstones and duplicated rows."""
     for key, val in variant.items():
         monkeypatch.setenv(key, val)
-    n = 150_001 if d <= 192 else 70_003
+    n = 150_001 if d <= 192 else (70_003 if d <= 768 else 33_001)
     rows, qs = make_case(300 + d, n, d, 40, dup=True)
     deleted = deleted_mask(7, n, 0.05)
     got, stats = run_hip(rows, qs, 10, space, "filter", deleted, append_chunks=3)
