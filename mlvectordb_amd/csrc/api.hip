@@ -59,6 +59,7 @@ struct mlvdb_index {
     // workspaces (grow only)
     DevBuf stage, qpad, qaux, partial, qsel, seed_lab, seed_dist, seed_cnt, seed_d64;
     DevBuf row_mask, rn_masked;  // filtered search
+    DevBuf qerr, rowerr;         // rounding errors of the bf16 images: per query / maximum over the rows (device scalar)
     DevBuf qimg, fmisc, cand, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, counters, labels_in;
     DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
     uint32_t* host_flags = nullptr;  // pinned, kFilterQueries words
@@ -97,6 +98,10 @@ int fail(mlvdb_index* h, int code, const char* what, hipError_t e = hipSuccess) 
     } while (0)
 
 int reserve_rows(mlvdb_index* h, int64_t rows) {
+    if (!h->rowerr.p) {  // largest relative bf16 rounding error of any row appended so far (0 = no rows)
+        HIP_TRY(h, h->rowerr.ensure(sizeof(unsigned int)));
+        HIP_TRY(h, hipMemsetAsync(h->rowerr.p, 0, sizeof(unsigned int), h->stream));
+    }
     if (rows <= h->capacity) return MLVDB_OK;
     int64_t want = rows;
     if (h->capacity > 0 && want < h->capacity + h->capacity / 2) want = h->capacity + h->capacity / 2;
@@ -240,9 +245,9 @@ struct FilterWs {
     FilterArgs fa;
 };
 
-int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const double* qaux, int32_t nq) {
+int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const double* qaux, const float* qerr, int32_t nq) {
     HIP_TRY(h, h->qimg.ensure(filter_qimg_bytes(h->ld)));
-    HIP_TRY(h, h->fmisc.ensure(4 * kFilterQueries * sizeof(uint32_t)));
+    HIP_TRY(h, h->fmisc.ensure(5 * kFilterQueries * sizeof(uint32_t)));
     HIP_TRY(h, h->cand.ensure((size_t)kFilterQueries * kCandCap * sizeof(CandEntry)));
     if (h->Xb) {  // the assembly scan appends through workgroup-private buffers
         HIP_TRY(h, h->wgbuf.ensure((size_t)kScanMaxGrid * kWgCap * sizeof(WgEntry)));
@@ -258,12 +263,15 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     fa.space = h->space;
     fa.Qpad = Qpad;
     fa.qaux = qaux;
+    fa.qerr = qerr;
+    fa.row_err = h->rowerr.as<float>();
     fa.nq = nq;
     fa.qimg = h->qimg.p;
     fa.qscale = h->fmisc.as<float>();
     fa.thr = h->fmisc.as<float>() + kFilterQueries;
     fa.cnt = h->fmisc.as<uint32_t>() + 2 * kFilterQueries;
     fa.overflow = h->fmisc.as<uint32_t>() + 3 * kFilterQueries;
+    fa.ke = h->fmisc.as<float>() + 4 * kFilterQueries;
     fa.cand = h->cand.as<CandEntry>();
     fa.wgbuf = h->wgbuf.as<WgEntry>();
     fa.wgcnt = h->wgcnt.as<uint32_t>();
@@ -292,7 +300,7 @@ int collect_overflow(mlvdb_index* h, hipStream_t s, const FilterArgs& fa, int32_
 int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qaux, int32_t q0, int32_t nq,
                     int32_t k, int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_d64) {
     FilterArgs fa{};
-    int rc = setup_filter_ws(h, fa, Qpad + (size_t)q0 * h->ld, qaux + q0, nq);
+    int rc = setup_filter_ws(h, fa, Qpad + (size_t)q0 * h->ld, qaux + q0, h->qerr.as<float>() + q0, nq);
     if (rc) return rc;
     HIP_TRY(h, launch_filter_prep(fa, s));
     // seed: a dense pass of the filter kernel over the first rows puts every bound into the lists,
@@ -524,7 +532,7 @@ int mlvdb_index_destroy(mlvdb_index* h) {
     if (h->rn) (void)hipFree(h->rn);
     if (h->Xb) (void)hipFree(h->Xb);
     for (DevBuf* b : {&h->stage, &h->qpad, &h->qaux, &h->partial, &h->qsel, &h->seed_lab, &h->seed_dist, &h->seed_cnt,
-                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt,
+                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->qerr, &h->rowerr, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt,
                       &h->counters, &h->labels_in, &h->page_lab, &h->page_dist, &h->page_cnt, &h->page_d64, &h->cur_d,
                       &h->cur_l})
         b->release();
@@ -550,7 +558,7 @@ int mlvdb_index_append_device(mlvdb_index* h, const float* rows_device, int64_t 
     rc = reserve_rows(h, h->total + n);
     if (rc) return rc;
     HIP_TRY(h, launch_scatter_rows(rows_device, h->X, h->total, n, h->dim, h->ld, h->stream));
-    HIP_TRY(h, launch_row_norms(h->X, h->rn, h->total, n, h->ld, h->stream));
+    HIP_TRY(h, launch_row_norms(h->X, h->rn, h->total, n, h->ld, h->rowerr.as<unsigned int>(), h->stream));
     if (h->Xb) HIP_TRY(h, launch_shadow_rows(h->X, h->Xb, h->total, n, h->ld, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->total += n;
@@ -573,7 +581,7 @@ int mlvdb_index_append(mlvdb_index* h, const float* rows, int64_t n, int64_t* fi
         HIP_TRY(h, hipMemcpyAsync(h->stage.p, rows + (size_t)done * h->dim, (size_t)m * h->dim * sizeof(float),
                                   hipMemcpyHostToDevice, h->stream));
         HIP_TRY(h, launch_scatter_rows(h->stage.as<float>(), h->X, h->total + done, m, h->dim, h->ld, h->stream));
-        HIP_TRY(h, launch_row_norms(h->X, h->rn, h->total + done, m, h->ld, h->stream));
+        HIP_TRY(h, launch_row_norms(h->X, h->rn, h->total + done, m, h->ld, h->rowerr.as<unsigned int>(), h->stream));
         if (h->Xb) HIP_TRY(h, launch_shadow_rows(h->X, h->Xb, h->total + done, m, h->ld, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
@@ -673,6 +681,7 @@ int mlvdb_index_reset(mlvdb_index* h, int32_t space) {
         if (h->Xb) HIP_TRY(h, hipMemsetAsync(h->Xb, 0, (size_t)h->capacity * h->ld * 2, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
+    if (h->rowerr.p) HIP_TRY(h, hipMemsetAsync(h->rowerr.p, 0, sizeof(unsigned int), h->stream));
     h->total = 0;
     h->deleted = 0;
     if (space >= 0) h->space = space;
@@ -720,8 +729,9 @@ int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64
     HIP_TRY(h, h->qaux.ensure((size_t)nq * sizeof(double)));
     if (!h->counters_pending) HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 32, s));
     h->counters_stream = s;
+    HIP_TRY(h, h->qerr.ensure((size_t)nq * sizeof(float)));
     HIP_TRY(h, launch_query_prep(queries_device, (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
-                                 h->qaux.as<double>(), s));
+                                 h->qaux.as<double>(), h->qerr.as<float>(), s));
     if (k > MLVDB_MAX_TOPK) {
         h->stats.strategy_used = MLVDB_STRATEGY_EXACT;
         rc = run_paged_exact(h, s, h->qpad.as<float>(), h->qaux.as<double>(), nq, nullptr, (int32_t)nq, k, out_labels_device,
@@ -809,15 +819,17 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
     HIP_TRY(h, h->io_dist.ensure((size_t)nq * cap_eff * sizeof(float)));
     HIP_TRY(h, h->io_cnt.ensure((size_t)nq * sizeof(int64_t)));
     HIP_TRY(h, hipMemcpyAsync(h->io_q.p, queries, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, h->qerr.ensure((size_t)nq * sizeof(float)));
     HIP_TRY(h, launch_query_prep(h->io_q.as<float>(), (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
-                                 h->qaux.as<double>(), s));
+                                 h->qaux.as<double>(), h->qerr.as<float>(), s));
     const bool filt = h->strategy != MLVDB_STRATEGY_EXACT && filter_supported(h->ld) &&
                       (h->strategy == MLVDB_STRATEGY_FILTER || (nq >= 12 && h->total >= 32768));
     h->stats.strategy_used = filt ? MLVDB_STRATEGY_FILTER : MLVDB_STRATEGY_EXACT;
     for (int64_t q0 = 0; q0 < nq; q0 += kFilterQueries) {
         const int32_t n = (int32_t)std::min<int64_t>(kFilterQueries, nq - q0);
         FilterArgs fa{};
-        rc = setup_filter_ws(h, fa, h->qpad.as<float>() + (size_t)q0 * h->ld, h->qaux.as<double>() + q0, n);
+        rc = setup_filter_ws(h, fa, h->qpad.as<float>() + (size_t)q0 * h->ld, h->qaux.as<double>() + q0,
+                             h->qerr.as<float>() + q0, n);
         if (rc) return rc;
         HIP_TRY(h, launch_filter_prep(fa, s));  // also clears the candidate counters
         rc = scan_event(h, s, true);

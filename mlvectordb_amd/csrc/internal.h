@@ -18,8 +18,10 @@ hipError_t launch_scatter_rows(const float* stage, float* X, int64_t first_row, 
                                hipStream_t s);
 // Xb (bf16 shadow, layout_offset_b) for the same rows, from the fp32 panels
 hipError_t launch_shadow_rows(const float* X, void* Xb, int64_t first_row, int64_t n, int32_t ld, hipStream_t s);
-// rn[row] = (float)|x_row| for the same rows (fp64 sum of squares)
-hipError_t launch_row_norms(const float* X, float* rn, int64_t first_row, int64_t n, int32_t ld, hipStream_t s);
+// rn[row] = (float)|x_row| for the same rows (fp64 sum of squares); *rel_err_max = max(*rel_err_max, |x - bf16(x)| / |x|)
+// as float bits (rounded up)
+hipError_t launch_row_norms(const float* X, float* rn, int64_t first_row, int64_t n, int32_t ld, unsigned int* rel_err_max,
+                            hipStream_t s);
 // panels -> row-major [n, dim]
 hipError_t launch_gather_rows(const float* X, float* out, int64_t first_row, int64_t n, int32_t dim, int32_t ld,
                               hipStream_t s);
@@ -36,8 +38,9 @@ hipError_t launch_compact_rows(const float* X, float* nX, const void* Xb, void* 
 // out[i] = mask[i] ? rn[i] : NaN (i < total), NaN up to capacity: a masked-out row looks tombstoned to every scan
 hipError_t launch_mask_norms(const float* rn, const uint8_t* mask, float* out, int64_t total, int64_t capacity, hipStream_t s);
 // Qpad[q][0..ld) = queries[q][0..dim) zero padded; qaux[q] = 1/(|q|+1e-30) (cosine) or |q| (l2, ip)
+// qerr (optional): |q^ - bf16 image of q^| per query, rounded up
 hipError_t launch_query_prep(const float* queries, int32_t nq, int32_t dim, int32_t ld, int32_t space, float* Qpad,
-                             double* qaux, hipStream_t s);
+                             double* qaux, float* qerr, hipStream_t s);
 
 // ---------------------------------------------------------------- exact scan (kernels_exact.hip)
 struct ExactPlan {
@@ -107,11 +110,14 @@ struct FilterArgs {
     int32_t space;
     const float* Qpad;      // [nq][ld] raw queries of this pass (q0..q0+nq)
     const double* qaux;
+    const float* qerr;      // [nq] rounding error of the bf16 query image, |q^ - q^_b| (rounded up)
+    const float* row_err;   // device scalar: max over rows of |x - bf16(x)| / |x| (rounded up)
     int32_t nq;             // <= kFilterQueries
     // workspace (per pass)
     void* qimg;             // bf16 image, filter_qimg_bytes
     float* qscale;          // [256] per-query multiplier of the dot product in score units
     float* thr;             // [256] admission threshold (lower bound of the k-th best score)
+    float* ke;              // [256] per-query error term of the bound: cosine E1q + 2 slack, ip / l2 E1q + slack (x |x|)
     uint32_t* cnt;          // [256] candidates appended
     uint32_t* overflow;     // [256] nonzero = list overflowed, query must be re-run exactly
     CandEntry* cand;        // [256][kCandCap]

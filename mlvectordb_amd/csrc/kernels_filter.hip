@@ -6,8 +6,13 @@
 // bf16 MFMA it fits under the HBM stream.  bf16 scores are not exact, so they are used only
 // as BOUNDS:  for every (query, row) the kernel computes u >= s, an upper bound of the true
 // score s (higher = nearer), from the bf16 dot product a and a rigorous rounding bound
-//       |a - <q^, x>| <= E1 * |x|,  E1 = 2^-7 + 2^-16 + ld*2^-22   (|q^| = 1)
-// (two bf16 roundings of relative size 2^-8 each, Cauchy-Schwarz, fp32 accumulation slack).
+//       |a - <q^, x>| <= E1q * |x|,  E1q = eq + (1 + 2^-8) * rmax + ld*2^-22
+// with eq = |q^ - q^_b| the MEASURED rounding error of this query's bf16 image (query_prep_kernel)
+// and rmax = max over rows of |x - x_b| / |x| (row_norms_kernel), both rounded up:
+//   <q^,x> - <q^_b,x_b> = <q^ - q^_b, x> + <q^_b, x - x_b>,  |.| <= eq |x| + (1 + eq) rmax |x|
+// (Cauchy-Schwarz, eq <= 2^-8), plus the fp32 accumulation slack of the MFMA chain.  (The worst
+// case of two bf16 roundings is 2^-7; measured errors are ~0.4 * 2^-8 each, and a 2.3x tighter
+// bound means ~4x fewer candidates per query.)
 // A row is discarded only if u < thr[q], where thr[q] is a proven LOWER bound of the k-th
 // best true score (k rows with lower bound l = u - 2*eps >= thr exist, or k exactly scored
 // seed rows do).  Everything else is appended to the query's candidate list and rescored in
@@ -50,7 +55,6 @@ static_assert(kFilterTile % 192 == 0 && kFilterTile % 128 == 0, "kFilterTile");
 bool filter_supported(int32_t ld) { return ld >= kFilterChunkK && (ld % kFilterChunkK) == 0; }
 size_t filter_qimg_bytes(int32_t ld) { return (size_t)kFilterQueries * ld * 2; }
 
-static inline float filter_e1(int32_t ld) { return 0.0078125f + 1.52587890625e-05f + (float)ld * 2.384185791015625e-07f; }
 
 // ------------------------------------------------------------------ query image
 // Qimg[kc][n][ks][lane][j] = bf16(q^[16n + (lane&15)][64kc + 16(2ks + (j>>2)) + 4(lane>>4) + (j&3)])
@@ -84,6 +88,10 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const FilterArgs a) {
         const int q = threadIdx.x;  // 256 threads = kFilterQueries
         const double nrm = q < a.nq ? (a.space == kSpaceCosine ? 0.0 : a.qaux[q]) : 0.0;
         a.qscale[q] = a.space == kSpaceL2 ? (float)(2.0 * nrm) : 1.0f;
+        // per-query error term of the bound (see the header): E1q, plus the slack of the epilogue arithmetic
+        const double e1q = (q < a.nq ? (double)a.qerr[q] : 0.0) + 1.00390625 * (double)*a.row_err + (double)a.ld * 2.384185791015625e-07;
+        float ke = (float)(e1q * 1.000001) + (a.space == kSpaceCosine ? 2.0f : 1.0f) * kSlack;
+        a.ke[q] = __uint_as_float(__float_as_uint(ke) + 1u);
         a.thr[q] = q < a.nq ? -3.0e38f : 3.4e38f;  // padded queries never admit anything
         a.cnt[q] = 0;
         a.overflow[q] = 0;
@@ -142,13 +150,14 @@ __global__ __launch_bounds__(256) void filter_range_thr_kernel(const FilterArgs 
 // row0 = first of this lane's rows; dump = this lane's column of a [4*kMT][64] LDS scratch per wave.
 template <int SPACE, int kMT, bool DENSE>
 __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (&acc)[kMT][16], const float4 (&rnv)[kMT],
-                                              const int32_t row0, const int32_t base_row, const float e1,
-                                              const float* thr_l, const float* sq_l, float* dump, const int c16) {
-    // per-row constants: cosine  u = a*p0 + ec      (p0 = 1/(|x|+1e-30))
-    //                    ip      u = a + p0          (p0 = (e1+slack)|x|)
-    //                    l2      u = sq*(a + p0) + p1 (p1 = -|x|^2 (1-slack))
+                                              const int32_t row0, const int32_t base_row,
+                                              const float* thr_l, const float* sq_l, const float* ke_l, float* dump,
+                                              const int c16) {
+    // ke = the query's error term (filter_prep_kernel).  Per-row constants:
+    //   cosine  u = a*p0 + ke             (p0 = 1/(|x|+1e-30))
+    //   ip      u = a + ke*p0             (p0 = |x|)
+    //   l2      u = sq*(a + ke*p0) + p1   (p1 = -|x|^2 (1-slack))
     float p0[kMT][4], p1[kMT][4];
-    const float ec = e1 + 2.0f * kSlack;
 #pragma unroll
     for (int m = 0; m < kMT; ++m) {
         const float nr[4] = {rnv[m].x, rnv[m].y, rnv[m].z, rnv[m].w};
@@ -158,16 +167,16 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
                 p0[m][i] = 1.0f / (nr[i] + 1e-30f);
                 p1[m][i] = 0.f;
             } else {
-                p0[m][i] = (e1 + kSlack) * nr[i];
+                p0[m][i] = nr[i];
                 p1[m][i] = SPACE == kSpaceL2 ? -(nr[i] * nr[i]) * (1.0f - kSlack) : 0.f;
             }
         }
     }
-    auto bound = [&](int m, int i, int n, float sq) __attribute__((always_inline)) {
+    auto bound = [&](int m, int i, int n, float sq, float ke) __attribute__((always_inline)) {
         const float av = acc[m][n][i];
-        if (SPACE == kSpaceCosine) return __builtin_fmaf(av, p0[m][i], ec);
-        if (SPACE == kSpaceIp) return av + p0[m][i];
-        return __builtin_fmaf(sq, av + p0[m][i], p1[m][i]);
+        if (SPACE == kSpaceCosine) return __builtin_fmaf(av, p0[m][i], ke);
+        if (SPACE == kSpaceIp) return __builtin_fmaf(ke, p0[m][i], av);
+        return __builtin_fmaf(sq, __builtin_fmaf(ke, p0[m][i], av), p1[m][i]);
     };
     if (DENSE) {
         // seeding pass: every (query,row) bound of these tiles goes straight into the candidate
@@ -175,13 +184,14 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
             const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
+            const float ke = ke_l[16 * n + c16];
             CandEntry* dst = a.cand + (int64_t)(16 * n + c16) * kCandCap + (row0 - base_row);
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     CandEntry e;
-                    e.u = bound(m, i, n, sq);
+                    e.u = bound(m, i, n, sq, ke);
                     e.row = row0 + 16 * m + i;
                     dst[16 * m + i] = e;
                 }
@@ -197,17 +207,18 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
         __builtin_amdgcn_sched_barrier(0);  // keep only one query tile's scores live at a time
         const float thr = thr_l[16 * n + c16];
         const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
+        const float ke = ke_l[16 * n + c16];
         float mx = -3.4e38f;
 #pragma unroll
         for (int m = 0; m < kMT; ++m)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) mx = __builtin_fmaxf(mx, bound(m, i, n, sq));
+            for (int i = 0; i < 4; ++i) mx = __builtin_fmaxf(mx, bound(m, i, n, sq, ke));
         uint32_t mask = 0, slot = 0;
         if (__ballot(mx >= thr)) {
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) mask |= bound(m, i, n, sq) >= thr ? 1u << (4 * m + i) : 0u;
+                for (int i = 0; i < 4; ++i) mask |= bound(m, i, n, sq, ke) >= thr ? 1u << (4 * m + i) : 0u;
             if (mask) slot = atomicAdd(&a.cnt[16 * n + c16], (uint32_t)__popc(mask));
         }
         packed[n] = mask | (min(slot, (uint32_t)kCandCap) << 12);
@@ -217,10 +228,11 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
     for (int n = 0; n < 16; ++n) {
         if (__ballot((packed[n] & 0xfffu) != 0)) {
             const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
+            const float ke = ke_l[16 * n + c16];
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) dump[(4 * m + i) * 64] = bound(m, i, n, sq);
+                for (int i = 0; i < 4; ++i) dump[(4 * m + i) * 64] = bound(m, i, n, sq, ke);
             const int q = 16 * n + c16;
             uint32_t mask = packed[n] & 0xfffu;
             uint32_t slot = packed[n] >> 12;
@@ -256,7 +268,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
 // All loads are ordinary loads on purpose: hipcc then tracks them with counted s_waitcnt.
 template <int SPACE, bool XB, bool DENSE>
 __global__ __launch_bounds__(256, 2) void filter_scan_kernel(const FilterArgs a, const int64_t tile_begin,
-                                                                        const int64_t tile_end, const float e1) {
+                                                             const int64_t tile_end) {
     constexpr int R = 2, QD = 2, kMT = 2, NW = 4;  // ring depth, B read-ahead, panels per wave, waves (measured best for hipcc's schedule)
     constexpr int U = R;                          // steps per unrolled body
     constexpr int kThreads = NW * 64;
@@ -266,7 +278,8 @@ __global__ __launch_bounds__(256, 2) void filter_scan_kernel(const FilterArgs a,
     uint4* qlds = reinterpret_cast<uint4*>(smem);                                  // [2][kChunkVec]
     float* thr_l = reinterpret_cast<float*>(smem + 2 * kChunkVec * sizeof(uint4));  // [256]
     float* sq_l = thr_l + kFilterQueries;                                           // [256]
-    float* hit_l = sq_l + kFilterQueries;                                           // [NW waves][4*kMT][64]
+    float* ke_l = sq_l + kFilterQueries;                                            // [256]
+    float* hit_l = ke_l + kFilterQueries;                                           // [NW waves][4*kMT][64]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform
@@ -277,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void filter_scan_kernel(const FilterArgs a,
     if (threadIdx.x < kFilterQueries) {
         thr_l[threadIdx.x] = a.thr[threadIdx.x];
         sq_l[threadIdx.x] = a.qscale[threadIdx.x];
+        ke_l[threadIdx.x] = a.ke[threadIdx.x];
     }
 
     const int64_t ntiles = tile_end - tile_begin;
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void filter_scan_kernel(const FilterArgs a,
 
     auto epilogue = [&](const int64_t ti) __attribute__((always_inline)) {
         scan_epilogue<SPACE, kMT, DENSE>(a, acc, rnv, (int32_t)(tile_of(ti) * kFilterTileRows) + wave * (16 * kMT) + g * 4,
-                                         (int32_t)(tile_begin * kFilterTileRows), e1, thr_l, sq_l,
+                                         (int32_t)(tile_begin * kFilterTileRows), thr_l, sq_l, ke_l,
                                          hit_l + wave * (4 * kMT * 64) + lane, c16);
     };
 
@@ -489,17 +503,18 @@ static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagre
 
 template <int SPACE, int R, int NW, bool NT, int QD, bool PRIO, int MT>
 __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kernel(const FilterArgs a, const int64_t tile_begin,
-                                                                      const int64_t tile_end, const float e1) {
+                                                                                  const int64_t tile_end) {
     constexpr int kThreads = NW * 64;
     constexpr int kQPer = 1024 / kThreads;  // uint4 of a Q half-chunk moved per thread
     constexpr int kWaveRows = 16 * MT;  // MT = 2: two waves per SIMD; MT = 4: one, 64 rows each
     constexpr int kTileRowsV = NW * kWaveRows;
     constexpr int kQBufs = 2;
     constexpr int kStageCap = MT == 4 ? kAsmStageCapNw4Mt4 : (NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4);  // entries a wave stages in LDS
-    // LDS: [2][32 KiB] Q chunks at offset 0, thr[256], qscale[256], [NW waves] staging {u[], row[], q[]}
+    // LDS: [2][32 KiB] Q chunks at offset 0, thr[256], qscale[256], ke[256], [NW waves] staging {u[], row[], q[]}
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* thr_l = reinterpret_cast<float*>(smem + kQBufs * kChunkVec * sizeof(uint4));
     float* sq_l = thr_l + kFilterQueries;
+    float* ke_l = sq_l + kFilterQueries;
     if (threadIdx.x < NW) a.wgcnt[blockIdx.x * NW + threadIdx.x] = 0;  // workgroups without tiles return below
 
     const int lane = threadIdx.x & 63;
@@ -510,6 +525,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     for (int t = threadIdx.x; t < kFilterQueries; t += kThreads) {
         thr_l[t] = a.thr[t];
         sq_l[t] = a.qscale[t];
+        ke_l[t] = a.ke[t];
     }
     const int64_t ntiles_all = tile_end - tile_begin;
     const int64_t my_tiles = ntiles_all > blockIdx.x ? (ntiles_all - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
@@ -544,7 +560,6 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
         qsrd[2] = qbytes;
         qsrd[3] = 0x00020000u;
     }
-    const float k0 = SPACE == kSpaceCosine ? e1 + 2.0f * kSlack : e1 + kSlack;
     const float k1 = -(1.0f - kSlack);
     // the later-dispatched half of the workgroup's waves (readfirstlane: an "s" operand must live in an SGPR)
     const uint32_t wtype = __builtin_amdgcn_readfirstlane(wave >= NW / 2 ? 1u : 0u);
@@ -556,7 +571,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     const int32_t* wgbr = reinterpret_cast<const int32_t*>(wgb + kCapW * 4);
     const uint32_t* wgbq = reinterpret_cast<const uint32_t*>(wgb + kCapW * 8);
     const uint32_t* wgcp = a.wgcnt + blockIdx.x * NW + wave;
-    const uint32_t stg = (uint32_t)(kQBufs * chunk_bytes) + 2 * kFilterQueries * sizeof(float) + (uint32_t)wave * (12 * kStageCap);
+    const uint32_t stg = (uint32_t)(kQBufs * chunk_bytes) + 3 * kFilterQueries * sizeof(float) + (uint32_t)wave * (12 * kStageCap);
     const uint32_t* ovfb = a.overflow;
     const uint32_t lane16 = lane * 16;
     const uint32_t qvoff = (uint32_t)wave * 2048u + lane16;  // this thread's uint4 of fragment piece 2*wave + h
@@ -568,7 +583,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
 
     u32x4s xring[R * MT], qsa[kQPer], qsb[kQPer], qt[QD > 8 ? 4 : QD];
     float vr[4 * MT], vp[4 * MT], vu[4 * MT];
-    uint32_t ve[12], ldr, ldw;
+    uint32_t ve[13], ldr, ldw;
     uint32_t s_xso0, s_xso1, s_xso2, s_xso3, s_qcur, s_cnt, s_st0, s_tl, s_trow, s_sn64, s_wcnt, s_sacc0, s_sacc1;
     (void)vp;
     (void)s_xso2;
@@ -579,10 +594,10 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
 
 // ------------------------------------------------------------------ threshold update + compaction
 // eps such that l = u - 2*eps <= s <= u for the entry's (query,row); mirrors the scan epilogue.
-__device__ __forceinline__ float entry_eps(int space, float e1, float sq, float nr) {
-    if (space == kSpaceCosine) return e1 + 2.0f * kSlack;
-    if (space == kSpaceIp) return (e1 + kSlack) * nr;
-    return sq * (e1 + kSlack) * nr + kSlack * nr * nr;
+__device__ __forceinline__ float entry_eps(int space, float ke, float sq, float nr) {
+    if (space == kSpaceCosine) return ke;
+    if (space == kSpaceIp) return ke * nr;
+    return sq * ke * nr + kSlack * nr * nr;
 }
 
 __device__ __forceinline__ uint32_t float_order_key(float f) {  // monotone float -> uint (larger float, larger key)
@@ -597,7 +612,7 @@ __device__ __forceinline__ float float_from_order_key(uint32_t k) {
 // u < thr are dropped.  The k-th largest lower bound is found by a 4-pass radix select on the order
 // keys through an LDS histogram (no shuffles, 8 barriers), then the list is compacted through LDS.
 constexpr int kUpdThreads = 256;
-__global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const FilterArgs a, const int32_t k, const float e1,
+__global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const FilterArgs a, const int32_t k,
                                                                       const int32_t forced_cnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     CandEntry* stage = reinterpret_cast<CandEntry*>(smem);                                   // [kCandCap]
@@ -613,6 +628,7 @@ __global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const Filter
     }
     CandEntry* list = a.cand + (int64_t)q * kCandCap;
     const float sq = a.qscale[q];
+    const float ke = a.ke[q];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool need_norm = a.space != kSpaceCosine;
     float thr = a.thr[q];
@@ -623,7 +639,7 @@ __global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const Filter
         stage[idx] = e;
         uint32_t key = 0;
         if (e.u == e.u) {
-            const float eps = entry_eps(a.space, e1, sq, need_norm ? a.rn[e.row] : 0.f);
+            const float eps = entry_eps(a.space, ke, sq, need_norm ? a.rn[e.row] : 0.f);
             float l = e.u - 2.0f * eps;
             l -= kSlack * (__builtin_fabsf(e.u) + eps);  // rounding of the line above
             key = float_order_key(l);
@@ -977,7 +993,7 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
     const int64_t tile_begin = row_begin / tile_rows;
     const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
     if (tile_end <= tile_begin) return hipSuccess;
-    const size_t lds = 2 * kChunkVec * sizeof(uint4) + 2 * kFilterQueries * sizeof(float) +
+    const size_t lds = 2 * kChunkVec * sizeof(uint4) + 3 * kFilterQueries * sizeof(float) +
                        (size_t)NW * 4 * MT * 64 * sizeof(float);
     const int64_t ntiles = tile_end - tile_begin;
     const int max_grid = 256 * 2;  // workgroups resident per launch
@@ -990,7 +1006,7 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
         if (e != hipSuccess) return e;
         configured = true;
     }
-    kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end, filter_e1(a.ld));
+    kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end);
     return hipGetLastError();
 }
 
@@ -1000,7 +1016,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     const int64_t tile_begin = row_begin / tile_rows;
     const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
     if (tile_end <= tile_begin) return hipSuccess;
-    const size_t lds = 2 * kChunkVec * sizeof(uint4) + 2 * kFilterQueries * sizeof(float) +
+    const size_t lds = 2 * kChunkVec * sizeof(uint4) + 3 * kFilterQueries * sizeof(float) +
                        (size_t)NW * 12 * (MT == 4 ? kAsmStageCapNw4Mt4 : (NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4));
     const int64_t ntiles = tile_end - tile_begin;
     const int max_grid = 256 * ((16 / MT) / NW);  // two waves per SIMD on every CU (<= kScanMaxGrid)  // two waves per SIMD on every CU
@@ -1013,7 +1029,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
         if (e != hipSuccess) return e;
         configured = true;
     }
-    kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end, filter_e1(a.ld));
+    kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end);
     info->scatter_grid = grid;  // the caller runs launch_filter_scatter next (outside its timing window)
     info->nw = NW;
     info->dbg = QD == 108 ? 1 : 0;
@@ -1116,7 +1132,7 @@ static hipError_t launch_update(const FilterArgs& a, int32_t k, int32_t forced_c
         if (e != hipSuccess) return e;
         configured = true;
     }
-    filter_update_kernel<<<a.nq, kUpdThreads, lds, s>>>(a, k, filter_e1(a.ld), forced_cnt);
+    filter_update_kernel<<<a.nq, kUpdThreads, lds, s>>>(a, k, forced_cnt);
     return hipGetLastError();
 }
 

@@ -62,8 +62,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 // One wave per panel; lane 16*g + r sums the squares of row r over its column slices.
+// Also maintains *rel_err_max = max over rows of |x - bf16(x)| / |x| (RNE, the conversion the filter scan and the
+// shadow use): the row half of the filter's rounding bound (kernels_filter.hip).  Non-negative floats order like
+// their bit patterns, so the maximum is an atomicMax on the bits.
 __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ X, float* __restrict__ rn,
-                                                        int64_t first_row, int64_t n, int32_t ld) {
+                                                        int64_t first_row, int64_t n, int32_t ld,
+                                                        unsigned int* __restrict__ rel_err_max) {
     const int lane = threadIdx.x & 63;
     const int64_t first_panel = first_row >> 4;
     const int64_t last_panel = (first_row + n - 1) >> 4;
@@ -72,18 +76,30 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
     const int nkb = ld >> 4;
     for (int64_t panel = first_panel + wave; panel <= last_panel; panel += nwaves) {
         const float* base = X + panel * (int64_t)(kPanelRows * ld) + lane_group_offset(lane);
-        double s = 0.0;
+        double s = 0.0, err = 0.0;
         for (int kb = 0; kb < nkb; ++kb) {
             const float4 x = *reinterpret_cast<const float4*>(base + (int64_t)kb * kGroupFloats);
-            s = __builtin_fma((double)x.x, (double)x.x, s);
-            s = __builtin_fma((double)x.y, (double)x.y, s);
-            s = __builtin_fma((double)x.z, (double)x.z, s);
-            s = __builtin_fma((double)x.w, (double)x.w, s);
+            const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s = __builtin_fma((double)xs[i], (double)xs[i], s);
+                const double e = (double)xs[i] - (double)(float)(__bf16)xs[i];
+                err = __builtin_fma(e, e, err);
+            }
         }
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
+        err += __shfl_xor(err, 16);
+        err += __shfl_xor(err, 32);
         const int64_t row = panel * kPanelRows + (lane & 15);
-        if (lane < 16 && row >= first_row && row < first_row + n) rn[row] = (float)__builtin_sqrt(s);
+        if (lane < 16 && row >= first_row && row < first_row + n) {
+            rn[row] = (float)__builtin_sqrt(s);
+            if (s > 0.0 && err > 0.0) {
+                float rel = (float)(__builtin_sqrt(err / s) * 1.000001);
+                rel = __uint_as_float(__float_as_uint(rel) + 1u);  // (float) may have rounded down
+                atomicMax(rel_err_max, __float_as_uint(rel));
+            }
+        }
     }
 }
 
@@ -100,10 +116,14 @@ __global__ __launch_bounds__(256) void tombstone_kernel(float* __restrict__ rn, 
 }
 
 // One block per query: zero-padded copy + fp64 norm.
+// qerr[q] (optional) = |q^ - q^_b| rounded up, where q^ = q / (|q| + 1e-30) and q^_b is the bf16 query image exactly
+// as filter_prep_kernel computes it (fp32 product with the fp32 inverse norm, then RNE to bf16): the query half of
+// the filter's rounding bound.
 __global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict__ queries, int32_t dim, int32_t ld,
                                                          int32_t space, float* __restrict__ Qpad,
-                                                         double* __restrict__ qaux) {
+                                                         double* __restrict__ qaux, float* __restrict__ qerr) {
     __shared__ double red[4];
+    __shared__ double inv_s;
     const int q = blockIdx.x;
     const float* src = queries + (int64_t)q * dim;
     float* dst = Qpad + (int64_t)q * ld;
@@ -118,7 +138,26 @@ __global__ __launch_bounds__(256) void query_prep_kernel(const float* __restrict
     __syncthreads();
     if (threadIdx.x == 0) {
         const double nrm = __builtin_sqrt((red[0] + red[1]) + (red[2] + red[3]));
-        qaux[q] = space == kSpaceCosine ? 1.0 / (nrm + 1e-30) : nrm;
+        const double aux = space == kSpaceCosine ? 1.0 / (nrm + 1e-30) : nrm;
+        qaux[q] = aux;
+        inv_s = space == kSpaceCosine ? aux : 1.0 / (aux + 1e-30);  // what filter_prep_kernel multiplies by
+    }
+    if (!qerr) return;
+    __syncthreads();
+    const double inv = inv_s;
+    double e2 = 0.0;
+    for (int c = threadIdx.x; c < dim; c += blockDim.x) {
+        const float v = src[c];
+        const double e = (double)v * inv - (double)(float)(__bf16)(v * (float)inv);
+        e2 = __builtin_fma(e, e, e2);
+    }
+    for (int off = 32; off > 0; off >>= 1) e2 += __shfl_xor(e2, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = e2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float e = (float)(__builtin_sqrt((red[0] + red[1]) + (red[2] + red[3])) * 1.000001);
+        qerr[q] = __uint_as_float(__float_as_uint(e) + 1u);  // (float) may have rounded down; never below the true error
     }
 }
 
@@ -149,10 +188,11 @@ hipError_t launch_gather_rows(const float* X, float* out, int64_t first_row, int
     return hipGetLastError();
 }
 
-hipError_t launch_row_norms(const float* X, float* rn, int64_t first_row, int64_t n, int32_t ld, hipStream_t s) {
+hipError_t launch_row_norms(const float* X, float* rn, int64_t first_row, int64_t n, int32_t ld, unsigned int* rel_err_max,
+                            hipStream_t s) {
     if (n <= 0) return hipSuccess;
     const int64_t panels = ((first_row + n - 1) >> 4) - (first_row >> 4) + 1;
-    row_norms_kernel<<<grid_for(panels, 4), 256, 0, s>>>(X, rn, first_row, n, ld);
+    row_norms_kernel<<<grid_for(panels, 4), 256, 0, s>>>(X, rn, first_row, n, ld, rel_err_max);
     return hipGetLastError();
 }
 
@@ -164,9 +204,9 @@ hipError_t launch_tombstone(float* rn, const int64_t* labels, int64_t n, int64_t
 }
 
 hipError_t launch_query_prep(const float* queries, int32_t nq, int32_t dim, int32_t ld, int32_t space, float* Qpad,
-                             double* qaux, hipStream_t s) {
+                             double* qaux, float* qerr, hipStream_t s) {
     if (nq <= 0) return hipSuccess;
-    query_prep_kernel<<<nq, 256, 0, s>>>(queries, dim, ld, space, Qpad, qaux);
+    query_prep_kernel<<<nq, 256, 0, s>>>(queries, dim, ld, space, Qpad, qaux, qerr);
     return hipGetLastError();
 }
 

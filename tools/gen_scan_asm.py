@@ -253,23 +253,24 @@ def gen_admission(space):
     a = s.emit
     a("s_nop 15")   # XDL write -> v_accvgpr_read of the accumulators
     a("s_nop 7")
-    # per-row constants (scan_epilogue): cosine p0 = 1/(|x|+1e-30); ip p0 = (e1+slack)|x|;
-    # l2 p0 = (e1+slack)|x|, p1 = -|x|^2 (1-slack)
+    # ke = the query's error term from LDS (filter_prep_kernel).  Per-row constants (scan_epilogue):
+    # cosine p0 = 1/(|x|+1e-30), u = a*p0 + ke; ip p0 = |x|, u = a + ke*p0; l2 p0 = |x|, p1 = -|x|^2 (1-slack),
+    # u = sq*(a + ke*p0) + p1
     NR = 4 * MT
     for j in range(NR):
         if space == "cosine":
             a(f"v_add_f32 %[r{j}], 0x0da24260, %[r{j}]")   # + 1e-30f
             a(f"v_rcp_f32 %[r{j}], %[r{j}]")
-        else:
-            if space == "l2":
-                a(f"v_mul_f32 %[p{j}], %[r{j}], %[r{j}]")
-                a(f"v_mul_f32 %[p{j}], %[k1], %[p{j}]")    # k1 = -(1 - slack)
-            a(f"v_mul_f32 %[r{j}], %[k0], %[r{j}]")        # k0 = e1 + slack
+        elif space == "l2":
+            a(f"v_mul_f32 %[p{j}], %[r{j}], %[r{j}]")
+            a(f"v_mul_f32 %[p{j}], %[k1], %[p{j}]")        # k1 = -(1 - slack)
     thr = lambda n: f"%[e{n & 1}]"
     sq = lambda n: f"%[e{2 + (n & 1)}]"
+    ke = lambda n: f"%[e{10 if n & 1 else 12}]"
 
     def fetch(n):
         s.lds(f"ds_read_b32 {thr(n)}, %[thra] offset:{n * 64}", ("thr", n))
+        s.lds(f"ds_read_b32 {ke(n)}, %[thra] offset:{2048 + n * 64}", ("ke", n))
         if space == "l2":
             s.lds(f"ds_read_b32 {sq(n)}, %[thra] offset:{1024 + n * 64}", ("sq", n))
 
@@ -280,15 +281,14 @@ def gen_admission(space):
         for j in range(NR):
             m, i = j >> 2, j & 3
             a(f"v_accvgpr_read_b32 %[u{j}], a{(m * 16 + n) * 4 + i}")
-        if space == "l2":
-            s.need_lg(("sq", n))
+        s.need_lg(("ke", n), *([("sq", n)] if space == "l2" else []))
         for j in range(NR):
             if space == "cosine":
-                a(f"v_fma_f32 %[u{j}], %[u{j}], %[r{j}], %[k0]")    # k0 = e1 + 2 slack
+                a(f"v_fma_f32 %[u{j}], %[u{j}], %[r{j}], {ke(n)}")
             elif space == "ip":
-                a(f"v_add_f32 %[u{j}], %[u{j}], %[r{j}]")
+                a(f"v_fma_f32 %[u{j}], {ke(n)}, %[r{j}], %[u{j}]")
             else:
-                a(f"v_add_f32 %[u{j}], %[u{j}], %[r{j}]")
+                a(f"v_fma_f32 %[u{j}], {ke(n)}, %[r{j}], %[u{j}]")
                 a(f"v_fma_f32 %[u{j}], {sq(n)}, %[u{j}], %[p{j}]")
         a("v_max3_f32 %[e4], %[u0], %[u1], %[u2]")
         a("v_max3_f32 %[e5], %[u3], %[u4], %[u5]")
@@ -322,7 +322,7 @@ def gen_hit_stubs():
 def lds_stage_cap(NW, mt=2):
     """Entries of a wave's staging area in LDS (12 B each, SoA): what is left of the 160 KiB per CU."""
     wgs_per_cu = (16 // mt) // NW      # mt = 2: two waves per SIMD, mt = 4: one
-    per_wg = (160 * 1024) // wgs_per_cu - (2 * CHUNK_BYTES + 2048)
+    per_wg = (160 * 1024) // wgs_per_cu - (2 * CHUNK_BYTES + 3072)   # Q buffers + thr[256], qscale[256], ke[256]
     return min(WG_CAP // NW, (per_wg // NW) // 12 // 8 * 8)
 
 
@@ -539,7 +539,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2):
             ops_out.append(f'[p{j}] "=&v"(vp[{j}])')
     for j in range(4 * MT):
         ops_out.append(f'[u{j}] "=&v"(vu[{j}])')
-    for j in range(12):
+    for j in range(13):
         ops_out.append(f'[e{j}] "=&v"(ve[{j}])')
     ops_out += ['[ldr] "=&v"(ldr)', '[ldw] "=&v"(ldw)']
     for name in [f"xso{m}" for m in range(MT)] + ["qcur", "cnt", "st0", "tl", "trow", "sn64", "wcnt", "sacc0", "sacc1"]:
@@ -550,7 +550,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2):
                '[rnlo] "s"(rnlo)', '[rnhi] "s"(rnhi)', '[rnstride] "s"(rnstride)',
                '[row0] "s"(row0)', '[rowstride] "s"(rowstride)', '[ntiles] "s"(ntiles)',
                '[pb] "s"(pb)', '[qbytes] "s"(qbytes)', '[nb] "s"(nb)', '[qcur0] "s"(qcur0)', '[qc1] "s"(qc1)',
-               '[k0] "s"(k0)', '[wtype] "s"(wtype)', '[wgbu] "s"(wgbu)', '[wgbr] "s"(wgbr)', '[wgbq] "s"(wgbq)', '[wgcp] "s"(wgcp)',
+               '[wtype] "s"(wtype)', '[wgbu] "s"(wgbu)', '[wgbr] "s"(wgbr)', '[wgbq] "s"(wgbq)', '[wgcp] "s"(wgcp)',
                '[ovfb] "s"(ovfb)']
     if space == "l2":
         ops_in.append('[k1] "s"(k1)')
