@@ -14,7 +14,7 @@
 
 namespace mlvdb {
 
-template <int SPACE, int QT, int PW, int NW>
+template <int SPACE, int QT, int PW, int NW, bool NT>
 __global__ __launch_bounds__(NW * 64) void exact_scan_kernel(const ExactArgs a, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* qs = reinterpret_cast<double*>(smem);  // [QT][ld]
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(NW * 64) void exact_scan_kernel(const ExactArgs a, 
         }
         double acc[PW][QT];
         double nx[PW];
-        accumulate_rows<SPACE, QT, PW, (QT == 8 ? 4 : 0)>(base, qs, ld, g, acc, nx);
+        accumulate_rows<SPACE, QT, PW, (QT == 8 ? 4 : 0), NT>(base, qs, ld, g, acc, nx);
 #pragma unroll
         for (int p = 0; p < PW; ++p) {
             const int64_t row = panel[p] * kPanelRows + r;
@@ -282,9 +282,9 @@ ExactPlan plan_exact(int64_t nrows, int32_t ld, int32_t nq_sel, int32_t k) {
     return p;
 }
 
-template <int SPACE, int QT, int PW, int NW>
+template <int SPACE, int QT, int PW, int NW, bool NT = false>
 static hipError_t launch_one(const ExactArgs& a, const ExactPlan& p, hipStream_t s) {
-    auto kern = exact_scan_kernel<SPACE, QT, PW, NW>;
+    auto kern = exact_scan_kernel<SPACE, QT, PW, NW, NT>;
     if (p.lds_bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
@@ -296,11 +296,15 @@ static hipError_t launch_one(const ExactArgs& a, const ExactPlan& p, hipStream_t
 
 template <int SPACE>
 static hipError_t launch_space(const ExactArgs& a, const ExactPlan& p, hipStream_t s) {
+    // non-temporal corpus loads (every row is read once per launch); MLVDB_EXACT_NT=0 selects plain loads for the
+    // batch-1 shape only (A/B: tools/exact_ab.py)
+    static const bool plain = [] { const char* e = getenv("MLVDB_EXACT_NT"); return e && atoi(e) == 0; }();
+    if (p.qt == 1 && plain) return launch_one<SPACE, 1, 2, 16, false>(a, p, s);
     switch (p.qt) {
-        case 1: return launch_one<SPACE, 1, 2, 16>(a, p, s);
-        case 2: return launch_one<SPACE, 2, 2, 16>(a, p, s);
-        case 4: return launch_one<SPACE, 4, 4, 8>(a, p, s);
-        default: return launch_one<SPACE, 8, 2, 8>(a, p, s);
+        case 1: return launch_one<SPACE, 1, 2, 16, true>(a, p, s);
+        case 2: return launch_one<SPACE, 2, 2, 16, true>(a, p, s);
+        case 4: return launch_one<SPACE, 4, 4, 8, true>(a, p, s);
+        default: return launch_one<SPACE, 8, 2, 8, true>(a, p, s);
     }
 }
 

@@ -57,7 +57,8 @@ __device__ __forceinline__ void accumulate_group(const float4 (&x)[PW], const do
 // PF > 0: the groups are fetched in blocks of PF, two register banks, the next block is in
 //         flight while the current one is consumed (low-occupancy callers: seed scan, rescoring).
 //         The summation order is the same for every PF.
-template <int SPACE, int QT, int PW, int PF = 0>
+// NT: non-temporal loads (the streaming scans read every row once: +8 % on the batch-1 scan of 1M x 768).
+template <int SPACE, int QT, int PW, int PF = 0, bool NT = false>
 __device__ __forceinline__ void accumulate_rows(const float* const (&base)[PW], const double* qs, int ld, int g,
                                                 double (&acc)[PW][QT], double (&nx)[PW]) {
     const int nkb = ld >> 4;
@@ -72,7 +73,12 @@ __device__ __forceinline__ void accumulate_rows(const float* const (&base)[PW], 
         for (int kb = 0; kb < nkb; ++kb) {
             float4 x[PW];
 #pragma unroll
-            for (int p = 0; p < PW; ++p) x[p] = *reinterpret_cast<const float4*>(base[p] + (int64_t)kb * kGroupFloats);
+            for (int p = 0; p < PW; ++p) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v* src = reinterpret_cast<const f4v*>(base[p] + (int64_t)kb * kGroupFloats);
+                const f4v v = NT ? __builtin_nontemporal_load(src) : *src;
+                x[p] = make_float4(v.x, v.y, v.z, v.w);
+            }
             accumulate_group<SPACE, QT, PW>(x, qs, ld, g, kb, acc, nx);
         }
     } else {
@@ -84,8 +90,12 @@ __device__ __forceinline__ void accumulate_rows(const float* const (&base)[PW], 
 #pragma unroll
             for (int i = 0; i < B; ++i)
 #pragma unroll
-                for (int p = 0; p < PW; ++p)
-                    bank[i][p] = *reinterpret_cast<const float4*>(base[p] + (int64_t)(bb * B + i) * kGroupFloats);
+                for (int p = 0; p < PW; ++p) {
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const f4v* src = reinterpret_cast<const f4v*>(base[p] + (int64_t)(bb * B + i) * kGroupFloats);
+                    const f4v v = NT ? __builtin_nontemporal_load(src) : *src;
+                    bank[i][p] = make_float4(v.x, v.y, v.z, v.w);
+                }
         };
         auto consume = [&](const float4(&bank)[B][PW], int blk) __attribute__((always_inline)) {
 #pragma unroll
