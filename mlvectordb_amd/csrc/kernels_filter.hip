@@ -43,6 +43,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
 __device__ __forceinline__ float4 buf_load_f4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// the same, non-temporal (aux bit 1 = nt on gfx950): the corpus stream is read once per pass
+__device__ __forceinline__ float4 buf_load_f4_nt(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2));
+}
 __device__ __forceinline__ uint4 buf_load_u4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void filter_scan_kernel(const FilterArgs a,
         for (int m = 0; m < kMT; ++m)
 #pragma unroll
             for (int kb = 0; kb < kLoads; ++kb)
-                xb[m][kb] = buf_load_f4(r, lane_off16 + kb * 1024, pre_soff + m * panel_bytes);
+                xb[m][kb] = buf_load_f4_nt(r, lane_off16 + kb * 1024, pre_soff + m * panel_bytes);
         // advance, saturating at the last half-chunk (the tail re-loads it: harmless, and it keeps
         // every load unconditional -- a conditional load's phi makes hipcc wait for it at once)
         pre_soff += kLoads * 1024;
