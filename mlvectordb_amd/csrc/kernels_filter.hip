@@ -505,7 +505,7 @@ typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 #include "scan_asm_consts.inc"
 static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagree");
 
-template <int SPACE, int R, int NW, bool NT, int QD, bool PRIO, int MT>
+template <int SPACE, int R, int NW, bool NT, int QD, bool PRIO, int MT, bool DMA>
 __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kernel(const FilterArgs a, const int64_t tile_begin,
                                                                                   const int64_t tile_end) {
     constexpr int kThreads = NW * 64;
@@ -587,7 +587,13 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
 
     u32x4s xring[R * MT], qsa[kQPer], qsb[kQPer], qt[QD > 8 ? 4 : QD];
     float vr[4 * MT], vp[4 * MT], vu[4 * MT];
-    uint32_t ve[13], ldr, ldw;
+    uint32_t ve[13], ldr, ldw, s_sldw;
+    const uint32_t wave2k = (uint32_t)wave * 2048u;  // LDS-DMA staging: this wave's piece offset inside a Q buffer
+    (void)ldw;
+    (void)s_sldw;
+    (void)wave2k;
+    (void)qsa;
+    (void)qsb;
     uint32_t s_xso0, s_xso1, s_xso2, s_xso3, s_qcur, s_cnt, s_st0, s_tl, s_trow, s_sn64, s_wcnt, s_sacc0, s_sacc1;
     (void)vp;
     (void)s_xso2;
@@ -1014,7 +1020,7 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
     return hipGetLastError();
 }
 
-template <int SPACE, int R, int NW, bool NT = false, int QD = 4, bool PRIO = false, int MT = 2>
+template <int SPACE, int R, int NW, bool NT = false, int QD = 4, bool PRIO = false, int MT = 2, bool DMA = false>
 static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info) {
     constexpr int tile_rows = NW * 16 * MT;
     const int64_t tile_begin = row_begin / tile_rows;
@@ -1025,7 +1031,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     const int64_t ntiles = tile_end - tile_begin;
     const int max_grid = 256 * ((16 / MT) / NW);  // two waves per SIMD on every CU (<= kScanMaxGrid)  // two waves per SIMD on every CU
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
-    auto kern = filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT>;
+    auto kern = filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT, DMA>;
     static bool configured = false;  // per instantiation
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1047,7 +1053,7 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
     const int nkc = a.ld / kFilterChunkK;
     if (a.Xb && env_int("MLVDB_SCAN_ASM", 1)) {
         // hand-written body (tools/gen_scan_asm.py).  Default: one 8-wave workgroup per CU (256-row tiles:
-        // the query image is staged once per CU), non-temporal X loads, ring of 4 k-steps -- measured
+        // the query image is staged once per CU, by LDS-DMA), non-temporal X loads, ring of 4 k-steps -- measured
         // fastest (profiles/r01/scan_ab_*.txt); a ring of R k-steps needs the tile's 2*nkc k-steps to be a
         // multiple of R.  MLVDB_SCAN_NW / _NT / _R / _QD select the other generated variants (tuning).
         const int nw = env_int("MLVDB_SCAN_NW", 8);
@@ -1074,6 +1080,10 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
 #endif
         }
         if (nw == 8) {
+            if (env_int("MLVDB_SCAN_DMA", 1)) {  // query image staged by LDS-DMA (default, +2 %) instead of through registers
+                if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8, true, 4, false, 2, true>(a, row_begin, row_end, s, info);
+                return launch_scan_asm<SPACE, 2, 8, true, 4, false, 2, true>(a, row_begin, row_end, s, info);
+            }
             if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8, true>(a, row_begin, row_end, s, info);
             return launch_scan_asm<SPACE, 2, 8, true>(a, row_begin, row_end, s, info);
         }

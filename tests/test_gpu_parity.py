@@ -254,7 +254,8 @@ def test_range_capacity_overflow_is_reported_then_resolved():
 
 
 SCAN_VARIANTS = [
-    {"MLVDB_SCAN_NW": "8"},                          # default: assembly body, one 8-wave workgroup per CU
+    {"MLVDB_SCAN_NW": "8"},                          # default: assembly body, one 8-wave workgroup per CU, Q by LDS-DMA
+    {"MLVDB_SCAN_NW": "8", "MLVDB_SCAN_DMA": "0"},   # Q staged through registers (global -> VGPR -> ds_write)
     {"MLVDB_SCAN_NW": "4"},                          # assembly body, two 4-wave workgroups per CU
     {"MLVDB_SCAN_MT": "4"},                          # assembly body, one wave per SIMD, 64 rows per wave
     {"MLVDB_SCAN_NW": "8", "MLVDB_SCAN_NT": "0"},    # (cosine only) temporal X loads

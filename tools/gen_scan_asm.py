@@ -22,11 +22,14 @@ energy per MFMA, which is what counts on a power-bound pipe (tools/probe).
     operands; a slot is refilled right after its last MFMA with the k-step R ahead -- the last R
     k-steps of a tile fetch the first R of the workgroup's next tile through a second descriptor,
     so the stream never stops, not even during the admission test.
-  * Q (bf16 image, L2): 64-column chunks, double buffered in LDS; during chunk c every thread
-    writes its share of chunk c+1 (fetched one chunk earlier into two register sets) into the other
-    buffer and fetches its share of chunk c+2; one s_barrier per chunk.  vmcnt completes in order,
-    so waiting for a Q set also waits for every X refill issued before that set's fetch: the
-    fetches sit just BEFORE the refills, which gives each refill about three k-steps.
+  * Q (bf16 image, L2): 64-column chunks, double buffered in LDS, one s_barrier per chunk.  Default
+    (dma): early in chunk c every wave sends its share of chunk c+1 global -> LDS directly
+    (buffer_load ... lds; the LDS address is M0 + 16*lane) and waits for it before the barrier.
+    Variant: through registers -- during chunk c every thread writes its share of chunk c+1
+    (fetched one chunk earlier into two register sets) and fetches its share of chunk c+2.
+    vmcnt completes in order, so waiting for a Q transfer also waits for every X refill issued
+    before it: the transfers sit BEFORE the refills of their k-step, which leaves each refill two
+    to three k-steps.
   * the 32 B fragments of a chunk are one software-pipelined stream: ds_read_b128 runs QD
     fragments ahead of the two MFMAs that consume a fragment.
   * admission test per query tile: 8 bounds per lane (same arithmetic as scan_epilogue), their
@@ -120,10 +123,13 @@ PRIO_STEPS = {8: (0, 2), 12: (1, 2), 16: (0, 1), 20: (1, 1), 24: (0, 0), 28: (1,
 XCUR, XNEXT, RNS, RET = "s[80:83]", "s[84:87]", "s[88:91]", "s[92:93]"
 
 
-def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False):
+def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=False):
     """One 64-column chunk = 2 k-steps = 32 fragments x MT MFMAs."""
     s.emit("v_xor_b32 %[ldr], 0x8000, %[ldr]")
-    s.emit("v_xor_b32 %[ldw], 0x8000, %[ldw]")
+    if dma:
+        s.emit("s_xor_b32 %[sldw], %[sldw], 0x8000")
+    else:
+        s.emit("v_xor_b32 %[ldw], 0x8000, %[ldw]")
 
     def read(f):
         h, n = f >> 4, f & 15
@@ -158,13 +164,22 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False):
     # before the ring refill that follows fragment 15, set qa (second halves) just before the one
     # that follows fragment 31 (see the module docstring).
     plan = {}
-    for setname, half, f in (("qb", 0, 16 - 2 * KQ), ("qa", 1, 32 - 2 * KQ)):
-        for i in range(KQ):
-            plan[f] = ("w", setname, i, half)
-            f += 1
-        for i in range(KQ):
-            plan[f] = ("l", setname, i, half)
-            f += 1
+    if dma:
+        # LDS-DMA staging: chunk c+1 goes global -> LDS directly (buffer_load ... lds: LDS address = M0 +
+        # 16*lane), early in chunk c; no staging registers, no ds_write (tools/probe: +5 % on the bare loop).
+        f = 2
+        for setname, half in (("qb", 0), ("qa", 1)):
+            for i in range(KQ):
+                plan[f] = ("d", setname, i, half)
+                f += 1
+    else:
+        for setname, half, f in (("qb", 0, 16 - 2 * KQ), ("qa", 1, 32 - 2 * KQ)):
+            for i in range(KQ):
+                plan[f] = ("w", setname, i, half)
+                f += 1
+            for i in range(KQ):
+                plan[f] = ("l", setname, i, half)
+                f += 1
 
     if prio:
         s.emit("s_setprio 3")
@@ -199,7 +214,11 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False):
             kind, setname, i, half = plan[f]
             reg = f"%[{setname}{i}]"
             const = i * NW * 2048 + half * 1024
-            if kind == "w":
+            if kind == "d":
+                s.emit(f"s_add_u32 m0, %[sldw], 0x{const:x}")
+                s.emit(f"s_add_u32 %[st0], %[qcur], 0x{const:x}")
+                s.vmem(f"buffer_load_dwordx4 %[qvoff], %[qsrd], %[st0] offen lds", (setname, i))
+            elif kind == "w":
                 s.need_vm((setname, i))
                 s.lds(f"ds_write_b128 %[ldw], {reg} offset:{const}", ("wr", setname, i))
             else:
@@ -211,6 +230,8 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False):
     s.emit("s_add_u32 %[qcur], %[qcur], 0x8000")
     s.emit("s_cmp_eq_u32 %[qcur], %[qbytes]")
     s.emit("s_cselect_b32 %[qcur], 0, %[qcur]")
+    if dma:   # this wave's share of the next chunk has landed in LDS
+        s.need_vm(*[(sn, i) for sn in ("qb", "qa") for i in range(KQ)])
     s.drain_lg()
     if "stamp" in DBG:   # cycles parked at the barrier, summed in an SGPR (timing diagnostic)
         s.emit("s_memtime s[78:79]")
@@ -223,7 +244,7 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False):
         s.emit("s_add_u32 %[sacc0], %[sacc0], s78")
 
 
-def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False):
+def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False, dma=False):
     if last:
         # |x| of this lane's 4*MT rows (rows 4g..4g+3 of every panel) for the admission test
         for j in range(4 * MT):
@@ -231,19 +252,19 @@ def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False):
             s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{off}" if off else ""),
                    ("rn", j))
     for ch in range(R // 2):
-        gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last, nt, prio)
+        gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last, nt, prio, dma)
     if last:
         s.need_vm(*[("rn", j) for j in range(4 * MT)])
 
 
-def body_lines(R, QD, KQ, NW, first, last, nt, prio=False, label0=0):
+def body_lines(R, QD, KQ, NW, first, last, nt, prio=False, label0=0, dma=False):
     s = Sched()
     s.recording = False
     for _ in range(2):   # history: every predecessor issues this pattern of memory operations
-        gen_body(s, R, QD, KQ, NW, False, False, nt, prio)
+        gen_body(s, R, QD, KQ, NW, False, False, nt, prio, dma)
     s.recording = True
     s.label = label0
-    gen_body(s, R, QD, KQ, NW, first, last, nt, prio)
+    gen_body(s, R, QD, KQ, NW, first, last, nt, prio, dma)
     return s.lines
 
 
@@ -411,7 +432,7 @@ def gen_flush(NW):
             "s_waitcnt vmcnt(0)"]
 
 
-def generate(space, R, QD, NW, nt=False, prio=False, mt=2):
+def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False):
     global MT
     MT = mt
     assert R in (2, 4, 6) and 2 <= QD <= 8 and mt in (2, 4)
@@ -438,11 +459,19 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2):
         a("s_waitcnt lgkmcnt(0)")
         a("s_mov_b32 %[sacc1], s78")
     a("v_add_u32 %[ldr], 0x8000, %[lane16]")   # the first chunk toggles it to buffer 0
-    a("v_mov_b32 %[ldw], %[qvoff]")            # ... and this one to buffer 1
-    # ---- prologue: Q chunk 0 -> LDS buffer 0, chunk 1 -> the sets, k-steps 0..R-1 -> the ring
-    for half, setname in ((0, "qb"), (1, "qa")):
-        for i in range(KQ):
-            a(f"s_movk_i32 %[st0], 0x{i * NW * 2048 + half * 1024:x}")
+    if not dma:
+        a("v_mov_b32 %[ldw], %[qvoff]")        # ... and this one to buffer 1
+    # ---- prologue: Q chunk 0 -> LDS buffer 0, chunk 1 -> the sets (register staging only), k-steps 0..R-1 -> the ring
+    pieces = [(i * NW * 2048 + half * 1024, setname, i) for half, setname in ((0, "qb"), (1, "qa")) for i in range(KQ)]
+    if dma:
+        a("s_mov_b32 %[sldw], %[wave2k]")          # buffer 0; the first chunk toggles it to buffer 1
+        for const, setname, i in pieces:
+            a(f"s_add_u32 m0, %[sldw], 0x{const:x}")
+            a(f"s_movk_i32 %[st0], 0x{const:x}")
+            a("buffer_load_dwordx4 %[qvoff], %[qsrd], %[st0] offen lds")
+    else:
+        for const, setname, i in pieces:
+            a(f"s_movk_i32 %[st0], 0x{const:x}")
             a(f"buffer_load_dwordx4 %[{setname}{i}], %[qvoff], %[qsrd], %[st0] offen")
     for b in range(R):
         for m in range(MT):
@@ -457,12 +486,11 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2):
                   f"s_add_u32 %[st0], {'%[pb]' if m == 1 else '%[st0]'}, 0x{b * 1024:x}")
                 a(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, %[st0] offen")
     a("s_waitcnt vmcnt(0)")
-    for half, setname in ((0, "qb"), (1, "qa")):
-        for i in range(KQ):
-            a(f"ds_write_b128 %[ldw], %[{setname}{i}] offset:{i * NW * 2048 + half * 1024}")
-    for half, setname in ((0, "qb"), (1, "qa")):
-        for i in range(KQ):
-            a(f"s_add_u32 %[st0], %[qc1], 0x{i * NW * 2048 + half * 1024:x}")
+    if not dma:
+        for const, setname, i in pieces:
+            a(f"ds_write_b128 %[ldw], %[{setname}{i}] offset:{const}")
+        for const, setname, i in pieces:
+            a(f"s_add_u32 %[st0], %[qc1], 0x{const:x}")
             a(f"buffer_load_dwordx4 %[{setname}{i}], %[qvoff], %[qsrd], %[st0] offen")
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")   # counted waits below assume the steady-state issue pattern
     a("s_barrier")
@@ -473,7 +501,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2):
     a("s_cselect_b32 %[cnt], %[xshi], 0")
     a("s_add_u32 s84, s80, %[st0]")
     a("s_addc_u32 s85, s81, %[cnt]")
-    a("s_mov_b32 %[qcur], %[qcur0]")
+    a("s_mov_b32 %[qcur], %[qc1]" if dma else "s_mov_b32 %[qcur], %[qcur0]")   # first chunk staged inside this tile's loop
     a(f"s_movk_i32 %[xso0], 0x{R * 1024:x}")
     a("s_add_u32 %[xso1], %[pb], %[xso0]")
     for m in range(2, MT):
@@ -481,19 +509,19 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2):
         a(f"s_add_u32 %[xso{m}], %[xso{m}], %[xso0]")
     a("s_cmp_eq_u32 %[nb], 1")
     a("s_cbranch_scc1 .Lsingle_%=")
-    out += body_lines(R, QD, KQ, NW, True, False, nt, prio, 0)
+    out += body_lines(R, QD, KQ, NW, True, False, nt, prio, 0, dma)
     a("s_sub_u32 %[cnt], %[nb], 2")
     a(".Lloop_%=:")
     a("s_cmp_eq_u32 %[cnt], 0")
     a("s_cbranch_scc1 .Llast_%=")
-    out += body_lines(R, QD, KQ, NW, False, False, nt, prio, 100)
+    out += body_lines(R, QD, KQ, NW, False, False, nt, prio, 100, dma)
     a("s_sub_u32 %[cnt], %[cnt], 1")
     a("s_branch .Lloop_%=")
     a(".Llast_%=:")
-    out += body_lines(R, QD, KQ, NW, False, True, nt, prio, 200)
+    out += body_lines(R, QD, KQ, NW, False, True, nt, prio, 200, dma)
     a("s_branch .Ladmit_%=")
     a(".Lsingle_%=:")
-    out += body_lines(R, QD, KQ, NW, True, True, nt, prio, 300)
+    out += body_lines(R, QD, KQ, NW, True, True, nt, prio, 300, dma)
     a(".Ladmit_%=:")
     if prio:
         a("s_setprio 0")
@@ -526,10 +554,11 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2):
     for b in range(R):
         for m in range(MT):
             ops_out.append(f'[x{b * MT + m}] "=&v"(xring[{b * MT + m}])')
-    for i in range(KQ):
-        ops_out.append(f'[qa{i}] "=&v"(qsa[{i}])')
-    for i in range(KQ):
-        ops_out.append(f'[qb{i}] "=&v"(qsb[{i}])')
+    if not dma:
+        for i in range(KQ):
+            ops_out.append(f'[qa{i}] "=&v"(qsa[{i}])')
+        for i in range(KQ):
+            ops_out.append(f'[qb{i}] "=&v"(qsb[{i}])')
     for i in range(QD):
         ops_out.append(f'[t{i}] "=&v"(qt[{i}])')
     for j in range(4 * MT):
@@ -541,7 +570,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2):
         ops_out.append(f'[u{j}] "=&v"(vu[{j}])')
     for j in range(13):
         ops_out.append(f'[e{j}] "=&v"(ve[{j}])')
-    ops_out += ['[ldr] "=&v"(ldr)', '[ldw] "=&v"(ldw)']
+    ops_out += ['[ldr] "=&v"(ldr)'] + (['[sldw] "=&s"(s_sldw)'] if dma else ['[ldw] "=&v"(ldw)'])
     for name in [f"xso{m}" for m in range(MT)] + ["qcur", "cnt", "st0", "tl", "trow", "sn64", "wcnt", "sacc0", "sacc1"]:
         ops_out.append(f'[{name}] "=&s"(s_{name})')
     ops_in += ['[qsrd] "s"(qsrd)', '[lane16] "v"(lane16)', '[qvoff] "v"(qvoff)', '[rnvoff] "v"(rnvoff)',
@@ -554,11 +583,13 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2):
                '[ovfb] "s"(ovfb)']
     if space == "l2":
         ops_in.append('[k1] "s"(k1)')
-    clobbers = ['"memory"', '"scc"', '"vcc"'] + [f'"s{i}"' for i in range(60, 80)] + [f'"s{i}"' for i in range(80, 94)] + [f'"a{i}"' for i in range(64 * MT)]
+    if dma:
+        ops_in.append('[wave2k] "s"(wave2k)')
+    clobbers = ['"memory"', '"scc"', '"vcc"'] + (['"m0"'] if dma else []) + [f'"s{i}"' for i in range(60, 80)] + [f'"s{i}"' for i in range(80, 94)] + [f'"a{i}"' for i in range(64 * MT)]
 
     text = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.",
             f"// filter scan body: space {space}, NW={NW} waves x {16 * MT} rows, ring R={R} k-steps, B fragments read {QD} ahead"
-            f"{', X loads non-temporal' if nt else ''}{', progress-based wave priority' if prio else ''}.",
+            f"{', X loads non-temporal' if nt else ''}{', progress-based wave priority' if prio else ''}{', Q staged by LDS-DMA' if dma else ''}.",
             "asm volatile("]
     for ln in out:
         text.append(f'    "{ln}\\n\\t"')
@@ -569,17 +600,19 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2):
 
 
 # (space, NW, R, nt) instantiated by kernels_filter.hip: the production set, and experiments (cosine only)
-CONFIGS = [(sp, nw, r, True, 4, False, 2) for sp in SPACES for nw in (4, 8) for r in (2, 4)] + [
-    ("cosine", 4, 4, False, 4, False, 2), ("cosine", 8, 4, False, 4, False, 2), ("cosine", 8, 4, True, 4, True, 2)] + [
-    (sp, 4, r, True, 4, False, 4) for sp in SPACES for r in (2, 4)]
+CONFIGS = [(sp, nw, r, True, 4, False, 2, False) for sp in SPACES for nw in (4, 8) for r in (2, 4)] + [
+    ("cosine", 4, 4, False, 4, False, 2, False), ("cosine", 8, 4, False, 4, False, 2, False),
+    ("cosine", 8, 4, True, 4, True, 2, False)] + [
+    (sp, 4, r, True, 4, False, 4, False) for sp in SPACES for r in (2, 4)] + [
+    (sp, 8, r, True, 4, False, 2, True) for sp in SPACES for r in (2, 4)]
 # timing diagnostics (cosine, NW=8, R=4, nt): QD slot carries the knob: 101 = nolds, 102 = nox, 103 = both
 DIAG = {101: {"nolds"}, 102: {"nox"}, 103: {"nolds", "nox"}, 104: {"nolds", "nox", "nobar"},
         107: {"nohit"}, 108: {"stamp"}}
 
 
-def inc_name(space, nw, r, nt, qd, prio, mt):
+def inc_name(space, nw, r, nt, qd, prio, mt, dma):
     return (f"scan_asm_{space}_nw{nw}_r{r}{'_nt' if nt else ''}{'_qd%d' % qd if qd != 4 else ''}"
-            f"{'_pr' if prio else ''}{'_mt4' if mt == 4 else ''}.inc")
+            f"{'_pr' if prio else ''}{'_mt4' if mt == 4 else ''}{'_dma' if dma else ''}.inc")
 
 
 def main():
@@ -592,22 +625,22 @@ def main():
         print(" ".join(names))
         return
     for c in CONFIGS:
-        space, nw, r, nt, qd, prio, mt = c
-        (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt, prio, mt))
+        space, nw, r, nt, qd, prio, mt, dma = c
+        (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt, prio, mt, dma))
     for code, knobs in DIAG.items():
         DBG.clear()
         DBG.update(knobs)
         (Path(args.outdir) / f"scan_asm_diag{code}.inc").write_text(generate("cosine", 4, 4, 8, True, False))
         DBG.clear()
-    disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT>."]
-    for i, (space, nw, r, nt, qd, prio, mt) in enumerate(CONFIGS):
+    disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT, DMA>."]
+    for i, (space, nw, r, nt, qd, prio, mt, dma) in enumerate(CONFIGS):
         cond = (f"SPACE == {SPACES[space]} && NW == {nw} && R == {r} && NT == {'true' if nt else 'false'} && QD == {qd}"
-                f" && PRIO == {'true' if prio else 'false'} && MT == {mt}")
+                f" && PRIO == {'true' if prio else 'false'} && MT == {mt} && DMA == {'true' if dma else 'false'}")
         disp.append(("if" if i == 0 else "} else if") + f" constexpr ({cond}) {{")
-        disp.append(f'#include "{inc_name(space, nw, r, nt, qd, prio, mt)}"')
+        disp.append(f'#include "{inc_name(space, nw, r, nt, qd, prio, mt, dma)}"')
     disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
     for code in DIAG:
-        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2) {{")
+        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2 && DMA == false) {{")
         disp.append(f'#include "scan_asm_diag{code}.inc"')
     disp.append("#endif")
     disp.append("} else {")

@@ -82,6 +82,35 @@ __global__ __launch_bounds__(256, 1) void probe_mt4(const u32x4* in, unsigned lo
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * 4 + threadIdx.x / 64] = tb - ta;
 }
 
+// level 6 with LDS-DMA staging
+__global__ __launch_bounds__(512, 2) void probe_dma(const u32x4* in, unsigned long long* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* l = reinterpret_cast<u32x4*>(smem);
+    for (int i = threadIdx.x; i < 4096; i += 512) l[i] = in[i];
+    __syncthreads();
+    u32x4 x0 = in[threadIdx.x], x1 = in[threadIdx.x + 512], t0 = in[threadIdx.x + 1024], t1 = in[threadIdx.x + 1536];
+    u32x4 t2 = in[threadIdx.x + 2048], t3 = in[threadIdx.x + 2560];
+    unsigned ldr = (threadIdx.x & 63) * 16;
+    unsigned sldw = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 2048 + 0x8000);
+    unsigned voff = threadIdx.x * 16;
+    u32x4 srd;
+    const unsigned long long b = (unsigned long long)in;
+    srd[0] = (unsigned)b; srd[1] = (unsigned)(b >> 32) & 0xffff; srd[2] = 65536; srd[3] = 0x00020000;
+    srd[0] = __builtin_amdgcn_readfirstlane(srd[0]); srd[1] = __builtin_amdgcn_readfirstlane(srd[1]);
+    unsigned long long ta, tb;
+    asm volatile("s_memtime %[ta]\n\ts_waitcnt lgkmcnt(0)\n\t"
+                 ".Lloop%=:\n\t" PROBE_BODY_DMA
+                 "s_sub_u32 %[n], %[n], 1\n\t"
+                 "s_cmp_lg_u32 %[n], 0\n\t"
+                 "s_cbranch_scc1 .Lloop%=\n\t"
+                 "s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_memtime %[tb]\n\ts_waitcnt lgkmcnt(0)\n\t"
+                 : [ta] "=&s"(ta), [tb] "=&s"(tb), [n] "+s"(iters), [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2),
+                   [t3] "+v"(t3), [ldr] "+v"(ldr), [sldw] "+s"(sldw)
+                 : [x0] "v"(x0), [x1] "v"(x1), [voff] "v"(voff), [srd] "s"(srd)
+                 : "memory", "scc", "m0", ACLOB);
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 8 + threadIdx.x / 64] = tb - ta;
+}
+
 PROBE_KERNEL(0)
 PROBE_KERNEL(1)
 PROBE_KERNEL(2)
@@ -109,11 +138,11 @@ int main() {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     typedef void (*kern_t)(const u32x4*, unsigned long long*, int);
-    kern_t ks[] = {probe0, probe1, probe2, probe3, probe4, probe5, probe6};
+    kern_t ks[] = {probe0, probe1, probe2, probe3, probe4, probe5, probe6, probe_dma};
     const char* names[] = {"0 bare MFMA", "1 +rotating operands", "2 +s_waitcnt", "3 +ds_read_b128", "4 +s_barrier/chunk",
-                           "5 +Q ds_write", "6 +Q buffer_load"};
+                           "5 +Q ds_write", "6 +Q buffer_load", "6d Q staged by LDS-DMA"};
     for (int rep = 0; rep < 2; ++rep)
-        for (int k = 0; k < 7; ++k) {
+        for (int k = 0; k < 8; ++k) {
             CK(hipFuncSetAttribute(reinterpret_cast<const void*>(ks[k]), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
             float ms;
             CK(hipEventRecord(e0));
