@@ -1075,6 +1075,7 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                 case 104: return launch_scan_asm<SPACE, 4, 8, true, 104>(a, row_begin, row_end, s, info);
                 case 107: return launch_scan_asm<SPACE, 4, 8, true, 107>(a, row_begin, row_end, s, info);
                 case 108: return launch_scan_asm<SPACE, 4, 8, true, 108>(a, row_begin, row_end, s, info);
+                case 109: return launch_scan_asm<SPACE, 4, 8, true, 109>(a, row_begin, row_end, s, info);
                 default: break;
             }
 #endif

@@ -295,6 +295,10 @@ def gen_admission(space):
         if space == "l2":
             s.lds(f"ds_read_b32 {sq(n)}, %[thra] offset:{1024 + n * 64}", ("sq", n))
 
+    if "noadm" in DBG:   # timing diagnostic: no admission test at all (labels only: the hit stubs refer to them)
+        for n in range(16):
+            a(f".Lback{n}_%=:")
+        return s.lines
     fetch(0)
     for n in range(16):
         if n + 1 < 16:
@@ -607,7 +611,7 @@ CONFIGS = [(sp, nw, r, True, 4, False, 2, False) for sp in SPACES for nw in (4, 
     (sp, 8, r, True, 4, False, 2, True) for sp in SPACES for r in (2, 4)]
 # timing diagnostics (cosine, NW=8, R=4, nt): QD slot carries the knob: 101 = nolds, 102 = nox, 103 = both
 DIAG = {101: {"nolds"}, 102: {"nox"}, 103: {"nolds", "nox"}, 104: {"nolds", "nox", "nobar"},
-        107: {"nohit"}, 108: {"stamp"}}
+        107: {"nohit"}, 108: {"stamp"}, 109: {"noadm"}}
 
 
 def inc_name(space, nw, r, nt, qd, prio, mt, dma):
