@@ -443,7 +443,10 @@ __global__ void range_resolve_kernel(uint32_t* overflow, const uint32_t* cnt, co
 bool use_filter(const mlvdb_index* h, int64_t nq) {
     if (h->strategy == MLVDB_STRATEGY_EXACT || !filter_supported(h->ld)) return false;
     if (h->strategy == MLVDB_STRATEGY_FILTER) return true;
-    return nq >= 12 && h->total >= 32768;
+    if (nq >= 12 || (nq >= 8 && h->Xb != nullptr)) return h->total >= 32768;
+    // small batches: the narrow filter kernel streams the bf16 shadow, half the bytes of the exact fp32 scan; below
+    // ~125k rows of 768 columns the exact scan's two launches win (profiles/r01/small_batch_ab_crossover.txt)
+    return h->Xb != nullptr && h->total * (int64_t)h->ld >= (int64_t)96 << 20;
 }
 
 int check_handle(mlvdb_index* h) {
@@ -822,8 +825,7 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
     HIP_TRY(h, h->qerr.ensure((size_t)nq * sizeof(float)));
     HIP_TRY(h, launch_query_prep(h->io_q.as<float>(), (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
                                  h->qaux.as<double>(), h->qerr.as<float>(), s));
-    const bool filt = h->strategy != MLVDB_STRATEGY_EXACT && filter_supported(h->ld) &&
-                      (h->strategy == MLVDB_STRATEGY_FILTER || (nq >= 12 && h->total >= 32768));
+    const bool filt = use_filter(h, nq);
     h->stats.strategy_used = filt ? MLVDB_STRATEGY_FILTER : MLVDB_STRATEGY_EXACT;
     for (int64_t q0 = 0; q0 < nq; q0 += kFilterQueries) {
         const int32_t n = (int32_t)std::min<int64_t>(kFilterQueries, nq - q0);

@@ -152,8 +152,8 @@ __global__ __launch_bounds__(256) void filter_range_thr_kernel(const FilterArgs 
 // Tile finished: bounds, admission test, rare appends.  acc[m][n] = bf16 dot products of this
 // lane's rows (16 m + 4 g + i, i = register component) with query 16 n + c16; rnv[m] = |x| of the rows;
 // row0 = first of this lane's rows; dump = this lane's column of a [4*kMT][64] LDS scratch per wave.
-template <int SPACE, int kMT, bool DENSE>
-__device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (&acc)[kMT][16], const float4 (&rnv)[kMT],
+template <int SPACE, int kMT, bool DENSE, int NQT = 16>
+__device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (&acc)[kMT][NQT], const float4 (&rnv)[kMT],
                                               const int32_t row0, const int32_t base_row,
                                               const float* thr_l, const float* sq_l, const float* ke_l, float* dump,
                                               const int c16) {
@@ -186,7 +186,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
         // seeding pass: every (query,row) bound of these tiles goes straight into the candidate
         // lists, slot = row - first row of the pass (the caller sets cnt and runs the update kernel)
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
+        for (int n = 0; n < NQT; ++n) {
             const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
             const float ke = ke_l[16 * n + c16];
             CandEntry* dst = a.cand + (int64_t)(16 * n + c16) * kCandCap + (row0 - base_row);
@@ -205,9 +205,9 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
     // pass 1: quick reject per query tile on the maximum bound (NaN bounds of tombstoned rows are
     // ignored by v_max); the per-row mask and one slot reservation (atomic) per lane only where it
     // is needed.  The atomics' results are not touched before pass 2: all of them are in flight.
-    uint32_t packed[16];  // bits 0..11 hit mask, bits 12.. first reserved slot (clamped)
+    uint32_t packed[NQT];  // bits 0..11 hit mask, bits 12.. first reserved slot (clamped)
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
+    for (int n = 0; n < NQT; ++n) {
         __builtin_amdgcn_sched_barrier(0);  // keep only one query tile's scores live at a time
         const float thr = thr_l[16 * n + c16];
         const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
@@ -229,7 +229,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
     }
     // pass 2 (rare): write the admitted (bound, row) pairs into the reserved slots
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
+    for (int n = 0; n < NQT; ++n) {
         if (__ballot((packed[n] & 0xfffu) != 0)) {
             const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
             const float ke = ke_l[16 * n + c16];
@@ -438,6 +438,108 @@ __global__ __launch_bounds__(256, 2) void filter_scan_kernel(const FilterArgs a,
             }
         }
         epilogue(ti);
+    }
+}
+
+// Narrow scan for batches of <= 16*NQT queries: the whole query image of those queries stays in LDS
+// for the life of the (persistent) workgroup, so the tile loop has no staging and no barrier; the
+// kernel is a pure stream of the bf16 shadow (1 KiB burst per wave load = one MFMA A fragment) and is
+// HBM-bound at HALF the bytes of the exact fp32 scan.  Same bounds, admission test, candidate lists
+// and rescoring as the 256-query kernels, so the ids are the exact ones here too.
+// One workgroup = NW waves = one 32*NW-row tile; wave w owns panels 2w, 2w+1 (NW = 8; 4 for the seeding pass).
+template <int SPACE, int NQT, bool DENSE, int R, int NW>
+__global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const FilterArgs a, const int64_t tile_begin,
+                                                                     const int64_t tile_end) {
+    constexpr int kMT = 2;  // panels per wave; R = k-steps in flight per wave, NW = waves
+    constexpr int kFilterTileRows = NW * 16 * kMT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ld = a.ld;
+    const int nsteps = ld / 32;  // a multiple of R (ld is a multiple of 64; the launcher picks R = 4 or 2)
+    uint4* qlds = reinterpret_cast<uint4*>(smem);  // [nsteps][NQT][64]
+    float* thr_l = reinterpret_cast<float*>(smem + (size_t)nsteps * NQT * 1024);  // [256]
+    float* sq_l = thr_l + kFilterQueries;
+    float* ke_l = sq_l + kFilterQueries;
+    float* hit_l = ke_l + kFilterQueries;  // [NW waves][4*kMT][64]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4;
+    const int c16 = lane & 15;
+    const int64_t ntiles = tile_end - tile_begin;
+    const int64_t my_tiles = ntiles > blockIdx.x ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    if (my_tiles == 0) return;
+    if (threadIdx.x < kFilterQueries) {
+        thr_l[threadIdx.x] = a.thr[threadIdx.x];
+        sq_l[threadIdx.x] = a.qscale[threadIdx.x];
+        ke_l[threadIdx.x] = a.ke[threadIdx.x];
+    }
+    // query image (filter_prep_kernel's [kc][n][ks][lane] order) -> LDS [2kc+ks][n < NQT][lane]
+    {
+        const uint4* qimg = reinterpret_cast<const uint4*>(a.qimg);
+        for (int v = threadIdx.x; v < nsteps * NQT * 64; v += NW * 64) {
+            const int l = v & 63, n = (v >> 6) % NQT, st = (v >> 6) / NQT;
+            qlds[v] = qimg[(((st >> 1) * 16 + n) * 2 + (st & 1)) * 64 + l];
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[kMT][NQT];
+    float4 xr[R][kMT];
+    float4 rnv[kMT];
+    const uint32_t panel_bytes = (uint32_t)ld * 32;  // 16 rows of bf16
+    const uint32_t wave_bytes = kMT * panel_bytes;
+    const uint64_t tile_stride_bytes = (uint64_t)gridDim.x * (NW * wave_bytes);
+    const char* pre_base = reinterpret_cast<const char*>(a.Xb) + (uint64_t)(tile_begin + blockIdx.x) * (NW * wave_bytes) +
+                           (uint64_t)wave * wave_bytes;
+    uint32_t pre_soff = 0;
+    int64_t pre_tiles_left = my_tiles - 1;
+    auto load_x = [&](float4(&xb)[kMT]) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(pre_base, wave_bytes);
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) xb[m] = buf_load_f4_nt(r, lane * 16, pre_soff + m * panel_bytes);
+        pre_soff += 1024;  // saturates at the last k-step of the last tile (every load stays unconditional)
+        if (pre_soff == panel_bytes) {
+            if (pre_tiles_left > 0) {
+                --pre_tiles_left;
+                pre_soff = 0;
+                pre_base += tile_stride_bytes;
+            } else {
+                pre_soff -= 1024;
+            }
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < R; ++b) load_x(xr[b]);
+
+    for (int64_t ti = 0; ti < my_tiles; ++ti) {
+        const int64_t tile = tile_begin + blockIdx.x + ti * gridDim.x;
+        const __amdgpu_buffer_rsrc_t rn_rsrc = make_rsrc(a.rn + tile * kFilterTileRows + wave * (16 * kMT), 16 * kMT * 4);
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) rnv[m] = buf_load_f4(rn_rsrc, g * 16, m * 64);
+#pragma unroll
+        for (int m = 0; m < kMT; ++m)
+#pragma unroll
+            for (int n = 0; n < NQT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int st = 0; st < nsteps; st += R) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                bf16x8 xa[kMT];
+#pragma unroll
+                for (int m = 0; m < kMT; ++m) xa[m] = __builtin_bit_cast(bf16x8, xr[j][m]);
+                load_x(xr[j]);
+                const uint4* qb = qlds + (size_t)(st + j) * (NQT * 64) + lane;
+#pragma unroll
+                for (int n = 0; n < NQT; ++n) {
+                    const bf16x8 qf = __builtin_bit_cast(bf16x8, qb[n * 64]);
+#pragma unroll
+                    for (int m = 0; m < kMT; ++m)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[m], qf, acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+        scan_epilogue<SPACE, kMT, DENSE, NQT>(a, acc, rnv, (int32_t)(tile * kFilterTileRows) + wave * (16 * kMT) + g * 4,
+                                              (int32_t)(tile_begin * kFilterTileRows), thr_l, sq_l, ke_l,
+                                              hit_l + wave * (4 * kMT * 64) + lane, c16);
     }
 }
 
@@ -1020,6 +1122,61 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
     return hipGetLastError();
 }
 
+// narrow kernel: batches of <= 64 queries whose image fits in LDS beside the scratch
+constexpr int kNarrowMaxQueries = 64;
+constexpr size_t kNarrowLdsMax = 152 * 1024;
+static int narrow_nqt(int nq) { return nq <= 16 ? 1 : (nq <= 32 ? 2 : 4); }
+static size_t narrow_lds(int32_t ld, int nqt, int nw) {
+    return (size_t)(ld / 32) * nqt * 1024 + 3 * kFilterQueries * sizeof(float) + (size_t)nw * 4 * 2 * 64 * sizeof(float);
+}
+bool filter_narrow_ok(const FilterArgs& a) {
+    if (!a.Xb || a.nq > kNarrowMaxQueries) return false;
+    if (env_int("MLVDB_SCAN_NARROW", 1) == 0) return false;
+    return narrow_lds(a.ld, narrow_nqt(a.nq), 8) <= kNarrowLdsMax;
+}
+template <int SPACE, int NQT, bool DENSE, int R, int NW>
+static hipError_t launch_scan_narrow_n(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
+    constexpr int tile_rows = NW * 32;
+    const int64_t tile_begin = row_begin / tile_rows;
+    const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
+    if (tile_end <= tile_begin) return hipSuccess;
+    const size_t lds = narrow_lds(a.ld, NQT, NW);
+    const int64_t ntiles = tile_end - tile_begin;
+    const int per_cu = (int)std::min<size_t>(32 / NW, (160 * 1024) / lds);  // workgroups resident per CU
+    const int max_grid = 256 * env_int("MLVDB_NARROW_WGS", per_cu);
+    const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
+    auto kern = filter_scan_narrow_kernel<SPACE, NQT, DENSE, R, NW>;
+    static bool configured = false;  // per instantiation
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNarrowLdsMax);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end);
+    return hipGetLastError();
+}
+template <int SPACE, int NQT, bool DENSE>
+static hipError_t launch_scan_narrow_q(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
+    const bool r4 = (a.ld / 32) % 4 == 0;
+    if constexpr (DENSE) {  // the seeding pass is a few tiles: one geometry
+        return r4 ? launch_scan_narrow_n<SPACE, NQT, true, 4, 4>(a, row_begin, row_end, s)
+                  : launch_scan_narrow_n<SPACE, NQT, true, 2, 4>(a, row_begin, row_end, s);
+    } else {
+        // 8 waves per workgroup: measured 2-6 % faster than 4 on the 10M x 768 corpus (fewer copies of the image)
+        return r4 ? launch_scan_narrow_n<SPACE, NQT, false, 4, 8>(a, row_begin, row_end, s)
+                  : launch_scan_narrow_n<SPACE, NQT, false, 2, 8>(a, row_begin, row_end, s);
+    }
+}
+template <int SPACE, bool DENSE>
+static hipError_t launch_scan_narrow(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
+    switch (narrow_nqt(a.nq)) {
+        case 1: return launch_scan_narrow_q<SPACE, 1, DENSE>(a, row_begin, row_end, s);
+        case 2: return launch_scan_narrow_q<SPACE, 2, DENSE>(a, row_begin, row_end, s);
+        default: return launch_scan_narrow_q<SPACE, 4, DENSE>(a, row_begin, row_end, s);
+    }
+}
+
 template <int SPACE, int R, int NW, bool NT = false, int QD = 4, bool PRIO = false, int MT = 2, bool DMA = false>
 static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info) {
     constexpr int tile_rows = NW * 16 * MT;
@@ -1051,6 +1208,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
 template <int SPACE>
 static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info) {
     const int nkc = a.ld / kFilterChunkK;
+    if (filter_narrow_ok(a)) return launch_scan_narrow<SPACE, false>(a, row_begin, row_end, s);  // appends to the lists itself
     if (a.Xb && env_int("MLVDB_SCAN_ASM", 1)) {
         // hand-written body (tools/gen_scan_asm.py).  Default: one 8-wave workgroup per CU (256-row tiles:
         // the query image is staged once per CU, by LDS-DMA), non-temporal X loads, ring of 4 k-steps -- measured
@@ -1105,6 +1263,13 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
     const int64_t rows = (row_end + kSeedTileRows - 1) / kSeedTileRows * kSeedTileRows;
     hipError_t e;
     const bool xb = a.Xb != nullptr;
+    if (filter_narrow_ok(a)) {
+        e = a.space == kSpaceL2       ? launch_scan_narrow<kSpaceL2, true>(a, 0, rows, s)
+            : a.space == kSpaceCosine ? launch_scan_narrow<kSpaceCosine, true>(a, 0, rows, s)
+                                      : launch_scan_narrow<kSpaceIp, true>(a, 0, rows, s);
+        if (e != hipSuccess) return e;
+        return launch_update(a, k, (int32_t)rows, s);
+    }
     switch (a.space) {
         case kSpaceL2:
             e = xb ? launch_scan_one<kSpaceL2, true, true>(a, 0, rows, s)

@@ -262,6 +262,27 @@ SCAN_VARIANTS = [
     {"MLVDB_SCAN_ASM": "0"},                         # the hipcc-scheduled kernel (also serves corpora without shadow)
 ]
 
+NARROW_CASES = [
+    # space, d, nq, n  (batches of <= 64 queries: the narrow kernel, query image resident in LDS)
+    ("cosine", 768, 1, 70_003), ("cosine", 768, 16, 70_003), ("cosine", 768, 17, 70_003), ("l2", 768, 32, 40_001),
+    ("ip", 128, 5, 150_001), ("l2", 192, 9, 150_001), ("cosine", 64, 31, 150_001), ("ip", 1536, 3, 33_001),
+    ("l2", 1536, 20, 33_001), ("cosine", 320, 2, 9_000), ("cosine", 768, 33, 70_003), ("l2", 128, 64, 150_001),
+    ("ip", 1536, 40, 33_001), ("l2", 1088, 64, 20_000), ("ip", 192, 50, 9_000),
+]
+
+
+@pytest.mark.parametrize("narrow", ["1", "0"])
+@pytest.mark.parametrize("space,d,nq,n", NARROW_CASES)
+def test_small_batches_through_the_filter_agree_with_oracle(space, d, nq, n, narrow, monkeypatch):
+    """Batches of 1..64 queries forced through the filter: the narrow kernel (MLVDB_SCAN_NARROW=1, default) and the
+    same batch padded into a 256-query pass (=0) return the oracle's ids; ragged tiles, tombstones, duplicates."""
+    monkeypatch.setenv("MLVDB_SCAN_NARROW", narrow)
+    rows, qs = make_case(500 + d + nq, n, d, nq, dup=True)
+    deleted = deleted_mask(11, n, 0.05)
+    got, stats = run_hip(rows, qs, 10, space, "filter", deleted, append_chunks=3)
+    assert stats["strategy_used"] == 2 and stats["fallback_queries"] == 0
+    assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"narrow={narrow}/{space}/d{d}/nq{nq}")
+
 
 @pytest.mark.parametrize("variant", SCAN_VARIANTS, ids=lambda v: ",".join(f"{k[11:]}={x}" for k, x in v.items()))
 @pytest.mark.parametrize("space,d", [("cosine", 128), ("l2", 192), ("ip", 64), ("cosine", 768), ("l2", 1536)])
