@@ -29,6 +29,8 @@ class ScanEngine(Protocol):
 
     def compact(self) -> np.ndarray: ...
 
+    def get_rows(self, first: int, n: int) -> np.ndarray: ...
+
     def search(self, queries: np.ndarray, k: int, mask: np.ndarray | None = None
                ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]: ...
 

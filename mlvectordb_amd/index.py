@@ -17,10 +17,13 @@ dimensionality returns ``[]`` exactly as the reference does (hnswlib's RuntimeEr
 swallowed by index.py:110-119); rows of the wrong dimensionality raise ``RuntimeError``.
 
 Additive (no reference counterpart): ``search_many`` (one scan for a whole query batch),
-``range_search`` / ``range_search_many``, and ``metric="euclidean"`` as sqrt(l2).
+``range_search`` / ``range_search_many``, ``metric="euclidean"`` as sqrt(l2), ``compact`` and
+``save_index`` / ``load_index`` (named in the reference's README.md:240-241 only).
 """
 from __future__ import annotations
 
+import json
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, Iterable, List, Mapping, Optional, Sequence
 from uuid import UUID
@@ -284,6 +287,83 @@ class Index:
     def namespace_counts(self, namespace: str):
         ns = self._ns.get(namespace)
         return (0, 0) if ns is None else (ns.total, ns.deleted)
+
+    # ------------------------------------------------------------------ additive: persistence
+    # Directory layout ("mlvdb-index-v1"): index.json + per namespace i
+    #   ns<i>.rows.f32     raw row-major float32 [total, dim], every label incl. tombstoned ones (labels stay stable)
+    #   ns<i>.ids.u8       [total, 16] UUID bytes, all-zero for tombstoned labels
+    # The fp32 rows are the ones the device holds (bit-exact round trip); norms, bf16 shadow and panel layout are
+    # rebuilt by the ingest kernels at load.  No reference behaviour (README.md:240-241 names the two methods only).
+    _FORMAT = "mlvdb-index-v1"
+    _CHUNK_BYTES = 256 << 20
+
+    def save_index(self, path: str) -> bool:
+        """Write every namespace to directory ``path`` (created if missing); streams the rows off the device in
+        chunks, so host memory stays bounded."""
+        os.makedirs(path, exist_ok=True)
+        meta = {"format": self._FORMAT, "space": self._space, "rebuild_threshold": self._rebuild_threshold, "namespaces": []}
+        for i, (name, ns) in enumerate(self._ns.items()):
+            chunk = max(1, self._CHUNK_BYTES // (4 * ns.dim))
+            with open(os.path.join(path, f"ns{i}.rows.f32"), "wb") as f:
+                for first in range(0, ns.total, chunk):
+                    f.write(ns.engine.get_rows(first, min(chunk, ns.total - first)).tobytes())
+            ids = np.zeros((ns.total, 16), dtype=np.uint8)
+            for label, uid in ns.label_to_uuid.items():
+                ids[label] = np.frombuffer(uid.bytes, dtype=np.uint8)
+            ids.tofile(os.path.join(path, f"ns{i}.ids.u8"))
+            live = np.zeros(ns.total, dtype=bool)
+            live[list(ns.label_to_uuid.keys())] = True
+            np.nonzero(~live)[0].astype(np.int64).tofile(os.path.join(path, f"ns{i}.deleted.i64"))
+            meta["namespaces"].append({"name": name, "dim": ns.dim, "space": ns.engine.space, "total": ns.total,
+                                       "deleted": ns.deleted, "rebuild_required": ns.rebuild_required})
+        tmp = os.path.join(path, "index.json.tmp")
+        with open(tmp, "w") as f:
+            json.dump(meta, f, indent=1)
+        os.replace(tmp, os.path.join(path, "index.json"))  # the manifest appears last and atomically
+        return True
+
+    def load_index(self, path: str) -> bool:
+        """Replace the contents of this index by the directory written by ``save_index``.  Returns False (index
+        untouched) when ``path`` holds no manifest; raises ``RuntimeError`` on a manifest it cannot honour."""
+        manifest = os.path.join(path, "index.json")
+        if not os.path.isfile(manifest):
+            return False
+        with open(manifest) as f:
+            meta = json.load(f)
+        if meta.get("format") != self._FORMAT:
+            raise RuntimeError(f"unknown index format {meta.get('format')!r}")
+        for i, m in enumerate(meta["namespaces"]):  # validate sizes before touching anything
+            total, dim = int(m["total"]), int(m["dim"])
+            if os.path.getsize(os.path.join(path, f"ns{i}.rows.f32")) != total * dim * 4 or \
+                    os.path.getsize(os.path.join(path, f"ns{i}.ids.u8")) != total * 16:
+                raise RuntimeError(f"namespace {m['name']!r}: file sizes do not match the manifest")
+        self.close()
+        self._space = meta["space"]
+        self._rebuild_threshold = float(meta["rebuild_threshold"])
+        for i, m in enumerate(meta["namespaces"]):
+            total, dim = int(m["total"]), int(m["dim"])
+            ns = self._get_or_create(m["name"], dim, m["space"])
+            if total:
+                rows = np.memmap(os.path.join(path, f"ns{i}.rows.f32"), dtype=np.float32, mode="r", shape=(total, dim))
+                chunk = max(1, self._CHUNK_BYTES // (4 * dim))
+                for first in range(0, total, chunk):
+                    if ns.engine.append(np.ascontiguousarray(rows[first:first + chunk])) != first:
+                        raise RuntimeError("engine label base does not match the file offset")
+                del rows
+            deleted = np.fromfile(os.path.join(path, f"ns{i}.deleted.i64"), dtype=np.int64)
+            if deleted.size:
+                ns.engine.tombstone(deleted)
+            ids = np.fromfile(os.path.join(path, f"ns{i}.ids.u8"), dtype=np.uint8).reshape(total, 16)
+            dead = set(deleted.tolist())
+            for label in range(total):
+                if label not in dead:
+                    uid = UUID(bytes=ids[label].tobytes())
+                    ns.label_to_uuid[label] = uid
+                    ns.uuid_to_label[uid] = label
+            ns.total = total
+            ns.deleted = int(m["deleted"])
+            ns.rebuild_required = bool(m["rebuild_required"])
+        return True
 
     def close(self) -> None:
         for ns in self._ns.values():

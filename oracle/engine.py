@@ -41,6 +41,11 @@ class OracleScanEngine:
     def counts(self):
         return int(self._rows.shape[0]), int(self._deleted.sum())
 
+    def get_rows(self, first: int, n: int) -> np.ndarray:
+        if first < 0 or n < 0 or first + n > self._rows.shape[0]:
+            raise RuntimeError("row range out of bounds")
+        return self._rows[first:first + n].copy()
+
     def compact(self) -> np.ndarray:
         old = np.nonzero(~self._deleted)[0].astype(np.int64)
         self._rows = np.ascontiguousarray(self._rows[old])

@@ -215,3 +215,56 @@ def test_metadata_filtered_search_is_exact_among_the_matching_vectors():
     qp.delete([red[0]["id"]])
     again = qp.find_similar_where(q, 5, where=lambda m: m["colour"] == "red")
     assert red[0]["id"] not in [h["id"] for h in again] and len(again) == 5
+
+
+# ---- persistence (README.md:240-241 names save_index/load_index only: parity unpinned)
+def _results(i, qs, ns, metric, k=5):
+    return [[(r.vector_id, r.score) for r in hits] for hits in i.search_many(qs, k, ns, metric)]
+
+
+def test_save_index_load_index_round_trip(tmp_path, monkeypatch):
+    monkeypatch.setattr(Index, "_CHUNK_BYTES", 8 * 4 * 7)  # 7 rows per chunk: the streamed path
+    i = idx("cosine", rebuild_threshold=0.3)
+    a, b = vecs(40, seed=1), vecs(25, d=5, seed=2)
+    i.add(a, "a")
+    i.add(b, "b")
+    i.remove([a[3].id, a[17].id, a[39].id], "a")
+    i.remove([v.id for v in b[:10]], "b")  # 0.4 >= 0.3: flag raised
+    qa = np.random.default_rng(5).standard_normal((4, 8)).astype(np.float32)
+    qb = np.random.default_rng(6).standard_normal((3, 5)).astype(np.float32)
+    want_a, want_b = _results(i, qa, "a", "cosine"), _results(i, qb, "b", "cosine")
+    assert i.save_index(str(tmp_path / "snap")) is True
+
+    j = idx("l2")  # space, threshold and contents all come from the snapshot
+    j.add(vecs(3, seed=9), "stale")
+    assert j.load_index(str(tmp_path / "snap")) is True
+    assert j._space == "cosine" and j._rebuild_threshold == 0.3
+    assert j.search(VectorDTO(values=[0.0] * 8, metadata={}), 1, "stale", "cosine") == []
+    assert _results(j, qa, "a", "cosine") == want_a and _results(j, qb, "b", "cosine") == want_b
+    assert j.namespace_counts("a") == (40, 3) and j.namespace_counts("b") == (25, 10)
+    assert j.is_rebuild_required("b") and not j.is_rebuild_required("a")
+    # the loaded index keeps working: labels continue, removed ids stay unknown, compaction still works
+    more = vecs(5, seed=3)
+    j.add(more, "a")
+    assert j.namespace_counts("a") == (45, 3)
+    hit = j.search(VectorDTO(values=more[2].values, metadata={}), 1, "a", "cosine")[0]
+    assert hit.vector_id == more[2].id
+    j.remove([a[3].id], "a")  # already gone: no state change (index.py:76-78)
+    assert j.namespace_counts("a") == (45, 3)
+    assert j.compact("b") and j.namespace_counts("b") == (15, 0)
+    assert _results(j, qb, "b", "cosine") == want_b
+
+
+def test_load_index_missing_or_inconsistent_snapshot(tmp_path):
+    i = idx("l2")
+    i.add(vecs(6), "a")
+    assert i.load_index(str(tmp_path / "absent")) is False
+    assert i.namespace_counts("a") == (6, 0)  # untouched
+    i.save_index(str(tmp_path / "snap"))
+    with open(tmp_path / "snap" / "ns0.rows.f32", "ab") as f:
+        f.write(b"\0" * 4)
+    with pytest.raises(RuntimeError):
+        i.load_index(str(tmp_path / "snap"))
+    assert i.namespace_counts("a") == (6, 0)  # validation happens before anything is dropped
+    empty = idx("ip")
+    assert empty.save_index(str(tmp_path / "empty")) and idx("l2").load_index(str(tmp_path / "empty"))
