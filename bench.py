@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the config-2 (1M x 768, batch 1) side measurement")
+    ap.add_argument("--tombstones", type=float, default=0.0,
+                    help="secondary run (SURVEY 8d): tombstone this fraction of every shard's rows, default_rng(99), before searching")
     ap.add_argument("--gen-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (gloo for single-device rehearsals)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -97,6 +99,13 @@ def main() -> None:
         eng.append(rows)
         if rank == 0 and off == 0:
             sample_rows = rows.copy()  # first 250k rows, reused for the parity gate
+    if args.tombstones > 0.0:
+        dead = np.nonzero(np.random.default_rng([99, rank]).random(n_local) < args.tombstones)[0].astype(np.int64)
+        eng.tombstone(dead)
+        if sample_rows is not None:
+            sample_dead = np.zeros(sample_rows.shape[0], dtype=bool)
+            sample_dead[dead[dead < sample_rows.shape[0]]] = True
+        log(f"tombstoned {dead.size} of {n_local} rows")
     load_s = time.perf_counter() - t0
     log(f"shard rows [{row0}, {row0 + n_local}) resident after {load_s:.1f} s ({threads} generator threads)")
 
@@ -182,9 +191,12 @@ def main() -> None:
 
         small = HipScanEngine(d, args.space, device=local_rank, strategy="filter" if d % 64 == 0 else "exact")
         small.append(sample_rows)
+        if args.tombstones > 0.0:
+            small.tombstone(np.nonzero(sample_dead)[0].astype(np.int64))
         sl, sd, _ = small.search(q_host[:64], k)
         small.close()
-        ol, od, _ = exact_scan.knn(q_host[:64], sample_rows, k, args.space)
+        ol, od, _ = exact_scan.knn(q_host[:64], sample_rows, k, args.space,
+                                   deleted=sample_dead if args.tombstones > 0.0 else None)
         verify["oracle_sample"] = f"{sample_rows.shape[0]} rows x 64 queries"
         verify["oracle_ids_equal"] = bool(np.array_equal(sl, ol))
         verify["oracle_max_abs_err"] = float(np.abs(sd - od).max())
@@ -286,6 +298,7 @@ def main() -> None:
                                f"rows ({n_local}/GPU), {args.space} kNN k={k}, batch={batch}, exact ids "
                                f"(bf16-MFMA bound filter + fp64 rescoring)",
                    "rows_per_gpu": n_local, "dim": d, "k": k, "batch": batch, "space": args.space,
+                   "tombstoned_fraction": args.tombstones,
                    "strategy": {1: "exact", 2: "filter"}.get(stats0["strategy_used"], "?"),
                    "sharding": f"row-wise over {world} ranks, host merge of per-shard top-k"},
         "whole_corpus_qps": round(batch * args.steps / elapsed, 1),

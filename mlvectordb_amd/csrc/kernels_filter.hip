@@ -1144,7 +1144,10 @@ static hipError_t launch_scan_narrow_n(const FilterArgs& a, int64_t row_begin, i
     const int64_t ntiles = tile_end - tile_begin;
     const int per_cu = (int)std::min<size_t>(32 / NW, (160 * 1024) / lds);  // workgroups resident per CU
     const int max_grid = 256 * env_int("MLVDB_NARROW_WGS", per_cu);
-    const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
+    // equal tile counts per workgroup: the kernel is a pure stream, a last round with a few busy workgroups is all tail
+    const int64_t rounds = (ntiles + max_grid - 1) / max_grid;
+    const int grid = env_int("MLVDB_NARROW_BALANCE", 1) ? (int)((ntiles + rounds - 1) / rounds)
+                                                        : (int)(ntiles < max_grid ? ntiles : max_grid);
     auto kern = filter_scan_narrow_kernel<SPACE, NQT, DENSE, R, NW>;
     static bool configured = false;  // per instantiation
     if (!configured) {
