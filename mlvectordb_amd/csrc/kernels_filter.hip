@@ -607,7 +607,7 @@ typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 #include "scan_asm_consts.inc"
 static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagree");
 
-template <int SPACE, int R, int NW, bool NT, int QD, bool PRIO, int MT, bool DMA>
+template <int SPACE, int R, int NW, bool NT, int QD, bool PRIO, int MT, bool DMA, bool STAG>
 __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kernel(const FilterArgs a, const int64_t tile_begin,
                                                                                   const int64_t tile_end) {
     constexpr int kThreads = NW * 64;
@@ -670,6 +670,16 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     // the later-dispatched half of the workgroup's waves (readfirstlane: an "s" operand must live in an SGPR)
     const uint32_t wtype = __builtin_amdgcn_readfirstlane(wave >= NW / 2 ? 1u : 0u);
     (void)wtype;
+    // stagger (STAG): the later half runs nkc/2 chunk periods behind, its k origin rotated by half a row
+    // (tools/gen_scan_asm.py, generate); needs the R ring steps after the rotated origin inside the panel
+    const uint32_t hc = STAG && nkc % 2 == 0 && nkc >= R ? (uint32_t)nkc / 2 : 0u;
+    const uint32_t xrot = __builtin_amdgcn_readfirstlane(wtype && hc ? (uint32_t)nkc * 1024u : 0u);
+    const uint32_t pbrot = __builtin_amdgcn_readfirstlane(pb + xrot);
+    const uint32_t pb2 = 2 * pb;
+    (void)hc;
+    (void)xrot;
+    (void)pbrot;
+    (void)pb2;
     // this wave's append buffer in global memory: u[cap], row[cap], q[cap]
     constexpr int kCapW = kWgCap / NW;
     const char* wgb = reinterpret_cast<const char*>(a.wgbuf + ((size_t)blockIdx.x * NW + wave) * kCapW);
@@ -1180,7 +1190,7 @@ static hipError_t launch_scan_narrow(const FilterArgs& a, int64_t row_begin, int
     }
 }
 
-template <int SPACE, int R, int NW, bool NT = false, int QD = 4, bool PRIO = false, int MT = 2, bool DMA = false>
+template <int SPACE, int R, int NW, bool NT = false, int QD = 4, bool PRIO = false, int MT = 2, bool DMA = false, bool STAG = false>
 static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info) {
     constexpr int tile_rows = NW * 16 * MT;
     const int64_t tile_begin = row_begin / tile_rows;
@@ -1191,7 +1201,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     const int64_t ntiles = tile_end - tile_begin;
     const int max_grid = 256 * ((16 / MT) / NW);  // two waves per SIMD on every CU (<= kScanMaxGrid)  // two waves per SIMD on every CU
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
-    auto kern = filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT, DMA>;
+    auto kern = filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT, DMA, STAG>;
     static bool configured = false;  // per instantiation
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1243,6 +1253,8 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
         }
         if (nw == 8) {
             if (env_int("MLVDB_SCAN_DMA", 1)) {  // query image staged by LDS-DMA (default, +2 %) instead of through registers
+                if (nkc % 2 == 0 && env_int("MLVDB_SCAN_STAG", 0))  // later half of the waves half a tile behind
+                    return launch_scan_asm<SPACE, 4, 8, true, 4, false, 2, true, true>(a, row_begin, row_end, s, info);
                 if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8, true, 4, false, 2, true>(a, row_begin, row_end, s, info);
                 return launch_scan_asm<SPACE, 2, 8, true, 4, false, 2, true>(a, row_begin, row_end, s, info);
             }

@@ -260,6 +260,7 @@ SCAN_VARIANTS = [
     {"MLVDB_SCAN_MT": "4"},                          # assembly body, one wave per SIMD, 64 rows per wave
     {"MLVDB_SCAN_NW": "8", "MLVDB_SCAN_NT": "0"},    # (cosine only) temporal X loads
     {"MLVDB_SCAN_ASM": "0"},                         # the hipcc-scheduled kernel (also serves corpora without shadow)
+    {"MLVDB_SCAN_STAG": "1"},                        # later half of the waves half a tile behind (rotated k origin)
 ]
 
 NARROW_CASES = [

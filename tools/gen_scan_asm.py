@@ -47,6 +47,7 @@ MT = 2
 CHUNK_BYTES = 0x8000      # 256 queries x 64 columns x 2 B
 WG_CAP = 16384            # kWgCap: append entries per workgroup (split evenly over its waves)
 SPACES = {"l2": 0, "cosine": 1, "ip": 2}
+STAG = False   # generate(): the later-dispatched half of the waves runs half a tile behind (see generate)
 DBG = set()   # timing diagnostics only (wrong results): 'nolds' drops the B-fragment reads, 'nox' the X refills
 
 
@@ -144,6 +145,8 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
                 if m >= 2:
                     s.emit(f"s_mul_i32 %[st0], %[pb], {m}")
                 so = "0" if m == 0 else ("%[pb]" if m == 1 else "%[st0]")
+                if STAG:
+                    so = "%[xrot]" if m == 0 else "%[pbrot]"
                 off = f" offset:{step * 1024}" if step else ""
                 s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XNEXT}, {so} offen{off}{pol}", ("x", b, m))
             elif last:
@@ -159,6 +162,11 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
         if not last:
             for m in range(MT):
                 s.emit(f"s_add_u32 %[xso{m}], %[xso{m}], 0x400")
+            if STAG:   # a rotated k origin passes the end of the panel in mid-tile
+                s.emit("s_cmp_eq_u32 %[xso0], %[pb]")
+                s.emit("s_cselect_b32 %[xso0], 0, %[xso0]")
+                s.emit("s_cmp_eq_u32 %[xso1], %[pb2]")
+                s.emit("s_cselect_b32 %[xso1], %[pb], %[xso1]")
 
     # Staging plan, fragment index -> action.  Set qb (first halves) is written and re-fetched just
     # before the ring refill that follows fragment 15, set qa (second halves) just before the one
@@ -242,6 +250,20 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
         s.emit("s_memtime s[78:79]")
         s.emit("s_waitcnt lgkmcnt(0)")
         s.emit("s_add_u32 %[sacc0], %[sacc0], s78")
+
+
+def stage_only_chunk(KQ, NW):
+    """A chunk period of a wave that has no tile to work on (stagger: the first half tile of the late waves, the last
+    half tile of the early ones): its share of the next Q chunk (LDS-DMA), the buffer toggles and the barrier."""
+    o = ["v_xor_b32 %[ldr], 0x8000, %[ldr]", "s_xor_b32 %[sldw], %[sldw], 0x8000"]
+    for half in (0, 1):
+        for i in range(KQ):
+            const = i * NW * 2048 + half * 1024
+            o += [f"s_add_u32 m0, %[sldw], 0x{const:x}", f"s_add_u32 %[st0], %[qcur], 0x{const:x}",
+                  "buffer_load_dwordx4 %[qvoff], %[qsrd], %[st0] offen lds"]
+    o += ["s_add_u32 %[qcur], %[qcur], 0x8000", "s_cmp_eq_u32 %[qcur], %[qbytes]", "s_cselect_b32 %[qcur], 0, %[qcur]",
+          "s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
+    return o
 
 
 def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False, dma=False):
@@ -436,10 +458,18 @@ def gen_flush(NW):
             "s_waitcnt vmcnt(0)"]
 
 
-def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False):
-    global MT
+def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False):
+    """stag: both waves of a SIMD reach the admission test (VALU only) together and leave the MFMA pipe idle for it.
+    With the stagger the later-dispatched half of a workgroup's waves (wtype 1) runs half a tile behind: it sits out
+    the first nkc/2 chunk periods (staging only), starts every row tile at column ld/2 (k origin rotated by xrot,
+    wrapping at the end of the panel; the shared Q chunk stream is the same for everybody) and therefore reaches its
+    admission test while its SIMD partner is in mid-tile; the early half sits out nkc/2 periods at the end.
+    hc = 0 (and xrot = 0) turns it off at run time."""
+    global MT, STAG
     MT = mt
+    STAG = stag
     assert R in (2, 4, 6) and 2 <= QD <= 8 and mt in (2, 4)
+    assert not stag or (dma and mt == 2 and R * 1024 <= 4096)
     KQ = 1024 // (NW * 64)
     out = []
     a = out.append
@@ -483,6 +513,8 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False):
                 a(f"s_mul_i32 %[st0], %[pb], {m}")
             if b * 1024 < 4096:
                 so = "0" if m == 0 else ("%[pb]" if m == 1 else "%[st0]")
+                if stag:
+                    so = "%[xrot]" if m == 0 else "%[pbrot]"
                 off = f" offset:{b * 1024}" if b else ""
                 a(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, {so} offen{off}")
             else:
@@ -498,6 +530,19 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False):
             a(f"buffer_load_dwordx4 %[{setname}{i}], %[qvoff], %[qsrd], %[st0] offen")
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")   # counted waits below assume the steady-state issue pattern
     a("s_barrier")
+    if stag:
+        a("s_mov_b32 %[qcur], %[qc1]")   # the Q cursor follows the shared chunk stream from here on, never reset
+        a("s_cmp_eq_u32 %[wtype], 1")
+        a("s_cbranch_scc0 .Lnopre_%=")
+        a("s_cmp_eq_u32 %[hc], 0")
+        a("s_cbranch_scc1 .Lnopre_%=")
+        a("s_mov_b32 %[cnt], %[hc]")
+        a(".Lpre_%=:")
+        out += stage_only_chunk(KQ, NW)
+        a("s_sub_u32 %[cnt], %[cnt], 1")
+        a("s_cmp_lg_u32 %[cnt], 0")
+        a("s_cbranch_scc1 .Lpre_%=")
+        a(".Lnopre_%=:")
     # ---- persistent loop over this workgroup's tiles
     a(".Ltile_%=:")
     a("s_cmp_gt_u32 %[tl], 1")           # next tile's descriptor (the last tile re-reads itself: harmless)
@@ -505,8 +550,9 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False):
     a("s_cselect_b32 %[cnt], %[xshi], 0")
     a("s_add_u32 s84, s80, %[st0]")
     a("s_addc_u32 s85, s81, %[cnt]")
-    a("s_mov_b32 %[qcur], %[qc1]" if dma else "s_mov_b32 %[qcur], %[qcur0]")   # first chunk staged inside this tile's loop
-    a(f"s_movk_i32 %[xso0], 0x{R * 1024:x}")
+    if not stag:
+        a("s_mov_b32 %[qcur], %[qc1]" if dma else "s_mov_b32 %[qcur], %[qcur0]")   # first chunk staged inside this tile's loop
+    a(f"s_add_u32 %[xso0], %[xrot], 0x{R * 1024:x}" if stag else f"s_movk_i32 %[xso0], 0x{R * 1024:x}")
     a("s_add_u32 %[xso1], %[pb], %[xso0]")
     for m in range(2, MT):
         a(f"s_mul_i32 %[xso{m}], %[pb], {m}")
@@ -538,6 +584,18 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False):
     a("s_sub_u32 %[tl], %[tl], 1")
     a("s_cmp_lg_u32 %[tl], 0")
     a("s_cbranch_scc1 .Ltile_%=")
+    if stag:
+        a("s_cmp_eq_u32 %[wtype], 0")
+        a("s_cbranch_scc0 .Lnopost_%=")
+        a("s_cmp_eq_u32 %[hc], 0")
+        a("s_cbranch_scc1 .Lnopost_%=")
+        a("s_mov_b32 %[cnt], %[hc]")
+        a(".Lpost_%=:")
+        out += stage_only_chunk(KQ, NW)
+        a("s_sub_u32 %[cnt], %[cnt], 1")
+        a("s_cmp_lg_u32 %[cnt], 0")
+        a("s_cbranch_scc1 .Lpost_%=")
+        a(".Lnopost_%=:")
     out += gen_flush(NW)
     if "stamp" in DBG:   # q[cap-2] = cycles parked at barriers, q[cap-1] = cycles of the whole kernel body
         a("s_memtime s[78:79]")
@@ -589,11 +647,14 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False):
         ops_in.append('[k1] "s"(k1)')
     if dma:
         ops_in.append('[wave2k] "s"(wave2k)')
+    if stag:
+        ops_in += ['[xrot] "s"(xrot)', '[pbrot] "s"(pbrot)', '[pb2] "s"(pb2)', '[hc] "s"(hc)']
     clobbers = ['"memory"', '"scc"', '"vcc"'] + (['"m0"'] if dma else []) + [f'"s{i}"' for i in range(60, 80)] + [f'"s{i}"' for i in range(80, 94)] + [f'"a{i}"' for i in range(64 * MT)]
 
     text = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.",
             f"// filter scan body: space {space}, NW={NW} waves x {16 * MT} rows, ring R={R} k-steps, B fragments read {QD} ahead"
-            f"{', X loads non-temporal' if nt else ''}{', progress-based wave priority' if prio else ''}{', Q staged by LDS-DMA' if dma else ''}.",
+            f"{', X loads non-temporal' if nt else ''}{', progress-based wave priority' if prio else ''}{', Q staged by LDS-DMA' if dma else ''}"
+            f"{', late waves staggered by half a tile' if stag else ''}.",
             "asm volatile("]
     for ln in out:
         text.append(f'    "{ln}\\n\\t"')
@@ -604,19 +665,20 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False):
 
 
 # (space, NW, R, nt) instantiated by kernels_filter.hip: the production set, and experiments (cosine only)
-CONFIGS = [(sp, nw, r, True, 4, False, 2, False) for sp in SPACES for nw in (4, 8) for r in (2, 4)] + [
-    ("cosine", 4, 4, False, 4, False, 2, False), ("cosine", 8, 4, False, 4, False, 2, False),
-    ("cosine", 8, 4, True, 4, True, 2, False)] + [
-    (sp, 4, r, True, 4, False, 4, False) for sp in SPACES for r in (2, 4)] + [
-    (sp, 8, r, True, 4, False, 2, True) for sp in SPACES for r in (2, 4)]
+CONFIGS = [(sp, nw, r, True, 4, False, 2, False, False) for sp in SPACES for nw in (4, 8) for r in (2, 4)] + [
+    ("cosine", 4, 4, False, 4, False, 2, False, False), ("cosine", 8, 4, False, 4, False, 2, False, False),
+    ("cosine", 8, 4, True, 4, True, 2, False, False)] + [
+    (sp, 4, r, True, 4, False, 4, False, False) for sp in SPACES for r in (2, 4)] + [
+    (sp, 8, r, True, 4, False, 2, True, False) for sp in SPACES for r in (2, 4)] + [
+    (sp, 8, 4, True, 4, False, 2, True, True) for sp in SPACES]
 # timing diagnostics (cosine, NW=8, R=4, nt): QD slot carries the knob: 101 = nolds, 102 = nox, 103 = both
 DIAG = {101: {"nolds"}, 102: {"nox"}, 103: {"nolds", "nox"}, 104: {"nolds", "nox", "nobar"},
         107: {"nohit"}, 108: {"stamp"}, 109: {"noadm"}}
 
 
-def inc_name(space, nw, r, nt, qd, prio, mt, dma):
+def inc_name(space, nw, r, nt, qd, prio, mt, dma, stag=False):
     return (f"scan_asm_{space}_nw{nw}_r{r}{'_nt' if nt else ''}{'_qd%d' % qd if qd != 4 else ''}"
-            f"{'_pr' if prio else ''}{'_mt4' if mt == 4 else ''}{'_dma' if dma else ''}.inc")
+            f"{'_pr' if prio else ''}{'_mt4' if mt == 4 else ''}{'_dma' if dma else ''}{'_stag' if stag else ''}.inc")
 
 
 def main():
@@ -629,22 +691,23 @@ def main():
         print(" ".join(names))
         return
     for c in CONFIGS:
-        space, nw, r, nt, qd, prio, mt, dma = c
-        (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt, prio, mt, dma))
+        space, nw, r, nt, qd, prio, mt, dma, stag = c
+        (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag))
     for code, knobs in DIAG.items():
         DBG.clear()
         DBG.update(knobs)
         (Path(args.outdir) / f"scan_asm_diag{code}.inc").write_text(generate("cosine", 4, 4, 8, True, False))
         DBG.clear()
-    disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT, DMA>."]
-    for i, (space, nw, r, nt, qd, prio, mt, dma) in enumerate(CONFIGS):
+    disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT, DMA, STAG>."]
+    for i, (space, nw, r, nt, qd, prio, mt, dma, stag) in enumerate(CONFIGS):
         cond = (f"SPACE == {SPACES[space]} && NW == {nw} && R == {r} && NT == {'true' if nt else 'false'} && QD == {qd}"
-                f" && PRIO == {'true' if prio else 'false'} && MT == {mt} && DMA == {'true' if dma else 'false'}")
+                f" && PRIO == {'true' if prio else 'false'} && MT == {mt} && DMA == {'true' if dma else 'false'}"
+                f" && STAG == {'true' if stag else 'false'}")
         disp.append(("if" if i == 0 else "} else if") + f" constexpr ({cond}) {{")
-        disp.append(f'#include "{inc_name(space, nw, r, nt, qd, prio, mt, dma)}"')
+        disp.append(f'#include "{inc_name(space, nw, r, nt, qd, prio, mt, dma, stag)}"')
     disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
     for code in DIAG:
-        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2 && DMA == false) {{")
+        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2 && DMA == false && STAG == false) {{")
         disp.append(f'#include "scan_asm_diag{code}.inc"')
     disp.append("#endif")
     disp.append("} else {")
