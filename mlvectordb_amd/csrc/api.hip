@@ -60,6 +60,10 @@ struct mlvdb_index {
     DevBuf stage, qpad, qaux, partial, qsel, seed_lab, seed_dist, seed_cnt, seed_d64;
     DevBuf row_mask, rn_masked;  // filtered search
     DevBuf qerr, rowerr;         // rounding errors of the bf16 images: per query / maximum over the rows (device scalar)
+    // experimental int8 shadow (MLVDB_I8=1, cosine, ld % 256 == 0): built lazily at search time, rebuilt after any mutation
+    DevBuf x8, rp8, rowerr8, qimg8, sq8;
+    uint64_t mut = 0, i8_mut = ~0ull;  // mutation counter / the value the int8 shadow was built for
+    bool mask_active = false;           // h->rn is a masked copy (mlvdb_search_batch_filtered): the int8 rp8 knows no masks
     DevBuf qimg, fmisc, cand, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, counters, labels_in;
     DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
     uint32_t* host_flags = nullptr;  // pinned, kFilterQueries words
@@ -296,13 +300,40 @@ int collect_overflow(mlvdb_index* h, hipStream_t s, const FilterArgs& fa, int32_
     return MLVDB_OK;
 }
 
+// Experimental int8 shadow (MLVDB_I8=1): (re)build it when the corpus changed, and hand it to the pass.
+int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
+    const char* env = getenv("MLVDB_I8");  // read per pass: tools/scan_ab.py switches it inside one process
+    if (!(env && env[0] == '1') || h->space != kSpaceCosine || !h->Xb || h->ld % 256 != 0 || h->mask_active) return MLVDB_OK;
+    if (h->i8_mut != h->mut) {
+        HIP_TRY(h, h->x8.ensure((size_t)h->capacity * h->ld));
+        HIP_TRY(h, h->rp8.ensure((size_t)h->capacity * sizeof(float)));
+        HIP_TRY(h, h->rowerr8.ensure(sizeof(float)));
+        HIP_TRY(h, hipMemsetAsync(h->x8.p, 0, (size_t)h->capacity * h->ld, s));
+        HIP_TRY(h, hipMemsetAsync(h->rp8.p, 0xff, (size_t)h->capacity * sizeof(float), s));  // NaN: not a row
+        HIP_TRY(h, hipMemsetAsync(h->rowerr8.p, 0, sizeof(float), s));
+        HIP_TRY(h, launch_shadow8_rows(h->X, h->rn, h->x8.p, h->rp8.as<float>(), h->rowerr8.as<float>(), h->total, h->ld, s));
+        h->i8_mut = h->mut;
+    }
+    HIP_TRY(h, h->qimg8.ensure((size_t)kFilterQueries * h->ld));
+    HIP_TRY(h, h->sq8.ensure(kFilterQueries * sizeof(float)));
+    fa.X8 = h->x8.p;
+    fa.rp8 = h->rp8.as<float>();
+    fa.row_err8 = h->rowerr8.as<float>();
+    fa.qimg8 = h->qimg8.p;
+    fa.sq8 = h->sq8.as<float>();
+    return MLVDB_OK;
+}
+
 // One pass of <= 256 queries through the filter path; outputs at query index q0.. of the batch.
 int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qaux, int32_t q0, int32_t nq,
                     int32_t k, int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_d64) {
     FilterArgs fa{};
     int rc = setup_filter_ws(h, fa, Qpad + (size_t)q0 * h->ld, qaux + q0, h->qerr.as<float>() + q0, nq);
     if (rc) return rc;
+    rc = attach_i8(h, s, fa);
+    if (rc) return rc;
     HIP_TRY(h, launch_filter_prep(fa, s));
+    if (fa.X8) HIP_TRY(h, launch_filter_prep8(fa, s));  // int8 query image; ke becomes the int8 error term
     // seed: a dense pass of the filter kernel over the first rows puts every bound into the lists,
     // the update kernel turns them into thresholds; the remaining rows follow in rounds of growing
     // size so that thresholds tighten early
@@ -321,6 +352,7 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
         HIP_TRY(h, launch_filter_scatter(fa, info, s));
         h->stats.scan_launches += 1;
         h->stats.rows_scanned += e - b;
+        if (fa.X8) HIP_TRY(h, launch_filter_refine_thr(fa, k, -1, s));  // exact thresholds (the int8 bounds are loose)
         HIP_TRY(h, launch_filter_update(fa, k, s));
     }
     // counters: [0] rescored pairs, [1] fallback queries (accumulated over the passes of a call), [2] flag count
@@ -565,6 +597,7 @@ int mlvdb_index_append_device(mlvdb_index* h, const float* rows_device, int64_t 
     if (h->Xb) HIP_TRY(h, launch_shadow_rows(h->X, h->Xb, h->total, n, h->ld, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->total += n;
+    ++h->mut;
     return MLVDB_OK;
 }
 
@@ -589,6 +622,7 @@ int mlvdb_index_append(mlvdb_index* h, const float* rows, int64_t n, int64_t* fi
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     h->total += n;
+    ++h->mut;
     return MLVDB_OK;
 }
 
@@ -607,6 +641,7 @@ int mlvdb_index_tombstone(mlvdb_index* h, const int64_t* labels, int64_t n, int6
     HIP_TRY(h, hipMemcpyAsync(&changed, h->counters.p, sizeof changed, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->deleted += (int64_t)changed;
+    ++h->mut;
     if (newly_deleted) *newly_deleted = (int64_t)changed;
     return MLVDB_OK;
 }
@@ -664,6 +699,7 @@ int mlvdb_index_compact(mlvdb_index* h, int64_t* old_labels, int64_t capacity, i
     h->capacity = cap;
     h->total = want;
     h->deleted = 0;
+    ++h->mut;
     return MLVDB_OK;
 }
 
@@ -687,6 +723,7 @@ int mlvdb_index_reset(mlvdb_index* h, int32_t space) {
     if (h->rowerr.p) HIP_TRY(h, hipMemsetAsync(h->rowerr.p, 0, sizeof(unsigned int), h->stream));
     h->total = 0;
     h->deleted = 0;
+    ++h->mut;
     if (space >= 0) h->space = space;
     return MLVDB_OK;
 }
@@ -794,8 +831,10 @@ int mlvdb_search_batch_filtered(mlvdb_index* h, const float* queries, int64_t nq
     HIP_TRY(h, launch_mask_norms(h->rn, h->row_mask.as<uint8_t>(), h->rn_masked.as<float>(), h->total, h->capacity, h->stream));
     float* const all_rows = h->rn;  // every kernel of the call reads the masked norms instead
     h->rn = h->rn_masked.as<float>();
+    h->mask_active = true;
     rc = mlvdb_search_batch(h, queries, nq, k, out_labels, out_dist, out_counts);
     h->rn = all_rows;
+    h->mask_active = false;
     return rc;
 }
 

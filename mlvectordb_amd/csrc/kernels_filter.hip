@@ -548,7 +548,8 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
 // (u[cap], row[cap], q[cap] each) go to the per-query lists.  Entries are counted per query in LDS
 // first, so the block issues one device-scope atomic per query it has entries for (a per-entry
 // atomic on 256 hot counters cost ~90 us per launch).
-__global__ __launch_bounds__(256) void filter_scatter_kernel(const FilterArgs a, const int cap, const int nw, const int dbg) {
+__global__ __launch_bounds__(256) void filter_scatter_kernel(const FilterArgs a, const int cap, const int nw, const int dbg,
+                                                             const int i8) {
     __shared__ uint32_t hist[kFilterQueries], base[kFilterQueries];
 #ifdef MLVDB_SCAN_DIAGNOSTICS
     if (dbg && threadIdx.x < (unsigned)nw && (blockIdx.x % 64) == 0) {  // MLVDB_SCAN_DIAG=108: in-kernel cycle stamps
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(256) void filter_scatter_kernel(const FilterArgs a,
             const uint32_t slot = base[q] + atomicAdd(&hist[q], 1u);
             if (slot < (uint32_t)kCandCap) {
                 CandEntry e;
-                e.u = bu[i];
+                e.u = i8 ? __builtin_fmaf(bu[i], a.sq8[q], a.ke[q]) : bu[i];  // int8 scan: w = float(I) * rp8 -> bound
                 e.row = br[i];
                 a.cand[(size_t)q * kCandCap + slot] = e;
             }
@@ -616,6 +617,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     constexpr int kTileRowsV = NW * kWaveRows;
     constexpr int kQBufs = 2;
     constexpr int kStageCap = MT == 4 ? kAsmStageCapNw4Mt4 : (NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4);  // entries a wave stages in LDS
+    constexpr bool I8 = QD == 208;  // experimental int8 shadow: k-steps of 64 int8 columns, same bytes per step
     // LDS: [2][32 KiB] Q chunks at offset 0, thr[256], qscale[256], ke[256], [NW waves] staging {u[], row[], q[]}
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* thr_l = reinterpret_cast<float*>(smem + kQBufs * kChunkVec * sizeof(uint4));
@@ -627,9 +629,16 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4;
     const int c16 = lane & 15;
-    const int nkc = a.ld / kFilterChunkK;
+    const int nkc = I8 ? a.ld / (2 * kFilterChunkK) : a.ld / kFilterChunkK;
     for (int t = threadIdx.x; t < kFilterQueries; t += kThreads) {
-        thr_l[t] = a.thr[t];
+        float thr = a.thr[t];
+        if (I8) {
+            // the assembly tests float(I) * rp8 >= T: u = w*sq8 + ke >= thr  <=>  w >= (thr - ke)/sq8, rounded down
+            if (thr > 1.0e30f) thr = 3.4e38f;
+            else if (thr < -1.0e30f) thr = -3.4e38f;
+            else thr = float_below(((double)thr - (double)a.ke[t]) / (double)a.sq8[t]);
+        }
+        thr_l[t] = thr;
         sq_l[t] = a.qscale[t];
         ke_l[t] = a.ke[t];
     }
@@ -640,13 +649,13 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     if (lds_base != 0) __builtin_trap();  // the assembly toggles the Q buffers with xor 0x8000
 
     const uint32_t chunk_bytes = (uint32_t)(kChunkVec * sizeof(uint4));
-    const uint32_t pb = (uint32_t)a.ld * 32u;  // bytes of one bf16 panel (16 rows)
+    const uint32_t pb = (uint32_t)a.ld * (I8 ? 16u : 32u);  // bytes of one shadow panel (16 rows)
     const uint32_t wbytes = MT * pb;           // this wave's panels of a tile
     const uint64_t tile_bytes = (uint64_t)NW * wbytes;
     const int64_t first_tile = tile_begin + blockIdx.x;
-    const uint64_t xbase = reinterpret_cast<uint64_t>(a.Xb) + (uint64_t)first_tile * tile_bytes + (uint64_t)wave * wbytes;
+    const uint64_t xbase = reinterpret_cast<uint64_t>(I8 ? a.X8 : a.Xb) + (uint64_t)first_tile * tile_bytes + (uint64_t)wave * wbytes;
     const uint64_t xstride = (uint64_t)gridDim.x * tile_bytes;
-    const uint64_t rnbase = reinterpret_cast<uint64_t>(a.rn + first_tile * kTileRowsV + wave * kWaveRows);
+    const uint64_t rnbase = reinterpret_cast<uint64_t>((I8 ? a.rp8 : a.rn) + first_tile * kTileRowsV + wave * kWaveRows);
     const uint32_t xlo = (uint32_t)xbase, xhi = (uint32_t)(xbase >> 32) & 0xffffu;
     const uint32_t xslo = (uint32_t)xstride, xshi = (uint32_t)(xstride >> 32);
     const uint32_t rnlo = (uint32_t)rnbase, rnhi = (uint32_t)(rnbase >> 32) & 0xffffu;
@@ -660,7 +669,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     const uint32_t qc1 = (uint32_t)(1 % nkc) * chunk_bytes;
     u32x4s qsrd;
     {
-        const uint64_t qb = reinterpret_cast<uint64_t>(a.qimg);
+        const uint64_t qb = reinterpret_cast<uint64_t>(I8 ? a.qimg8 : a.qimg);
         qsrd[0] = (uint32_t)qb;
         qsrd[1] = (uint32_t)(qb >> 32) & 0xffffu;
         qsrd[2] = qbytes;
@@ -1102,6 +1111,202 @@ hipError_t launch_filter_range_thr(const FilterArgs& a, float radius, hipStream_
     return hipGetLastError();
 }
 
+// ================================================================== experimental: int8 shadow (MLVDB_I8=1, cosine)
+// v_mfma_i32_16x16x64_i8 issues at the bf16 instruction's rate under the power cap (tools/probe/mfma_i8_probe):
+// half the MFMA instructions, shadow bytes and LDS reads per row.  Rows and queries are quantised with one scale
+// per vector, x ~ sx * x8, q^ ~ sq * q8; the integer dot product I is exact, and
+//   |<q^,x> - sq sx I| <= (eq8 + (1 + eq8) rmax8) |x|      (Cauchy-Schwarz on the two rounding errors, |q^| <= 1)
+// with eq8 = |q^ - sq q8| measured per query and rmax8 = max over rows of |x - sx x8| / |x| measured at build time.
+// The errors are ~7x those of bf16, so thresholds from lower bounds (u - 2 eps) would be far too loose:
+// filter_refine_thr_kernel sets them from EXACT scores of the k best bounds of every round instead.
+__device__ __forceinline__ int64_t layout_offset_i8(int64_t row, int32_t col, int32_t ld) {
+    return (row >> 4) * (int64_t)(kPanelRows * ld) + (int64_t)(col >> 6) * 1024 + ((col & 63) >> 4) * 256 + (row & 15) * 16 +
+           (col & 15);
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const float* rn, int8_t* X8, float* rp8,
+                                                           unsigned int* row_err8, int64_t rows, int32_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float amax = 0.f;
+    for (int c = lane; c < ld; c += 64) amax = __builtin_fmaxf(amax, __builtin_fabsf(X[layout_offset(row, c, ld)]));
+    for (int off = 32; off > 0; off >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, off));
+    const float sx = amax > 0.f ? amax / 127.0f : 1.0f;
+    const float inv = 1.0f / sx;
+    double err2 = 0.0, n2 = 0.0;
+    for (int c = lane; c < ld; c += 64) {
+        const float x = X[layout_offset(row, c, ld)];
+        float t = __builtin_rintf(x * inv);
+        t = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, t));
+        X8[layout_offset_i8(row, c, ld)] = (int8_t)t;
+        const double e = (double)x - (double)sx * (double)t;
+        err2 += e * e;
+        n2 += (double)x * (double)x;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        err2 += __shfl_xor(err2, off);
+        n2 += __shfl_xor(n2, off);
+    }
+    if (lane == 0) {
+        const float nrm = rn[row];  // NaN: tombstoned / not a row
+        rp8[row] = sx / (nrm + 1e-30f);
+        if (n2 > 0.0) {
+            float rel = (float)(__builtin_sqrt(err2 / n2) * 1.000001);
+            rel = __uint_as_float(__float_as_uint(rel) + 1u);
+            atomicMax(row_err8, __float_as_uint(rel));  // non-negative floats order like their bits
+        }
+    }
+}
+
+hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t rows,
+                               int32_t ld, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    shadow8_rows_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(X, rn, static_cast<int8_t*>(X8), rp8,
+                                                                    reinterpret_cast<unsigned int*>(row_err8), rows, ld);
+    return hipGetLastError();
+}
+
+// Query image: Qimg8[kc][n][ks][lane][j] = q8[16n + (lane&15)][128kc + 64ks + 16(lane>>4) + j], one block per query
+// slot; also sq8, and ke = the int8 error term (overrides filter_prep_kernel's, so that every kernel of the pass --
+// the bf16 seeding pass included -- uses the same, larger eps).
+__global__ __launch_bounds__(256) void filter_prep8_kernel(const FilterArgs a) {
+    __shared__ float red[4];
+    __shared__ double dred[4];
+    const int q = blockIdx.x;
+    const int ld = a.ld;
+    int8_t* img = reinterpret_cast<int8_t*>(a.qimg8);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float inv = 0.f;
+    if (q < a.nq) inv = (float)a.qaux[q];  // cosine: 1/(|q|+1e-30)
+    float amax = 0.f;
+    for (int c = threadIdx.x; c < ld; c += 256) {
+        const float v = q < a.nq ? a.Qpad[(int64_t)q * ld + c] * inv : 0.f;
+        amax = __builtin_fmaxf(amax, __builtin_fabsf(v));
+    }
+    for (int off = 32; off > 0; off >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, off));
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    amax = __builtin_fmaxf(__builtin_fmaxf(red[0], red[1]), __builtin_fmaxf(red[2], red[3]));
+    const float sq = amax > 0.f ? amax / 127.0f : 1.0f;
+    const float isq = 1.0f / sq;
+    double err2 = 0.0;
+    for (int c = threadIdx.x; c < ld; c += 256) {
+        const float v = q < a.nq ? a.Qpad[(int64_t)q * ld + c] * inv : 0.f;
+        float t = __builtin_rintf(v * isq);
+        t = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, t));
+        const double e = (double)v - (double)sq * (double)t;
+        err2 += e * e;
+        const int kc = c >> 7, ks = (c >> 6) & 1, g = (c >> 4) & 3, j = c & 15;
+        const int n = q >> 4, l = (q & 15) + 16 * g;
+        img[((((int64_t)kc * 16 + n) * 2 + ks) * 64 + l) * 16 + j] = (int8_t)t;
+    }
+    for (int off = 32; off > 0; off >>= 1) err2 += __shfl_xor(err2, off);
+    if (lane == 0) dred[wave] = err2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double eq8 = __builtin_sqrt(dred[0] + dred[1] + dred[2] + dred[3]) * 1.000001 + 1e-12;
+        a.sq8[q] = sq;
+        // E = eq8 + (1 + eq8) rmax8 (eq8 <= 2^-6), + the bf16 term as a floor (the seeding pass computes bf16 bounds),
+        // + rounding of float(I) * rp8 * sq8 (three roundings of a value <= ~1) and the usual slack
+        const double e8 = (q < a.nq ? eq8 : 0.0) + 1.016 * (double)*a.row_err8 + 4.0 * 5.9604644775390625e-08;
+        const double eb = (q < a.nq ? (double)a.qerr[q] : 0.0) + 1.00390625 * (double)*a.row_err + (double)ld * 2.384185791015625e-07;
+        float ke = (float)((e8 > eb ? e8 : eb) * 1.000001) + 2.0f * kSlack;
+        a.ke[q] = __uint_as_float(__float_as_uint(ke) + 1u);
+    }
+}
+
+hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s) {
+    filter_prep8_kernel<<<kFilterQueries, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+// Exact thresholds: the k entries with the largest bounds are scored exactly (fp64, the rescoring arithmetic); the
+// smallest of those k scores is a lower bound of the final k-th best score, however loose the bounds are.
+// Runs before filter_update_kernel, which keeps the larger of this and its own bound-derived threshold.
+template <int SPACE>
+__global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs a, const int32_t k, const int32_t forced_cnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* qs = reinterpret_cast<double*>(smem);                                   // [ld]
+    unsigned long long* red = reinterpret_cast<unsigned long long*>(qs + a.ld);     // [4]
+    int32_t* pick = reinterpret_cast<int32_t*>(red + 4);                            // [64] rows picked
+    double* smin = reinterpret_cast<double*>(pick + 64);                            // [4]
+    const int q = blockIdx.x;
+    if (q >= a.nq || a.overflow[q]) return;
+    const uint32_t cnt = forced_cnt >= 0 ? (uint32_t)forced_cnt : a.cnt[q];
+    if (cnt > (uint32_t)kCandCap || cnt < (uint32_t)k || k > 64) return;
+    const int ld = a.ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const CandEntry* list = a.cand + (int64_t)q * kCandCap;
+    for (int c = threadIdx.x; c < ld; c += 256) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
+    // k rounds of argmax over keys (order key of u, list index): strictly below the previous pick
+    unsigned long long prev = ~0ull;
+    for (int i = 0; i < k; ++i) {
+        unsigned long long best = 0;
+        for (uint32_t idx = threadIdx.x; idx < cnt; idx += 256) {
+            const CandEntry e = list[idx];
+            if (!(e.u == e.u)) continue;
+            const unsigned long long key = ((unsigned long long)float_order_key(e.u) << 32) | (0xffffffffu - idx);
+            if (key < prev && key > best) best = key;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off);
+            best = o > best ? o : best;
+        }
+        __syncthreads();
+        if (lane == 0) red[wave] = best;
+        __syncthreads();
+        best = red[0];
+        for (int w = 1; w < 4; ++w) best = red[w] > best ? red[w] : best;
+        if (best == 0) return;  // fewer than k valid entries (uniform: every thread sees the same value)
+        if (threadIdx.x == 0) pick[i] = list[0xffffffffu - (uint32_t)(best & 0xffffffffu)].row;
+        prev = best;
+    }
+    __syncthreads();
+    // exact scores of the picked rows: 16 rows per wave step (lane 16g + r: row r, column quarter g)
+    const int g = lane >> 4, r = lane & 15;
+    const double qinv = a.qaux[q];
+    double smallest = __builtin_inf();
+    for (int i0 = wave * 16; i0 < k; i0 += 64) {
+        const int idx = i0 + r;
+        const bool have = idx < k;
+        const int32_t row = have ? pick[idx] : 0;
+        const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 16 + g * 4};
+        double acc[1][1], nx[1];
+        accumulate_rows<SPACE, 1, 1, 8>(base, qs, ld, g, acc, nx);
+        const double dk = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
+        double sc;
+        if (SPACE == kSpaceCosine) sc = 1.0 - dk;
+        else if (SPACE == kSpaceIp) sc = (1.0 - dk) / qinv;  // qaux = |q| for ip / l2
+        else sc = qinv * qinv - dk;
+        if (have && sc < smallest) smallest = sc;
+        if (have && !(sc == sc)) smallest = -__builtin_inf();
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(smallest, off);
+        smallest = o < smallest ? o : smallest;
+    }
+    if (lane == 0) smin[wave] = smallest;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sm = smin[0];
+        for (int w = 1; w < 4; ++w) sm = smin[w] < sm ? smin[w] : sm;
+        if (sm > -1.0e300 && sm < 1.0e300) {
+            const double mag = SPACE == kSpaceL2 ? qinv * qinv + __builtin_fabs(sm) : __builtin_fabs(sm) + 1.0;
+            const float t = float_below(sm - 1e-9 * mag);
+            if (t > a.thr[q]) a.thr[q] = t;
+        }
+    }
+}
+
+hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s) {
+    const size_t lds = (size_t)a.ld * sizeof(double) + 4 * 8 + 64 * 4 + 4 * 8;
+    // (cosine only so far: the int8 path is)
+    filter_refine_thr_kernel<kSpaceCosine><<<a.nq, 256, lds, s>>>(a, k, forced_cnt);
+    return hipGetLastError();
+}
+
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -1213,6 +1418,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     info->scatter_grid = grid;  // the caller runs launch_filter_scatter next (outside its timing window)
     info->nw = NW;
     info->dbg = QD == 108 ? 1 : 0;
+    info->i8 = QD == 208 ? 1 : 0;
     return hipGetLastError();
 }
 
@@ -1221,7 +1427,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
 template <int SPACE>
 static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info) {
     const int nkc = a.ld / kFilterChunkK;
-    if (filter_narrow_ok(a)) return launch_scan_narrow<SPACE, false>(a, row_begin, row_end, s);  // appends to the lists itself
+    if (filter_narrow_ok(a) && !a.X8) return launch_scan_narrow<SPACE, false>(a, row_begin, row_end, s);  // appends to the lists itself
     if (a.Xb && env_int("MLVDB_SCAN_ASM", 1)) {
         // hand-written body (tools/gen_scan_asm.py).  Default: one 8-wave workgroup per CU (256-row tiles:
         // the query image is staged once per CU, by LDS-DMA), non-temporal X loads, ring of 4 k-steps -- measured
@@ -1233,6 +1439,8 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
             return launch_scan_asm<SPACE, 2, 4, true, 4, false, 4>(a, row_begin, row_end, s, info);
         }
         if constexpr (SPACE == kSpaceCosine) {
+            if (a.X8 && a.ld % 256 == 0)  // experimental int8 shadow (the caller built it: MLVDB_I8=1); ld/128 chunks, even
+                return launch_scan_asm<SPACE, 4, 8, true, 208, false, 2, true>(a, row_begin, row_end, s, info);
             if (nw == 8 && nkc % 2 == 0 && env_int("MLVDB_SCAN_PRIO", 0) != 0)
                 return launch_scan_asm<SPACE, 4, 8, true, 4, true>(a, row_begin, row_end, s, info);
             if (nkc % 2 == 0 && env_int("MLVDB_SCAN_NT", 1) == 0)
@@ -1283,6 +1491,7 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
             : a.space == kSpaceCosine ? launch_scan_narrow<kSpaceCosine, true>(a, 0, rows, s)
                                       : launch_scan_narrow<kSpaceIp, true>(a, 0, rows, s);
         if (e != hipSuccess) return e;
+        if (a.X8 && (e = launch_filter_refine_thr(a, k, (int32_t)rows, s)) != hipSuccess) return e;
         return launch_update(a, k, (int32_t)rows, s);
     }
     switch (a.space) {
@@ -1300,6 +1509,7 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
             break;
     }
     if (e != hipSuccess) return e;
+    if (a.X8 && (e = launch_filter_refine_thr(a, k, (int32_t)rows, s)) != hipSuccess) return e;
     return launch_update(a, k, (int32_t)rows, s);  // lists -> thresholds; cnt[q] = survivors
 }
 
@@ -1314,7 +1524,7 @@ hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t ro
 
 hipError_t launch_filter_scatter(const FilterArgs& a, const ScanInfo& info, hipStream_t s) {
     if (info.scatter_grid == 0) return hipSuccess;  // the compiler-scheduled kernel appends to the lists itself
-    filter_scatter_kernel<<<info.scatter_grid, 256, 0, s>>>(a, kWgCap / info.nw, info.nw, info.dbg);
+    filter_scatter_kernel<<<info.scatter_grid, 256, 0, s>>>(a, kWgCap / info.nw, info.nw, info.dbg, info.i8);
     return hipGetLastError();
 }
 

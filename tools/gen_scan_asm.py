@@ -47,6 +47,7 @@ MT = 2
 CHUNK_BYTES = 0x8000      # 256 queries x 64 columns x 2 B
 WG_CAP = 16384            # kWgCap: append entries per workgroup (split evenly over its waves)
 SPACES = {"l2": 0, "cosine": 1, "ip": 2}
+I8 = False     # generate(): int8 shadow -- v_mfma_i32_16x16x64_i8, k-steps of 64 columns, integer accumulators
 STAG = False   # generate(): the later-dispatched half of the waves runs half a tile behind (see generate)
 DBG = set()   # timing diagnostics only (wrong results): 'nolds' drops the B-fragment reads, 'nox' the X refills
 
@@ -215,7 +216,8 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
         s.need_lg(("rd", f))
         for m in range(MT):
             c = "0" if (zero_first and h == 0) else acc(m, n)
-            s.emit(f"v_mfma_f32_16x16x32_bf16 {acc(m, n)}, {ring(b, m)}, %[t{f % QD}], {c}")
+            op = "v_mfma_i32_16x16x64_i8" if I8 else "v_mfma_f32_16x16x32_bf16"
+            s.emit(f"{op} {acc(m, n)}, {ring(b, m)}, %[t{f % QD}], {c}")
         if f + QD < 32:
             read(f + QD)
         if f in plan:
@@ -300,6 +302,34 @@ def gen_admission(space):
     # cosine p0 = 1/(|x|+1e-30), u = a*p0 + ke; ip p0 = |x|, u = a + ke*p0; l2 p0 = |x|, p1 = -|x|^2 (1-slack),
     # u = sq*(a + ke*p0) + p1
     NR = 4 * MT
+    if I8:
+        # int8 shadow, cosine: r_j = sx/(|x|+1e-30) of the row (NaN: tombstoned), accumulators are exact integer dot
+        # products I; the test is float(I)*r_j >= T[q] with T = (thr - ke)/sq rounded down (filter_scan_asm_kernel);
+        # the append path stores w = float(I)*r_j, filter_scatter_kernel turns it into the bound u = w*sq + ke
+        assert space == "cosine"
+        s.lds(f"ds_read_b32 %[e0], %[thra]", ("thr", 0))
+        for n in range(16):
+            if n + 1 < 16:
+                s.lds(f"ds_read_b32 %[e{(n + 1) & 1}], %[thra] offset:{(n + 1) * 64}", ("thr", n + 1))
+            for j in range(NR):
+                m, i = j >> 2, j & 3
+                a(f"v_accvgpr_read_b32 %[u{j}], a{(m * 16 + n) * 4 + i}")
+            for j in range(NR):
+                a(f"v_cvt_f32_i32 %[u{j}], %[u{j}]")
+            for j in range(NR):
+                a(f"v_mul_f32 %[u{j}], %[u{j}], %[r{j}]")
+            a("v_max3_f32 %[e4], %[u0], %[u1], %[u2]")
+            a("v_max3_f32 %[e5], %[u3], %[u4], %[u5]")
+            for j in range(6, NR, 4):
+                a(f"v_max3_f32 %[e4], %[u{j}], %[u{j + 1}], %[e4]")
+                if j + 3 < NR:
+                    a(f"v_max3_f32 %[e5], %[u{j + 2}], %[u{j + 3}], %[e5]")
+            a("v_max_f32 %[e4], %[e4], %[e5]")
+            s.need_lg(("thr", n))
+            a(f"v_cmp_ge_f32 vcc, %[e4], %[e{n & 1}]")
+            a(f"s_cbranch_vccnz .Lhit{n}_%=")
+            a(f".Lback{n}_%=:")
+        return s.lines
     for j in range(NR):
         if space == "cosine":
             a(f"v_add_f32 %[r{j}], 0x0da24260, %[r{j}]")   # + 1e-30f
@@ -458,16 +488,17 @@ def gen_flush(NW):
             "s_waitcnt vmcnt(0)"]
 
 
-def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False):
+def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False):
     """stag: both waves of a SIMD reach the admission test (VALU only) together and leave the MFMA pipe idle for it.
     With the stagger the later-dispatched half of a workgroup's waves (wtype 1) runs half a tile behind: it sits out
     the first nkc/2 chunk periods (staging only), starts every row tile at column ld/2 (k origin rotated by xrot,
     wrapping at the end of the panel; the shared Q chunk stream is the same for everybody) and therefore reaches its
     admission test while its SIMD partner is in mid-tile; the early half sits out nkc/2 periods at the end.
     hc = 0 (and xrot = 0) turns it off at run time."""
-    global MT, STAG
+    global MT, STAG, I8
     MT = mt
     STAG = stag
+    I8 = i8
     assert R in (2, 4, 6) and 2 <= QD <= 8 and mt in (2, 4)
     assert not stag or (dma and mt == 2 and R * 1024 <= 4096)
     KQ = 1024 // (NW * 64)
@@ -654,7 +685,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     text = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.",
             f"// filter scan body: space {space}, NW={NW} waves x {16 * MT} rows, ring R={R} k-steps, B fragments read {QD} ahead"
             f"{', X loads non-temporal' if nt else ''}{', progress-based wave priority' if prio else ''}{', Q staged by LDS-DMA' if dma else ''}"
-            f"{', late waves staggered by half a tile' if stag else ''}.",
+            f"{', late waves staggered by half a tile' if stag else ''}{', int8 shadow (v_mfma_i32_16x16x64_i8)' if i8 else ''}.",
             "asm volatile("]
     for ln in out:
         text.append(f'    "{ln}\\n\\t"')
@@ -671,6 +702,7 @@ CONFIGS = [(sp, nw, r, True, 4, False, 2, False, False) for sp in SPACES for nw 
     (sp, 4, r, True, 4, False, 4, False, False) for sp in SPACES for r in (2, 4)] + [
     (sp, 8, r, True, 4, False, 2, True, False) for sp in SPACES for r in (2, 4)] + [
     (sp, 8, 4, True, 4, False, 2, True, True) for sp in SPACES]
+I8_CONFIGS = [("cosine", 8, 4, True, 4, False, 2, True, False)]   # int8 shadow (experimental): QD slot 208 in the dispatch
 # timing diagnostics (cosine, NW=8, R=4, nt): QD slot carries the knob: 101 = nolds, 102 = nox, 103 = both
 DIAG = {101: {"nolds"}, 102: {"nox"}, 103: {"nolds", "nox"}, 104: {"nolds", "nox", "nobar"},
         107: {"nohit"}, 108: {"stamp"}, 109: {"noadm"}}
@@ -686,13 +718,15 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + ["scan_asm_cosine_i8.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
     for c in CONFIGS:
         space, nw, r, nt, qd, prio, mt, dma, stag = c
         (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag))
+    for space, nw, r, nt, qd, prio, mt, dma, stag in I8_CONFIGS:
+        (Path(args.outdir) / "scan_asm_cosine_i8.inc").write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag, True))
     for code, knobs in DIAG.items():
         DBG.clear()
         DBG.update(knobs)
@@ -705,6 +739,8 @@ def main():
                 f" && STAG == {'true' if stag else 'false'}")
         disp.append(("if" if i == 0 else "} else if") + f" constexpr ({cond}) {{")
         disp.append(f'#include "{inc_name(space, nw, r, nt, qd, prio, mt, dma, stag)}"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 208 && PRIO == false && MT == 2 && DMA == true && STAG == false) {")
+    disp.append('#include "scan_asm_cosine_i8.inc"')
     disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
     for code in DIAG:
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2 && DMA == false && STAG == false) {{")
