@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLVDB_ABI_VERSION 1
+#define MLVDB_ABI_VERSION 2
 
 /* status codes */
 #define MLVDB_OK 0
@@ -70,6 +70,8 @@ typedef struct mlvdb_stats {
     int64_t fallback_queries;     /* queries re-run on the exact scan after a candidate-list overflow */
     double scan_ms;               /* summed HIP-event time of the scan launches (0 unless profiling is on) */
     double total_ms;              /* HIP-event time of the whole call on its stream (0 unless profiling is on) */
+    int32_t bound_dtype;          /* filter strategy: 1 = bf16 shadow, 2 = int8 shadow (cosine) computed the bounds; else 0 */
+    int32_t reserved;
 } mlvdb_stats;
 
 int mlvdb_abi_version(void);

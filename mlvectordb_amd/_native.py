@@ -18,7 +18,7 @@ SPACE_CODES = {"l2": 0, "cosine": 1, "ip": 2}
 STRATEGY_CODES = {"auto": 0, "exact": 1, "filter": 2}
 MAX_TOPK = 64
 MAX_TOPK_PAGED = 16384
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class Stats(C.Structure):
@@ -30,6 +30,8 @@ class Stats(C.Structure):
         ("fallback_queries", C.c_int64),
         ("scan_ms", C.c_double),
         ("total_ms", C.c_double),
+        ("bound_dtype", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

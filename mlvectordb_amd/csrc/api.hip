@@ -62,8 +62,8 @@ struct mlvdb_index {
     DevBuf qerr, rowerr;         // rounding errors of the bf16 images: per query / maximum over the rows (device scalar)
     // experimental int8 shadow (MLVDB_I8=1, cosine, ld % 256 == 0): built lazily at search time, rebuilt after any mutation
     DevBuf x8, rp8, rowerr8, qimg8, sq8;
-    uint64_t mut = 0, i8_mut = ~0ull;  // mutation counter / the value the int8 shadow was built for
-    bool mask_active = false;           // h->rn is a masked copy (mlvdb_search_batch_filtered): the int8 rp8 knows no masks
+    int64_t i8_rows = 0;      // rows [0, i8_rows) of the int8 shadow are current (0 after compact / reset / regrowth)
+    bool mask_active = false;  // h->rn is a masked copy (mlvdb_search_batch_filtered): the int8 rp8 knows no masks
     DevBuf qimg, fmisc, cand, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, counters, labels_in;
     DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
     uint32_t* host_flags = nullptr;  // pinned, kFilterQueries words
@@ -300,19 +300,33 @@ int collect_overflow(mlvdb_index* h, hipStream_t s, const FilterArgs& fa, int32_
     return MLVDB_OK;
 }
 
-// Experimental int8 shadow (MLVDB_I8=1): (re)build it when the corpus changed, and hand it to the pass.
+// int8 shadow of a cosine index (kernels_filter.hip, "int8 shadow"): kept current lazily -- rows appended since the
+// last pass are converted here, tombstones are patched in by mlvdb_index_tombstone, compaction / reset / regrowth
+// start it over.  MLVDB_I8=0 keeps the pass on the bf16 shadow.
+__global__ void tombstone_rp8_kernel(const int64_t* labels, int64_t n, float* rp8, int64_t rows) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && labels[i] >= 0 && labels[i] < rows) rp8[labels[i]] = __builtin_nanf("");
+}
+
 int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
     const char* env = getenv("MLVDB_I8");  // read per pass: tools/scan_ab.py switches it inside one process
-    if (!(env && env[0] == '1') || h->space != kSpaceCosine || !h->Xb || h->ld % 256 != 0 || h->mask_active) return MLVDB_OK;
-    if (h->i8_mut != h->mut) {
-        HIP_TRY(h, h->x8.ensure((size_t)h->capacity * h->ld));
-        HIP_TRY(h, h->rp8.ensure((size_t)h->capacity * sizeof(float)));
+    if ((env && env[0] == '0') || h->space != kSpaceCosine || !h->Xb || h->ld % 256 != 0 || h->mask_active) return MLVDB_OK;
+    const size_t need_x8 = (size_t)h->capacity * h->ld, need_rp = (size_t)h->capacity * sizeof(float);
+    if (h->x8.bytes < need_x8 || h->rp8.bytes < need_rp || !h->rowerr8.p) {
+        HIP_TRY(h, h->x8.ensure(need_x8));
+        HIP_TRY(h, h->rp8.ensure(need_rp));
         HIP_TRY(h, h->rowerr8.ensure(sizeof(float)));
-        HIP_TRY(h, hipMemsetAsync(h->x8.p, 0, (size_t)h->capacity * h->ld, s));
-        HIP_TRY(h, hipMemsetAsync(h->rp8.p, 0xff, (size_t)h->capacity * sizeof(float), s));  // NaN: not a row
+        h->i8_rows = 0;
+    }
+    if (h->i8_rows == 0) {
+        HIP_TRY(h, hipMemsetAsync(h->x8.p, 0, need_x8, s));
+        HIP_TRY(h, hipMemsetAsync(h->rp8.p, 0xff, need_rp, s));  // NaN: not a row
         HIP_TRY(h, hipMemsetAsync(h->rowerr8.p, 0, sizeof(float), s));
-        HIP_TRY(h, launch_shadow8_rows(h->X, h->rn, h->x8.p, h->rp8.as<float>(), h->rowerr8.as<float>(), h->total, h->ld, s));
-        h->i8_mut = h->mut;
+    }
+    if (h->i8_rows < h->total) {
+        HIP_TRY(h, launch_shadow8_rows(h->X, h->rn, h->x8.p, h->rp8.as<float>(), h->rowerr8.as<float>(), h->i8_rows, h->total,
+                                       h->ld, s));
+        h->i8_rows = h->total;
     }
     HIP_TRY(h, h->qimg8.ensure((size_t)kFilterQueries * h->ld));
     HIP_TRY(h, h->sq8.ensure(kFilterQueries * sizeof(float)));
@@ -334,6 +348,7 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
     if (rc) return rc;
     HIP_TRY(h, launch_filter_prep(fa, s));
     if (fa.X8) HIP_TRY(h, launch_filter_prep8(fa, s));  // int8 query image; ke becomes the int8 error term
+    h->stats.bound_dtype = fa.X8 ? 2 : 1;
     // seed: a dense pass of the filter kernel over the first rows puts every bound into the lists,
     // the update kernel turns them into thresholds; the remaining rows follow in rounds of growing
     // size so that thresholds tighten early
@@ -597,7 +612,6 @@ int mlvdb_index_append_device(mlvdb_index* h, const float* rows_device, int64_t 
     if (h->Xb) HIP_TRY(h, launch_shadow_rows(h->X, h->Xb, h->total, n, h->ld, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->total += n;
-    ++h->mut;
     return MLVDB_OK;
 }
 
@@ -622,7 +636,6 @@ int mlvdb_index_append(mlvdb_index* h, const float* rows, int64_t n, int64_t* fi
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     h->total += n;
-    ++h->mut;
     return MLVDB_OK;
 }
 
@@ -641,7 +654,10 @@ int mlvdb_index_tombstone(mlvdb_index* h, const int64_t* labels, int64_t n, int6
     HIP_TRY(h, hipMemcpyAsync(&changed, h->counters.p, sizeof changed, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->deleted += (int64_t)changed;
-    ++h->mut;
+    if (h->rp8.p && h->i8_rows > 0) {  // the int8 shadow's row constants carry the tombstones too
+        tombstone_rp8_kernel<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(h->labels_in.as<int64_t>(), n, h->rp8.as<float>(), h->i8_rows);
+        HIP_TRY(h, hipGetLastError());
+    }
     if (newly_deleted) *newly_deleted = (int64_t)changed;
     return MLVDB_OK;
 }
@@ -699,7 +715,7 @@ int mlvdb_index_compact(mlvdb_index* h, int64_t* old_labels, int64_t capacity, i
     h->capacity = cap;
     h->total = want;
     h->deleted = 0;
-    ++h->mut;
+    h->i8_rows = 0;
     return MLVDB_OK;
 }
 
@@ -723,7 +739,7 @@ int mlvdb_index_reset(mlvdb_index* h, int32_t space) {
     if (h->rowerr.p) HIP_TRY(h, hipMemsetAsync(h->rowerr.p, 0, sizeof(unsigned int), h->stream));
     h->total = 0;
     h->deleted = 0;
-    ++h->mut;
+    h->i8_rows = 0;
     if (space >= 0) h->space = space;
     return MLVDB_OK;
 }

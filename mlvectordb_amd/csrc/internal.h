@@ -121,7 +121,7 @@ struct FilterArgs {
     uint32_t* cnt;          // [256] candidates appended
     uint32_t* overflow;     // [256] nonzero = list overflowed, query must be re-run exactly
     CandEntry* cand;        // [256][kCandCap]
-    // experimental int8 shadow (MLVDB_I8=1, cosine): all null / unused otherwise
+    // int8 shadow (cosine, ld % 256 == 0; MLVDB_I8=0 disables): all null / unused otherwise
     const void* X8;         // int8 rows, per-row scale: panels of 16 rows, 64-column groups of 1 KiB (layout_offset_i8)
     const float* rp8;       // [rows] scale / (|x| + 1e-30): float(int dot) * rp8 * sq8 = bound of the cosine; NaN = tombstoned
     const float* row_err8;  // device scalar: max over rows of |x - scale * x8| / |x| (rounded up)
@@ -141,10 +141,10 @@ struct ScanInfo {
     int dbg = 0;
     int i8 = 0;  // entries hold w = float(int dot) * rp8: the scatter turns them into bounds
 };
-// experimental int8 shadow: build it for rows [0, rows) (also rp8 and the index-wide error), the query image of a
+// int8 shadow: (re)build the panels covering rows [row_begin, row_end) (also rp8 and the index-wide error), the query image of a
 // pass (after launch_filter_prep: overrides ke with the int8 error term), exact thresholds from the k best bounds
-hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t rows,
-                               int32_t ld, hipStream_t s);
+hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t row_begin,
+                               int64_t row_end, int32_t ld, hipStream_t s);
 hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s);
 hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s);
 hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info);

@@ -1111,7 +1111,7 @@ hipError_t launch_filter_range_thr(const FilterArgs& a, float radius, hipStream_
     return hipGetLastError();
 }
 
-// ================================================================== experimental: int8 shadow (MLVDB_I8=1, cosine)
+// ================================================================== int8 shadow (cosine; MLVDB_I8=0 disables)
 // v_mfma_i32_16x16x64_i8 issues at the bf16 instruction's rate under the power cap (tools/probe/mfma_i8_probe):
 // half the MFMA instructions, shadow bytes and LDS reads per row.  Rows and queries are quantised with one scale
 // per vector, x ~ sx * x8, q^ ~ sq * q8; the integer dot product I is exact, and
@@ -1124,32 +1124,51 @@ __device__ __forceinline__ int64_t layout_offset_i8(int64_t row, int32_t col, in
            (col & 15);
 }
 
-// one wave per row
+// One wave per 16-row panel: lane 16g + r owns row r, columns 4g..4g+3 of every 16-column group (one coalesced
+// 1 KiB load per group, as everywhere); pass 1 finds the row maxima, pass 2 (the panel is in L2 by then) quantises
+// and measures the error.  Whole panels are (re)written: idempotent for rows converted before.
 __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const float* rn, int8_t* X8, float* rp8,
-                                                           unsigned int* row_err8, int64_t rows, int32_t ld) {
+                                                           unsigned int* row_err8, int64_t panel_begin, int64_t panel_end,
+                                                           int32_t ld) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int64_t panel = panel_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (panel >= panel_end) return;
+    const int g = lane >> 4, r = lane & 15;
+    const float4* src = reinterpret_cast<const float4*>(X + panel * (int64_t)(kPanelRows * ld) + lane_group_offset(lane));
+    const int ngroups = ld / 16;
     float amax = 0.f;
-    for (int c = lane; c < ld; c += 64) amax = __builtin_fmaxf(amax, __builtin_fabsf(X[layout_offset(row, c, ld)]));
-    for (int off = 32; off > 0; off >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, off));
+    for (int cg = 0; cg < ngroups; ++cg) {
+        const float4 v = src[cg * (kGroupFloats / 4)];
+        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y))),
+                               __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+    }
+    amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16));
+    amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32));
     const float sx = amax > 0.f ? amax / 127.0f : 1.0f;
     const float inv = 1.0f / sx;
     double err2 = 0.0, n2 = 0.0;
-    for (int c = lane; c < ld; c += 64) {
-        const float x = X[layout_offset(row, c, ld)];
-        float t = __builtin_rintf(x * inv);
-        t = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, t));
-        X8[layout_offset_i8(row, c, ld)] = (int8_t)t;
-        const double e = (double)x - (double)sx * (double)t;
-        err2 += e * e;
-        n2 += (double)x * (double)x;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(X8 + panel * (int64_t)(kPanelRows * ld)) + r * 4 + g;
+    for (int cg = 0; cg < ngroups; ++cg) {
+        const float4 v = src[cg * (kGroupFloats / 4)];
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = __builtin_rintf(x[i] * inv);
+            t = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, t));
+            packed |= ((uint32_t)(int)t & 0xffu) << (8 * i);
+            const double e = (double)x[i] - (double)sx * (double)t;
+            err2 += e * e;
+            n2 += (double)x[i] * (double)x[i];
+        }
+        dst[(cg >> 2) * 256 + (cg & 3) * 64] = packed;  // bytes: (cg>>2)*1024 + (cg&3)*256 + r*16 + 4g (layout_offset_i8)
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        err2 += __shfl_xor(err2, off);
-        n2 += __shfl_xor(n2, off);
-    }
-    if (lane == 0) {
+    err2 += __shfl_xor(err2, 16);
+    err2 += __shfl_xor(err2, 32);
+    n2 += __shfl_xor(n2, 16);
+    n2 += __shfl_xor(n2, 32);
+    if (g == 0) {
+        const int64_t row = panel * kPanelRows + r;
         const float nrm = rn[row];  // NaN: tombstoned / not a row
         rp8[row] = sx / (nrm + 1e-30f);
         if (n2 > 0.0) {
@@ -1160,11 +1179,12 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
     }
 }
 
-hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t rows,
-                               int32_t ld, hipStream_t s) {
-    if (rows <= 0) return hipSuccess;
-    shadow8_rows_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(X, rn, static_cast<int8_t*>(X8), rp8,
-                                                                    reinterpret_cast<unsigned int*>(row_err8), rows, ld);
+hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t row_begin,
+                               int64_t row_end, int32_t ld, hipStream_t s) {
+    const int64_t pb = row_begin / kPanelRows, pe = (row_end + kPanelRows - 1) / kPanelRows;
+    if (pe <= pb) return hipSuccess;
+    shadow8_rows_kernel<<<(unsigned)((pe - pb + 3) / 4), 256, 0, s>>>(X, rn, static_cast<int8_t*>(X8), rp8,
+                                                                       reinterpret_cast<unsigned int*>(row_err8), pb, pe, ld);
     return hipGetLastError();
 }
 
@@ -1232,6 +1252,7 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
     unsigned long long* red = reinterpret_cast<unsigned long long*>(qs + a.ld);     // [4]
     int32_t* pick = reinterpret_cast<int32_t*>(red + 4);                            // [64] rows picked
     double* smin = reinterpret_cast<double*>(pick + 64);                            // [4]
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smin + 4);     // [kCandCap]
     const int q = blockIdx.x;
     if (q >= a.nq || a.overflow[q]) return;
     const uint32_t cnt = forced_cnt >= 0 ? (uint32_t)forced_cnt : a.cnt[q];
@@ -1240,14 +1261,18 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const CandEntry* list = a.cand + (int64_t)q * kCandCap;
     for (int c = threadIdx.x; c < ld; c += 256) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
-    // k rounds of argmax over keys (order key of u, list index): strictly below the previous pick
+    // keys (order key of u, list index) once into LDS; 0 = not a candidate (NaN bound: tombstoned / padding row)
+    for (uint32_t idx = threadIdx.x; idx < cnt; idx += 256) {
+        const float u = list[idx].u;
+        keys[idx] = u == u ? ((unsigned long long)float_order_key(u) << 32) | (0xffffffffu - idx) : 0ull;
+    }
+    __syncthreads();
+    // k rounds of argmax, each strictly below the previous pick
     unsigned long long prev = ~0ull;
     for (int i = 0; i < k; ++i) {
         unsigned long long best = 0;
         for (uint32_t idx = threadIdx.x; idx < cnt; idx += 256) {
-            const CandEntry e = list[idx];
-            if (!(e.u == e.u)) continue;
-            const unsigned long long key = ((unsigned long long)float_order_key(e.u) << 32) | (0xffffffffu - idx);
+            const unsigned long long key = keys[idx];
             if (key < prev && key > best) best = key;
         }
         for (int off = 32; off > 0; off >>= 1) {
@@ -1301,9 +1326,15 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
 }
 
 hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s) {
-    const size_t lds = (size_t)a.ld * sizeof(double) + 4 * 8 + 64 * 4 + 4 * 8;
-    // (cosine only so far: the int8 path is)
-    filter_refine_thr_kernel<kSpaceCosine><<<a.nq, 256, lds, s>>>(a, k, forced_cnt);
+    const size_t lds = (size_t)a.ld * sizeof(double) + 4 * 8 + 64 * 4 + 4 * 8 + (size_t)kCandCap * 8;
+    auto kern = filter_refine_thr_kernel<kSpaceCosine>;  // cosine only so far: the int8 path is
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    kern<<<a.nq, 256, lds, s>>>(a, k, forced_cnt);
     return hipGetLastError();
 }
 

@@ -38,7 +38,7 @@ def test_header_constants_match_binding():
 
 
 def test_stats_struct_layout_matches_header():
-    assert C.sizeof(_native.Stats) == 4 + 4 + 8 + 8 + 8 + 8 + 8
+    assert C.sizeof(_native.Stats) == 4 + 4 + 8 + 8 + 8 + 8 + 8 + 4 + 4
 
 
 def test_no_device_is_a_loud_error_not_a_fallback(gpu_available):

@@ -254,13 +254,14 @@ def test_range_capacity_overflow_is_reported_then_resolved():
 
 
 SCAN_VARIANTS = [
-    {"MLVDB_SCAN_NW": "8"},                          # default: assembly body, one 8-wave workgroup per CU, Q by LDS-DMA
-    {"MLVDB_SCAN_NW": "8", "MLVDB_SCAN_DMA": "0"},   # Q staged through registers (global -> VGPR -> ds_write)
-    {"MLVDB_SCAN_NW": "4"},                          # assembly body, two 4-wave workgroups per CU
-    {"MLVDB_SCAN_MT": "4"},                          # assembly body, one wave per SIMD, 64 rows per wave
-    {"MLVDB_SCAN_NW": "8", "MLVDB_SCAN_NT": "0"},    # (cosine only) temporal X loads
-    {"MLVDB_SCAN_ASM": "0"},                         # the hipcc-scheduled kernel (also serves corpora without shadow)
-    {"MLVDB_SCAN_STAG": "1"},                        # later half of the waves half a tile behind (rotated k origin)
+    {},                                              # defaults: int8 shadow body for cosine with dim % 256 == 0, else the bf16 body below
+    {"MLVDB_I8": "0"},                               # bf16 body: one 8-wave workgroup per CU, Q by LDS-DMA
+    {"MLVDB_I8": "0", "MLVDB_SCAN_DMA": "0"},        # Q staged through registers (global -> VGPR -> ds_write)
+    {"MLVDB_I8": "0", "MLVDB_SCAN_NW": "4"},         # two 4-wave workgroups per CU
+    {"MLVDB_I8": "0", "MLVDB_SCAN_MT": "4"},         # one wave per SIMD, 64 rows per wave
+    {"MLVDB_I8": "0", "MLVDB_SCAN_NT": "0"},         # (cosine only) temporal X loads
+    {"MLVDB_I8": "0", "MLVDB_SCAN_ASM": "0"},        # the hipcc-scheduled kernel (also serves corpora without shadow)
+    {"MLVDB_I8": "0", "MLVDB_SCAN_STAG": "1"},       # later half of the waves half a tile behind (rotated k origin)
 ]
 
 NARROW_CASES = [
@@ -285,7 +286,7 @@ def test_small_batches_through_the_filter_agree_with_oracle(space, d, nq, n, nar
     assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"narrow={narrow}/{space}/d{d}/nq{nq}")
 
 
-@pytest.mark.parametrize("variant", SCAN_VARIANTS, ids=lambda v: ",".join(f"{k[11:]}={x}" for k, x in v.items()))
+@pytest.mark.parametrize("variant", SCAN_VARIANTS, ids=lambda v: ",".join(f"{k[6:]}={x}" for k, x in v.items()) or "default")
 @pytest.mark.parametrize("space,d", [("cosine", 128), ("l2", 192), ("ip", 64), ("cosine", 768), ("l2", 1536)])
 def test_scan_kernel_variants_agree_with_oracle(variant, space, d, monkeypatch):
     """Every generated geometry of the filter scan (the variable is read per launch), on corpora with more
@@ -298,6 +299,7 @@ def test_scan_kernel_variants_agree_with_oracle(variant, space, d, monkeypatch):
     deleted = deleted_mask(7, n, 0.05)
     got, stats = run_hip(rows, qs, 10, space, "filter", deleted, append_chunks=3)
     assert stats["strategy_used"] == 2 and stats["fallback_queries"] == 0
+    assert stats["bound_dtype"] == (2 if space == "cosine" and d % 256 == 0 and variant.get("MLVDB_I8") != "0" else 1)
     assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"variant {variant}/{space}/d{d}")
 
 
@@ -385,3 +387,44 @@ def test_save_index_load_index_round_trip_on_device(tmp_path, monkeypatch):
     one = b.search(VectorDTO(values=rows[5], metadata={}), 1, "ns", "cosine")[0]
     assert one.vector_id == vs[5].id
     b.close()
+
+
+@pytest.mark.parametrize("d,nq,k", [(768, 40, 10), (256, 256, 64), (1536, 7, 1)])
+def test_int8_shadow_follows_appends_tombstones_compaction_and_masks(d, nq, k):
+    """The int8 shadow of a cosine index is maintained lazily: rows appended, tombstoned or compacted away after a
+    search must be reflected in the next one (ids == oracle each time); a row-mask search falls back to bf16."""
+    n = 30_000
+    rows, qs = make_case(900 + d, n, d, nq, dup=True)
+    eng = HipScanEngine(d, "cosine", device=0, strategy="filter")
+    try:
+        eng.append(rows[:20_000])
+        got = eng.search(qs, k)
+        assert eng.last_stats()["bound_dtype"] == 2
+        assert_knn_matches(got, oracle_knn(qs, rows[:20_000], k, "cosine"), "i8/first")
+        eng.append(rows[20_000:])  # not a multiple of the panel: the shared panel is rewritten
+        deleted = deleted_mask(3, n, 0.1)
+        eng.tombstone(np.nonzero(deleted)[0])
+        got = eng.search(qs, k)
+        assert eng.last_stats()["bound_dtype"] == 2 and eng.last_stats()["fallback_queries"] == 0
+        assert_knn_matches(got, oracle_knn(qs, rows, k, "cosine", deleted), "i8/append+tombstone")
+        # tombstone the current best hit of every query: it must disappear
+        best = np.unique(got[0][:, 0])
+        deleted[best] = True
+        eng.tombstone(best)
+        got = eng.search(qs, k)
+        assert_knn_matches(got, oracle_knn(qs, rows, k, "cosine", deleted), "i8/tombstoned best")
+        mask = (np.arange(n) % 3 != 0).astype(np.uint8)
+        got = eng.search(qs, k, mask=mask)
+        assert eng.last_stats()["bound_dtype"] == 1
+        assert_knn_matches(got, oracle_knn(qs, rows, k, "cosine", deleted | (mask == 0)), "i8/mask")
+        old = eng.compact()
+        live = rows[old]
+        got = eng.search(qs, k)
+        assert eng.last_stats()["bound_dtype"] == 2
+        assert_knn_matches(got, oracle_knn(qs, live, k, "cosine"), "i8/compacted")
+        eng.reset()
+        eng.append(rows[5_000:9_000])
+        got = eng.search(qs, k)
+        assert_knn_matches(got, oracle_knn(qs, rows[5_000:9_000], k, "cosine"), "i8/reset")
+    finally:
+        eng.close()
