@@ -9,7 +9,7 @@ GPU, every rank holds 10M rows (weak scaling; N=8 is configs[4], 80M rows, batch
 its shard for the whole query wave, and rank 0 merges the per-shard top-k on the host.
 
 A step = one query wave through the hot path with queries and corpus resident in HBM:
-query prep -> bf16-MFMA filter scan of the shard -> threshold updates -> exact fp64 rescoring
+query prep -> int8- (cosine) or bf16-MFMA filter scan of the shard -> threshold updates -> exact fp64 rescoring
 (-> gather + host merge when N>1).  Prints ONE JSON line (rank 0).  roofline.achieved: algorithmic
 bytes of the scan launches / their HIP-event durations (events around filter_scan_asm_kernel only).
 """
@@ -264,7 +264,8 @@ def main() -> None:
     if scan_ms > 0:
         achieved = alg_bytes_scan / (scan_ms * 1e-3) / 1e9
         traffic = None
-        tfile = ROOT / "profiles" / "r01" / "pmc_traffic.json"
+        i8 = stats0.get("bound_dtype") == 2  # the int8 shadow computed the bounds (cosine, dim % 256 == 0)
+        tfile = ROOT / "profiles" / "r01" / ("pmc_traffic_i8.json" if i8 else "pmc_traffic.json")
         if stats0["strategy_used"] == 2 and n_local == 10_000_000 and d == 768 and tfile.exists():
             # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
             # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); counters cannot be read from inside the process
@@ -272,9 +273,11 @@ def main() -> None:
         flops = 2.0 * float(rows_scanned) * d * 256 * passes
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc, separate passes)" if traffic else None,
+                    "traffic_source": f"profiles/r01/{tfile.name} (rocprofv3 --pmc, separate passes)" if traffic else None,
                     "hbm_actual_frac": round(traffic * scan_launches / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                    "mfma_bf16_frac": round(flops / (scan_ms * 1e-3) / 2.5e15, 4) if stats0["strategy_used"] == 2 else None,
+                    # matrix-core rate of the scan against the dense peak of its operand type (bf16 2.5 PFLOP/s, int8 5 POP/s)
+                    "mfma_dtype": ("i8" if i8 else "bf16") if stats0["strategy_used"] == 2 else None,
+                    "mfma_frac": round(flops / (scan_ms * 1e-3) / (5.0e15 if i8 else 2.5e15), 4) if stats0["strategy_used"] == 2 else None,
                     "kernel": "filter_scan_asm_kernel" if stats0["strategy_used"] == 2 else "exact_scan_kernel",
                     "avg_launch_ms": round(scan_ms / max(1, scan_launches), 4), "launches": scan_launches,
                     "alg_bytes_per_launch": round(alg_bytes_scan / max(1, scan_launches)),
@@ -292,11 +295,12 @@ def main() -> None:
         "unit": "queries/s (each query scanned against one 10M-row shard; whole-corpus QPS = value / n_gpus)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 (MFMA bounds) + f64 (exact rescoring of the f32 rows)",
+        "dtype": (("i8" if stats0.get("bound_dtype") == 2 else "bf16") + " (MFMA bounds) + f64 (exact rescoring of the f32 rows)")
+                 if stats0["strategy_used"] == 2 else "f64 (exact scan of the f32 rows)",
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[{2 if world == 1 else 4}]: {world * n_local} x {d} fp32 N(0,1) "
                                f"rows ({n_local}/GPU), {args.space} kNN k={k}, batch={batch}, exact ids "
-                               f"(bf16-MFMA bound filter + fp64 rescoring)",
+                               f"({'int8' if stats0.get('bound_dtype') == 2 else 'bf16'}-MFMA bound filter + fp64 rescoring)",
                    "rows_per_gpu": n_local, "dim": d, "k": k, "batch": batch, "space": args.space,
                    "tombstoned_fraction": args.tombstones,
                    "strategy": {1: "exact", 2: "filter"}.get(stats0["strategy_used"], "?"),

@@ -57,7 +57,7 @@ extern "C" {
 /* search strategy (mlvdb_index_set_strategy); AUTO picks per call */
 #define MLVDB_STRATEGY_AUTO 0
 #define MLVDB_STRATEGY_EXACT 1   /* fp64 streaming scan only */
-#define MLVDB_STRATEGY_FILTER 2  /* bf16-MFMA bound filter + exact fp64 rescoring (falls back to EXACT per query) */
+#define MLVDB_STRATEGY_FILTER 2  /* int8- or bf16-MFMA bound filter + exact fp64 rescoring (falls back to EXACT per query) */
 
 typedef struct mlvdb_index mlvdb_index;
 
