@@ -24,6 +24,7 @@
 //   ip      s = <q^,x>                   = (1 - dist)/|q|
 //   l2      s = 2|q|<q^,x> - |x|^2       = |q|^2 - dist
 #include <cstdlib>
+#include <type_traits>
 
 #include "internal.h"
 #include "scan_common.h"
@@ -32,6 +33,7 @@ namespace mlvdb {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void filter_range_thr_kernel(const FilterArgs 
 // Tile finished: bounds, admission test, rare appends.  acc[m][n] = bf16 dot products of this
 // lane's rows (16 m + 4 g + i, i = register component) with query 16 n + c16; rnv[m] = |x| of the rows;
 // row0 = first of this lane's rows; dump = this lane's column of a [4*kMT][64] LDS scratch per wave.
-template <int SPACE, int kMT, bool DENSE, int NQT = 16>
+template <int SPACE, int kMT, bool DENSE, int NQT = 16, bool I8 = false>
 __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (&acc)[kMT][NQT], const float4 (&rnv)[kMT],
                                               const int32_t row0, const int32_t base_row,
                                               const float* thr_l, const float* sq_l, const float* ke_l, float* dump,
@@ -167,7 +169,10 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
         const float nr[4] = {rnv[m].x, rnv[m].y, rnv[m].z, rnv[m].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (SPACE == kSpaceCosine) {
+            if (I8) {  // int8 shadow (cosine): acc = float(integer dot), rnv = rp8 = sx/(|x|+1e-30), sq = the query's scale
+                p0[m][i] = nr[i];
+                p1[m][i] = 0.f;
+            } else if (SPACE == kSpaceCosine) {
                 p0[m][i] = 1.0f / (nr[i] + 1e-30f);
                 p1[m][i] = 0.f;
             } else {
@@ -178,6 +183,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
     }
     auto bound = [&](int m, int i, int n, float sq, float ke) __attribute__((always_inline)) {
         const float av = acc[m][n][i];
+        if (I8) return __builtin_fmaf(av * p0[m][i], sq, ke);
         if (SPACE == kSpaceCosine) return __builtin_fmaf(av, p0[m][i], ke);
         if (SPACE == kSpaceIp) return __builtin_fmaf(ke, p0[m][i], av);
         return __builtin_fmaf(sq, __builtin_fmaf(ke, p0[m][i], av), p1[m][i]);
@@ -187,7 +193,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
         // lists, slot = row - first row of the pass (the caller sets cnt and runs the update kernel)
 #pragma unroll
         for (int n = 0; n < NQT; ++n) {
-            const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
+            const float sq = (SPACE == kSpaceL2 || I8) ? sq_l[16 * n + c16] : 1.0f;
             const float ke = ke_l[16 * n + c16];
             CandEntry* dst = a.cand + (int64_t)(16 * n + c16) * kCandCap + (row0 - base_row);
 #pragma unroll
@@ -210,7 +216,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
     for (int n = 0; n < NQT; ++n) {
         __builtin_amdgcn_sched_barrier(0);  // keep only one query tile's scores live at a time
         const float thr = thr_l[16 * n + c16];
-        const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
+        const float sq = (SPACE == kSpaceL2 || I8) ? sq_l[16 * n + c16] : 1.0f;
         const float ke = ke_l[16 * n + c16];
         float mx = -3.4e38f;
 #pragma unroll
@@ -231,7 +237,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
 #pragma unroll
     for (int n = 0; n < NQT; ++n) {
         if (__ballot((packed[n] & 0xfffu) != 0)) {
-            const float sq = SPACE == kSpaceL2 ? sq_l[16 * n + c16] : 1.0f;
+            const float sq = (SPACE == kSpaceL2 || I8) ? sq_l[16 * n + c16] : 1.0f;
             const float ke = ke_l[16 * n + c16];
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
@@ -447,14 +453,15 @@ __global__ __launch_bounds__(256, 2) void filter_scan_kernel(const FilterArgs a,
 // HBM-bound at HALF the bytes of the exact fp32 scan.  Same bounds, admission test, candidate lists
 // and rescoring as the 256-query kernels, so the ids are the exact ones here too.
 // One workgroup = NW waves = one 32*NW-row tile; wave w owns panels 2w, 2w+1 (NW = 8; 4 for the seeding pass).
-template <int SPACE, int NQT, bool DENSE, int R, int NW>
+template <int SPACE, int NQT, bool DENSE, int R, int NW, bool I8>
 __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const FilterArgs a, const int64_t tile_begin,
                                                                      const int64_t tile_end) {
     constexpr int kMT = 2;  // panels per wave; R = k-steps in flight per wave, NW = waves
+    // I8: the int8 shadow of a cosine index (k-steps of 64 int8 columns, integer accumulators, rp8 row constants)
     constexpr int kFilterTileRows = NW * 16 * kMT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ld = a.ld;
-    const int nsteps = ld / 32;  // a multiple of R (ld is a multiple of 64; the launcher picks R = 4 or 2)
+    const int nsteps = I8 ? ld / 64 : ld / 32;  // a multiple of R (the launcher picks R = 4 or 2)
     uint4* qlds = reinterpret_cast<uint4*>(smem);  // [nsteps][NQT][64]
     float* thr_l = reinterpret_cast<float*>(smem + (size_t)nsteps * NQT * 1024);  // [256]
     float* sq_l = thr_l + kFilterQueries;
@@ -470,12 +477,12 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
     if (my_tiles == 0) return;
     if (threadIdx.x < kFilterQueries) {
         thr_l[threadIdx.x] = a.thr[threadIdx.x];
-        sq_l[threadIdx.x] = a.qscale[threadIdx.x];
+        sq_l[threadIdx.x] = I8 ? a.sq8[threadIdx.x] : a.qscale[threadIdx.x];
         ke_l[threadIdx.x] = a.ke[threadIdx.x];
     }
     // query image (filter_prep_kernel's [kc][n][ks][lane] order) -> LDS [2kc+ks][n < NQT][lane]
     {
-        const uint4* qimg = reinterpret_cast<const uint4*>(a.qimg);
+        const uint4* qimg = reinterpret_cast<const uint4*>(I8 ? a.qimg8 : a.qimg);
         for (int v = threadIdx.x; v < nsteps * NQT * 64; v += NW * 64) {
             const int l = v & 63, n = (v >> 6) % NQT, st = (v >> 6) / NQT;
             qlds[v] = qimg[(((st >> 1) * 16 + n) * 2 + (st & 1)) * 64 + l];
@@ -483,13 +490,13 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
     }
     __syncthreads();
 
-    f32x4 acc[kMT][NQT];
+    typename std::conditional<I8, i32x4, f32x4>::type acc[kMT][NQT];
     float4 xr[R][kMT];
     float4 rnv[kMT];
-    const uint32_t panel_bytes = (uint32_t)ld * 32;  // 16 rows of bf16
+    const uint32_t panel_bytes = (uint32_t)ld * (I8 ? 16 : 32);  // 16 rows of int8 / bf16
     const uint32_t wave_bytes = kMT * panel_bytes;
     const uint64_t tile_stride_bytes = (uint64_t)gridDim.x * (NW * wave_bytes);
-    const char* pre_base = reinterpret_cast<const char*>(a.Xb) + (uint64_t)(tile_begin + blockIdx.x) * (NW * wave_bytes) +
+    const char* pre_base = reinterpret_cast<const char*>(I8 ? a.X8 : a.Xb) + (uint64_t)(tile_begin + blockIdx.x) * (NW * wave_bytes) +
                            (uint64_t)wave * wave_bytes;
     uint32_t pre_soff = 0;
     int64_t pre_tiles_left = my_tiles - 1;
@@ -513,31 +520,45 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
 
     for (int64_t ti = 0; ti < my_tiles; ++ti) {
         const int64_t tile = tile_begin + blockIdx.x + ti * gridDim.x;
-        const __amdgpu_buffer_rsrc_t rn_rsrc = make_rsrc(a.rn + tile * kFilterTileRows + wave * (16 * kMT), 16 * kMT * 4);
+        const __amdgpu_buffer_rsrc_t rn_rsrc = make_rsrc((I8 ? a.rp8 : a.rn) + tile * kFilterTileRows + wave * (16 * kMT), 16 * kMT * 4);
 #pragma unroll
         for (int m = 0; m < kMT; ++m) rnv[m] = buf_load_f4(rn_rsrc, g * 16, m * 64);
 #pragma unroll
         for (int m = 0; m < kMT; ++m)
 #pragma unroll
-            for (int n = 0; n < NQT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int n = 0; n < NQT; ++n) acc[m][n] = {0, 0, 0, 0};
         for (int st = 0; st < nsteps; st += R) {
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                bf16x8 xa[kMT];
+                float4 xa[kMT];
 #pragma unroll
-                for (int m = 0; m < kMT; ++m) xa[m] = __builtin_bit_cast(bf16x8, xr[j][m]);
+                for (int m = 0; m < kMT; ++m) xa[m] = xr[j][m];
                 load_x(xr[j]);
                 const uint4* qb = qlds + (size_t)(st + j) * (NQT * 64) + lane;
 #pragma unroll
                 for (int n = 0; n < NQT; ++n) {
-                    const bf16x8 qf = __builtin_bit_cast(bf16x8, qb[n * 64]);
+                    const uint4 qf = qb[n * 64];
 #pragma unroll
-                    for (int m = 0; m < kMT; ++m)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[m], qf, acc[m][n], 0, 0, 0);
+                    for (int m = 0; m < kMT; ++m) {
+                        if constexpr (I8)
+                            acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, xa[m]), __builtin_bit_cast(i32x4, qf),
+                                                                              acc[m][n], 0, 0, 0);
+                        else
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xa[m]),
+                                                                                __builtin_bit_cast(bf16x8, qf), acc[m][n], 0, 0, 0);
+                    }
                 }
             }
         }
-        scan_epilogue<SPACE, kMT, DENSE, NQT>(a, acc, rnv, (int32_t)(tile * kFilterTileRows) + wave * (16 * kMT) + g * 4,
+        f32x4 accf[kMT][NQT];
+#pragma unroll
+        for (int m = 0; m < kMT; ++m)
+#pragma unroll
+            for (int n = 0; n < NQT; ++n) {
+                if constexpr (I8) accf[m][n] = __builtin_convertvector(acc[m][n], f32x4);  // |I| < 2^24 for d <= 1040: exact; beyond: 1 ulp, inside the slack
+                else accf[m][n] = acc[m][n];
+            }
+        scan_epilogue<SPACE, kMT, DENSE, NQT, I8>(a, accf, rnv, (int32_t)(tile * kFilterTileRows) + wave * (16 * kMT) + g * 4,
                                               (int32_t)(tile_begin * kFilterTileRows), thr_l, sq_l, ke_l,
                                               hit_l + wave * (4 * kMT * 64) + lane, c16);
     }
@@ -1372,21 +1393,24 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
 constexpr int kNarrowMaxQueries = 64;
 constexpr size_t kNarrowLdsMax = 152 * 1024;
 static int narrow_nqt(int nq) { return nq <= 16 ? 1 : (nq <= 32 ? 2 : 4); }
-static size_t narrow_lds(int32_t ld, int nqt, int nw) {
-    return (size_t)(ld / 32) * nqt * 1024 + 3 * kFilterQueries * sizeof(float) + (size_t)nw * 4 * 2 * 64 * sizeof(float);
+static size_t narrow_lds(int32_t ld, int nqt, int nw, bool i8 = false) {
+    return (size_t)(ld / (i8 ? 64 : 32)) * nqt * 1024 + 3 * kFilterQueries * sizeof(float) + (size_t)nw * 4 * 2 * 64 * sizeof(float);
 }
 bool filter_narrow_ok(const FilterArgs& a) {
     if (!a.Xb || a.nq > kNarrowMaxQueries) return false;
     if (env_int("MLVDB_SCAN_NARROW", 1) == 0) return false;
-    return narrow_lds(a.ld, narrow_nqt(a.nq), 8) <= kNarrowLdsMax;
+    // int8 bounds admit ~7x more rows than bf16 ones and this kernel appends them one atomic at a time: beyond 8
+    // queries the 256-query body (appends staged per wave) is faster (profiles/r01/small_batch_ab_10m_i8.txt)
+    if (a.X8 && a.nq > 8) return false;
+    return narrow_lds(a.ld, narrow_nqt(a.nq), 8, a.X8 != nullptr) <= kNarrowLdsMax;
 }
-template <int SPACE, int NQT, bool DENSE, int R, int NW>
+template <int SPACE, int NQT, bool DENSE, int R, int NW, bool I8 = false>
 static hipError_t launch_scan_narrow_n(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
     constexpr int tile_rows = NW * 32;
     const int64_t tile_begin = row_begin / tile_rows;
     const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
     if (tile_end <= tile_begin) return hipSuccess;
-    const size_t lds = narrow_lds(a.ld, NQT, NW);
+    const size_t lds = narrow_lds(a.ld, NQT, NW, I8);
     const int64_t ntiles = tile_end - tile_begin;
     const int per_cu = (int)std::min<size_t>(32 / NW, (160 * 1024) / lds);  // workgroups resident per CU
     const int max_grid = 256 * env_int("MLVDB_NARROW_WGS", per_cu);
@@ -1394,7 +1418,7 @@ static hipError_t launch_scan_narrow_n(const FilterArgs& a, int64_t row_begin, i
     const int64_t rounds = (ntiles + max_grid - 1) / max_grid;
     const int grid = env_int("MLVDB_NARROW_BALANCE", 1) ? (int)((ntiles + rounds - 1) / rounds)
                                                         : (int)(ntiles < max_grid ? ntiles : max_grid);
-    auto kern = filter_scan_narrow_kernel<SPACE, NQT, DENSE, R, NW>;
+    auto kern = filter_scan_narrow_kernel<SPACE, NQT, DENSE, R, NW, I8>;
     static bool configured = false;  // per instantiation
     if (!configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1407,6 +1431,12 @@ static hipError_t launch_scan_narrow_n(const FilterArgs& a, int64_t row_begin, i
 }
 template <int SPACE, int NQT, bool DENSE>
 static hipError_t launch_scan_narrow_q(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
+    if constexpr (SPACE == kSpaceCosine) {
+        if (a.X8) {  // int8 shadow: k-steps of 64 columns; ld % 256 == 0, so their count is a multiple of 4
+            if constexpr (DENSE) return launch_scan_narrow_n<SPACE, NQT, true, 4, 4, true>(a, row_begin, row_end, s);
+            else return launch_scan_narrow_n<SPACE, NQT, false, 4, 8, true>(a, row_begin, row_end, s);
+        }
+    }
     const bool r4 = (a.ld / 32) % 4 == 0;
     if constexpr (DENSE) {  // the seeding pass is a few tiles: one geometry
         return r4 ? launch_scan_narrow_n<SPACE, NQT, true, 4, 4>(a, row_begin, row_end, s)
@@ -1458,7 +1488,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
 template <int SPACE>
 static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info) {
     const int nkc = a.ld / kFilterChunkK;
-    if (filter_narrow_ok(a) && !a.X8) return launch_scan_narrow<SPACE, false>(a, row_begin, row_end, s);  // appends to the lists itself
+    if (filter_narrow_ok(a)) return launch_scan_narrow<SPACE, false>(a, row_begin, row_end, s);  // appends to the lists itself
     if (a.Xb && env_int("MLVDB_SCAN_ASM", 1)) {
         // hand-written body (tools/gen_scan_asm.py).  Default: one 8-wave workgroup per CU (256-row tiles:
         // the query image is staged once per CU, by LDS-DMA), non-temporal X loads, ring of 4 k-steps -- measured
