@@ -56,6 +56,39 @@ def parse_args():
     return ap.parse_args()
 
 
+def config1_side(device: int) -> dict:
+    """BASELINE configs[0]: 10k x 128 random vectors, cosine k=5, batch 1 through QueryProcessor.find_similar
+    (reference query_processor.py:19-49): the same Protocol-level flow on the HIP engine and, as the CPU baseline of
+    this config, on the NumPy oracle engine (the reference itself cannot run: hnswlib is absent).  Part of the
+    cpu_baseline leg (rank 0, N=1)."""
+    from mlvectordb_amd import Index, InMemoryStorage, QueryProcessor, VectorDTO
+    from oracle.engine import OracleScanEngine
+
+    n, d, k, nq = 10_000, 128, 5, 120
+    rows = np.random.default_rng(1234).standard_normal((n, d), dtype=np.float32)
+    queries = np.random.default_rng(4321).standard_normal((nq, d), dtype=np.float32)
+
+    def run(index):
+        qp = QueryProcessor(InMemoryStorage(), index)
+        qp.upsert_many([VectorDTO(values=r, metadata={"i": i}) for i, r in enumerate(rows)], namespace="bench")
+        lat, out = [], []
+        for i in range(nq):
+            t0 = time.perf_counter()
+            hits = qp.find_similar(VectorDTO(values=queries[i], metadata={}), top_k=k, namespace="bench", metric="cosine")
+            lat.append(time.perf_counter() - t0)
+            out.append([(h["metadata"]["i"], h["score"]) for h in hits])
+        index.close()
+        lat = np.array(lat[20:])
+        return {"p50_ms": round(float(np.median(lat)) * 1e3, 4), "qps": round(1.0 / float(np.mean(lat)), 1)}, out
+
+    res = {}
+    res["hip"], got = run(Index(space="cosine", device=device))
+    res["cpu_numpy_oracle_engine"], want = run(Index(space="cosine", engine_factory=OracleScanEngine))
+    res["ids_equal"] = all([g[0] for g in a] == [w[0] for w in b] for a, b in zip(got, want))
+    res["max_abs_score_err"] = float(max(abs(g[1] - w[1]) for a, b in zip(got, want) for g, w in zip(a, b)))
+    return res
+
+
 def main() -> None:
     args = parse_args()
     # stdout carries exactly one JSON line: libraries that print there (gloo's rendezvous banner does) go to stderr
@@ -374,6 +407,8 @@ def main() -> None:
             e2.close()
             side["ids_equal"] = bool((ids["auto"] == ids["exact"]).all())
             out["config2_1Mx768_batch1"] = side
+        if not args.no_extras:
+            out["config1_10kx128_find_similar"] = config1_side(local_rank)
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:

@@ -63,6 +63,7 @@ struct mlvdb_index {
     // experimental int8 shadow (MLVDB_I8=1, cosine, ld % 256 == 0): built lazily at search time, rebuilt after any mutation
     DevBuf x8, rp8, rowerr8, qimg8, sq8;
     int64_t i8_rows = 0;      // rows [0, i8_rows) of the int8 shadow are current (0 after compact / reset / regrowth)
+    float i8_err = 0.f;       // host copy of rowerr8 (read back whenever rows were converted)
     bool mask_active = false;  // h->rn is a masked copy (mlvdb_search_batch_filtered): the int8 rp8 knows no masks
     DevBuf qimg, fmisc, cand, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, counters, labels_in;
     DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
@@ -327,7 +328,13 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
         HIP_TRY(h, launch_shadow8_rows(h->X, h->rn, h->x8.p, h->rp8.as<float>(), h->rowerr8.as<float>(), h->i8_rows, h->total,
                                        h->ld, s));
         h->i8_rows = h->total;
+        HIP_TRY(h, hipMemcpyAsync(&h->i8_err, h->rowerr8.p, sizeof(float), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
     }
+    // One scale per row: a row with an outlier component quantises badly, and the index-wide error term would then
+    // admit everything.  Typical data sits at 0.008-0.015; beyond 0.03 the bf16 shadow (error relative per component)
+    // gives the tighter bounds.
+    if (!(h->i8_err <= 0.03f)) return MLVDB_OK;
     HIP_TRY(h, h->qimg8.ensure((size_t)kFilterQueries * h->ld));
     HIP_TRY(h, h->sq8.ensure(kFilterQueries * sizeof(float)));
     fa.X8 = h->x8.p;

@@ -428,3 +428,20 @@ def test_int8_shadow_follows_appends_tombstones_compaction_and_masks(d, nq, k):
         assert_knn_matches(got, oracle_knn(qs, rows[5_000:9_000], k, "cosine"), "i8/reset")
     finally:
         eng.close()
+
+
+def test_int8_shadow_steps_aside_for_rows_with_outlier_components():
+    """One scale per row: a row dominated by one huge component has a large int8 error; the index then keeps to the
+    bf16 bounds (relative per component) instead of admitting everything -- same ids either way."""
+    rows, qs = make_case(77, 20_000, 768, 24)
+    rows[123, 5] = 4000.0
+    rows[9_000, 700] = -2500.0
+    eng = HipScanEngine(768, "cosine", device=0, strategy="filter")
+    try:
+        eng.append(rows)
+        got = eng.search(qs, 10)
+        st = eng.last_stats()
+        assert st["bound_dtype"] == 1 and st["fallback_queries"] == 0
+        assert_knn_matches(got, oracle_knn(qs, rows, 10, "cosine"), "i8/outliers")
+    finally:
+        eng.close()
