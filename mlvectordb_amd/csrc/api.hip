@@ -306,13 +306,13 @@ int collect_overflow(mlvdb_index* h, hipStream_t s, const FilterArgs& fa, int32_
 // start it over.  MLVDB_I8=0 keeps the pass on the bf16 shadow.
 __global__ void tombstone_rp8_kernel(const int64_t* labels, int64_t n, float* rp8, int64_t rows) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && labels[i] >= 0 && labels[i] < rows) rp8[labels[i]] = __builtin_nanf("");
+    if (i < n && labels[i] >= 0 && labels[i] < rows) rp8[2 * labels[i]] = rp8[2 * labels[i] + 1] = __builtin_nanf("");
 }
 
 int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
     const char* env = getenv("MLVDB_I8");  // read per pass: tools/scan_ab.py switches it inside one process
-    if ((env && env[0] == '0') || h->space != kSpaceCosine || !h->Xb || h->ld % 256 != 0 || h->mask_active) return MLVDB_OK;
-    const size_t need_x8 = (size_t)h->capacity * h->ld, need_rp = (size_t)h->capacity * sizeof(float);
+    if ((env && env[0] == '0') || !h->Xb || h->ld % 256 != 0 || h->mask_active) return MLVDB_OK;
+    const size_t need_x8 = (size_t)h->capacity * h->ld, need_rp = (size_t)h->capacity * 2 * sizeof(float);
     if (h->x8.bytes < need_x8 || h->rp8.bytes < need_rp || !h->rowerr8.p) {
         HIP_TRY(h, h->x8.ensure(need_x8));
         HIP_TRY(h, h->rp8.ensure(need_rp));
@@ -326,7 +326,7 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
     }
     if (h->i8_rows < h->total) {
         HIP_TRY(h, launch_shadow8_rows(h->X, h->rn, h->x8.p, h->rp8.as<float>(), h->rowerr8.as<float>(), h->i8_rows, h->total,
-                                       h->ld, s));
+                                       h->ld, h->space, s));
         h->i8_rows = h->total;
         HIP_TRY(h, hipMemcpyAsync(&h->i8_err, h->rowerr8.p, sizeof(float), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));

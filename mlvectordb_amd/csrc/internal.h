@@ -123,7 +123,7 @@ struct FilterArgs {
     CandEntry* cand;        // [256][kCandCap]
     // int8 shadow (cosine, ld % 256 == 0; MLVDB_I8=0 disables): all null / unused otherwise
     const void* X8;         // int8 rows, per-row scale: panels of 16 rows, 64-column groups of 1 KiB (layout_offset_i8)
-    const float* rp8;       // [rows] scale / (|x| + 1e-30): float(int dot) * rp8 * sq8 = bound of the cosine; NaN = tombstoned
+    const float* rp8;       // [rows][2] cosine {scale/(|x|+1e-30), row error}, l2 / ip {scale, |x|}; NaN = tombstoned
     const float* row_err8;  // device scalar: max over rows of |x - scale * x8| / |x| (rounded up)
     void* qimg8;            // int8 query image
     float* sq8;             // [256] scale of the query image
@@ -139,12 +139,12 @@ struct ScanInfo {
     int scatter_grid = 0;  // 0: nothing to scatter
     int nw = 0;
     int dbg = 0;
-    int i8 = 0;  // entries hold w = float(int dot) * rp8: the scatter turns them into bounds
+    int i8 = 0;  // int8 scan, entries in units of the query's scale: 1 cosine (u = w sq8 + ke), 2 ip (u = w sq8)
 };
 // int8 shadow: (re)build the panels covering rows [row_begin, row_end) (also rp8 and the index-wide error), the query image of a
 // pass (after launch_filter_prep: overrides ke with the int8 error term), exact thresholds from the k best bounds
 hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t row_begin,
-                               int64_t row_end, int32_t ld, hipStream_t s);
+                               int64_t row_end, int32_t ld, int32_t space, hipStream_t s);
 hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s);
 hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s);
 hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info);

@@ -111,6 +111,9 @@ __device__ __forceinline__ float float_below(double v) {
     return f;
 }
 
+// round a double up to a float that is >= it
+__device__ __forceinline__ float float_above(double v) { return -float_below(-v); }
+
 // thr[q] from the exact distance of the k-th nearest seed row
 __global__ __launch_bounds__(256) void filter_seed_thr_kernel(const FilterArgs a, const double* seed_d64, int32_t k) {
     const int q = threadIdx.x;
@@ -520,9 +523,17 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
 
     for (int64_t ti = 0; ti < my_tiles; ++ti) {
         const int64_t tile = tile_begin + blockIdx.x + ti * gridDim.x;
-        const __amdgpu_buffer_rsrc_t rn_rsrc = make_rsrc((I8 ? a.rp8 : a.rn) + tile * kFilterTileRows + wave * (16 * kMT), 16 * kMT * 4);
+        const __amdgpu_buffer_rsrc_t rn_rsrc = I8 ? make_rsrc(a.rp8 + 2 * (tile * kFilterTileRows + wave * (16 * kMT)), 16 * kMT * 8)
+                                                   : make_rsrc(a.rn + tile * kFilterTileRows + wave * (16 * kMT), 16 * kMT * 4);
 #pragma unroll
-        for (int m = 0; m < kMT; ++m) rnv[m] = buf_load_f4(rn_rsrc, g * 16, m * 64);
+        for (int m = 0; m < kMT; ++m) {
+            if constexpr (I8) {  // pairs per row: keep the first components (sx/(|x|+1e-30))
+                const float4 lo = buf_load_f4(rn_rsrc, g * 32, m * 128), hi = buf_load_f4(rn_rsrc, g * 32 + 16, m * 128);
+                rnv[m] = make_float4(lo.x, lo.z, hi.x, hi.z);
+            } else {
+                rnv[m] = buf_load_f4(rn_rsrc, g * 16, m * 64);
+            }
+        }
 #pragma unroll
         for (int m = 0; m < kMT; ++m)
 #pragma unroll
@@ -610,7 +621,8 @@ __global__ __launch_bounds__(256) void filter_scatter_kernel(const FilterArgs a,
             const uint32_t slot = base[q] + atomicAdd(&hist[q], 1u);
             if (slot < (uint32_t)kCandCap) {
                 CandEntry e;
-                e.u = i8 ? __builtin_fmaf(bu[i], a.sq8[q], a.ke[q]) : bu[i];  // int8 scan: w = float(I) * rp8 -> bound
+                // int8 scan: the stored value is in units of the query's scale (cosine: w, ip: w + ke' |x|)
+                e.u = i8 == 1 ? __builtin_fmaf(bu[i], a.sq8[q], a.ke[q]) : (i8 == 2 ? bu[i] * a.sq8[q] : bu[i]);
                 e.row = br[i];
                 a.cand[(size_t)q * kCandCap + slot] = e;
             }
@@ -652,16 +664,27 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     const int c16 = lane & 15;
     const int nkc = I8 ? a.ld / (2 * kFilterChunkK) : a.ld / kFilterChunkK;
     for (int t = threadIdx.x; t < kFilterQueries; t += kThreads) {
-        float thr = a.thr[t];
+        float thr = a.thr[t], sqv = a.qscale[t], kev = a.ke[t];
         if (I8) {
-            // the assembly tests float(I) * rp8 >= T: u = w*sq8 + ke >= thr  <=>  w >= (thr - ke)/sq8, rounded down
-            if (thr > 1.0e30f) thr = 3.4e38f;
-            else if (thr < -1.0e30f) thr = -3.4e38f;
-            else thr = float_below(((double)thr - (double)a.ke[t]) / (double)a.sq8[t]);
+            // the assembly computes w = float(I) * (row scale term); the per-query constants are rescaled by sq8 here
+            const double sq8 = (double)a.sq8[t];
+            if (SPACE == kSpaceCosine) {  // w >= T:  u = w*sq8 + ke >= thr  <=>  w >= (thr - ke)/sq8, rounded down
+                if (thr > 1.0e30f) thr = 3.4e38f;
+                else if (thr < -1.0e30f) thr = -3.4e38f;
+                else thr = float_below(((double)thr - (double)kev) / sq8);
+            } else if (SPACE == kSpaceIp) {  // w + ke' |x| >= thr/sq8  (the scatter multiplies the stored value by sq8)
+                if (thr > 1.0e30f) thr = 3.4e38f;
+                else if (thr < -1.0e30f) thr = -3.4e38f;
+                else thr = float_below((double)thr / sq8);
+                kev = float_above((double)kev / sq8);
+            } else {  // l2: sq' (w + ke' |x|) + p1 >= thr with sq' = 2|q| sq8
+                kev = float_above((double)kev / sq8);
+                sqv = sqv * a.sq8[t];
+            }
         }
         thr_l[t] = thr;
-        sq_l[t] = a.qscale[t];
-        ke_l[t] = a.ke[t];
+        sq_l[t] = sqv;
+        ke_l[t] = kev;
     }
     const int64_t ntiles_all = tile_end - tile_begin;
     const int64_t my_tiles = ntiles_all > blockIdx.x ? (ntiles_all - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
@@ -676,11 +699,12 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     const int64_t first_tile = tile_begin + blockIdx.x;
     const uint64_t xbase = reinterpret_cast<uint64_t>(I8 ? a.X8 : a.Xb) + (uint64_t)first_tile * tile_bytes + (uint64_t)wave * wbytes;
     const uint64_t xstride = (uint64_t)gridDim.x * tile_bytes;
-    const uint64_t rnbase = reinterpret_cast<uint64_t>((I8 ? a.rp8 : a.rn) + first_tile * kTileRowsV + wave * kWaveRows);
+    const uint64_t rnbase = reinterpret_cast<uint64_t>(I8 ? a.rp8 + 2 * (first_tile * kTileRowsV + wave * kWaveRows)  // pairs per row
+                                                          : a.rn + first_tile * kTileRowsV + wave * kWaveRows);
     const uint32_t xlo = (uint32_t)xbase, xhi = (uint32_t)(xbase >> 32) & 0xffffu;
     const uint32_t xslo = (uint32_t)xstride, xshi = (uint32_t)(xstride >> 32);
     const uint32_t rnlo = (uint32_t)rnbase, rnhi = (uint32_t)(rnbase >> 32) & 0xffffu;
-    const uint32_t rnstride = gridDim.x * (uint32_t)(kTileRowsV * 4);
+    const uint32_t rnstride = gridDim.x * (uint32_t)(kTileRowsV * (I8 ? 8 : 4));
     const uint32_t row0 = (uint32_t)(first_tile * kTileRowsV);
     const uint32_t rowstride = gridDim.x * (uint32_t)kTileRowsV;
     const uint32_t ntiles = (uint32_t)my_tiles;
@@ -721,14 +745,15 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     const uint32_t* ovfb = a.overflow;
     const uint32_t lane16 = lane * 16;
     const uint32_t qvoff = (uint32_t)wave * 2048u + lane16;  // this thread's uint4 of fragment piece 2*wave + h
-    const uint32_t rnvoff = g * 16;
+    const uint32_t rnvoff = g * (I8 ? 32 : 16);
     const uint32_t thra = (uint32_t)(kQBufs * chunk_bytes) + c16 * 4;
     const uint32_t c16v = c16;
     const uint32_t crow = (uint32_t)wave * (uint32_t)kWaveRows + g * 4;
     static_assert(kWgCap == 16384 && sizeof(WgEntry) == 16, "the assembly hard-codes the append buffer geometry");
 
     u32x4s xring[R * MT], qsa[kQPer], qsb[kQPer], qt[QD > 8 ? 4 : QD];
-    float vr[4 * MT], vp[4 * MT], vu[4 * MT];
+    float vr[4 * MT], vp[4 * MT], vu[4 * MT], vs[4 * MT];
+    (void)vs;
     uint32_t ve[13], ldr, ldw, s_sldw;
     const uint32_t wave2k = (uint32_t)wave * 2048u;  // LDS-DMA staging: this wave's piece offset inside a Q buffer
     (void)ldw;
@@ -1150,7 +1175,7 @@ __device__ __forceinline__ int64_t layout_offset_i8(int64_t row, int32_t col, in
 // and measures the error.  Whole panels are (re)written: idempotent for rows converted before.
 __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const float* rn, int8_t* X8, float* rp8,
                                                            unsigned int* row_err8, int64_t panel_begin, int64_t panel_end,
-                                                           int32_t ld) {
+                                                           int32_t ld, int32_t space) {
     const int lane = threadIdx.x & 63;
     const int64_t panel = panel_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (panel >= panel_end) return;
@@ -1191,21 +1216,26 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
     if (g == 0) {
         const int64_t row = panel * kPanelRows + r;
         const float nrm = rn[row];  // NaN: tombstoned / not a row
-        rp8[row] = sx / (nrm + 1e-30f);
+        float rel = 0.f;
         if (n2 > 0.0) {
-            float rel = (float)(__builtin_sqrt(err2 / n2) * 1.000001);
+            rel = (float)(__builtin_sqrt(err2 / n2) * 1.000001);
             rel = __uint_as_float(__float_as_uint(rel) + 1u);
             atomicMax(row_err8, __float_as_uint(rel));  // non-negative floats order like their bits
         }
+        // per-row pair: cosine {sx/(|x|+1e-30), this row's error}, l2 / ip {sx, |x|}; NaN marks a tombstone
+        float2 pr;
+        if (space == kSpaceCosine) pr = make_float2(sx / (nrm + 1e-30f), nrm == nrm ? rel : nrm);
+        else pr = make_float2(nrm == nrm ? sx : nrm, nrm);
+        reinterpret_cast<float2*>(rp8)[row] = pr;
     }
 }
 
 hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t row_begin,
-                               int64_t row_end, int32_t ld, hipStream_t s) {
+                               int64_t row_end, int32_t ld, int32_t space, hipStream_t s) {
     const int64_t pb = row_begin / kPanelRows, pe = (row_end + kPanelRows - 1) / kPanelRows;
     if (pe <= pb) return hipSuccess;
     shadow8_rows_kernel<<<(unsigned)((pe - pb + 3) / 4), 256, 0, s>>>(X, rn, static_cast<int8_t*>(X8), rp8,
-                                                                       reinterpret_cast<unsigned int*>(row_err8), pb, pe, ld);
+                                                                       reinterpret_cast<unsigned int*>(row_err8), pb, pe, ld, space);
     return hipGetLastError();
 }
 
@@ -1220,7 +1250,7 @@ __global__ __launch_bounds__(256) void filter_prep8_kernel(const FilterArgs a) {
     int8_t* img = reinterpret_cast<int8_t*>(a.qimg8);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float inv = 0.f;
-    if (q < a.nq) inv = (float)a.qaux[q];  // cosine: 1/(|q|+1e-30)
+    if (q < a.nq) inv = a.space == kSpaceCosine ? (float)a.qaux[q] : (float)(1.0 / (a.qaux[q] + 1e-30));  // as filter_prep_kernel
     float amax = 0.f;
     for (int c = threadIdx.x; c < ld; c += 256) {
         const float v = q < a.nq ? a.Qpad[(int64_t)q * ld + c] * inv : 0.f;
@@ -1253,7 +1283,7 @@ __global__ __launch_bounds__(256) void filter_prep8_kernel(const FilterArgs a) {
         // + rounding of float(I) * rp8 * sq8 (three roundings of a value <= ~1) and the usual slack
         const double e8 = (q < a.nq ? eq8 : 0.0) + 1.016 * (double)*a.row_err8 + 4.0 * 5.9604644775390625e-08;
         const double eb = (q < a.nq ? (double)a.qerr[q] : 0.0) + 1.00390625 * (double)*a.row_err + (double)ld * 2.384185791015625e-07;
-        float ke = (float)((e8 > eb ? e8 : eb) * 1.000001) + 2.0f * kSlack;
+        float ke = (float)((e8 > eb ? e8 : eb) * 1.000001) + (a.space == kSpaceCosine ? 2.0f : 1.0f) * kSlack;
         a.ke[q] = __uint_as_float(__float_as_uint(ke) + 1u);
     }
 }
@@ -1348,12 +1378,13 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
 
 hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s) {
     const size_t lds = (size_t)a.ld * sizeof(double) + 4 * 8 + 64 * 4 + 4 * 8 + (size_t)kCandCap * 8;
-    auto kern = filter_refine_thr_kernel<kSpaceCosine>;  // cosine only so far: the int8 path is
-    static bool configured = false;
-    if (!configured) {
+    auto kern = a.space == kSpaceL2 ? filter_refine_thr_kernel<kSpaceL2>
+                : a.space == kSpaceCosine ? filter_refine_thr_kernel<kSpaceCosine> : filter_refine_thr_kernel<kSpaceIp>;
+    static bool configured[3] = {false, false, false};
+    if (!configured[a.space]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        configured = true;
+        configured[a.space] = true;
     }
     kern<<<a.nq, 256, lds, s>>>(a, k, forced_cnt);
     return hipGetLastError();
@@ -1479,7 +1510,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     info->scatter_grid = grid;  // the caller runs launch_filter_scatter next (outside its timing window)
     info->nw = NW;
     info->dbg = QD == 108 ? 1 : 0;
-    info->i8 = QD == 208 ? 1 : 0;
+    info->i8 = QD != 208 ? 0 : (SPACE == kSpaceCosine ? 1 : (SPACE == kSpaceIp ? 2 : 0));  // how the scatter turns stored values into bounds
     return hipGetLastError();
 }
 
@@ -1499,9 +1530,9 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
             if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true, 4, false, 4>(a, row_begin, row_end, s, info);
             return launch_scan_asm<SPACE, 2, 4, true, 4, false, 4>(a, row_begin, row_end, s, info);
         }
+        if (a.X8 && a.ld % 256 == 0)  // int8 shadow (the caller attached it): ld/128 chunks, an even number
+            return launch_scan_asm<SPACE, 4, 8, true, 208, false, 2, true>(a, row_begin, row_end, s, info);
         if constexpr (SPACE == kSpaceCosine) {
-            if (a.X8 && a.ld % 256 == 0)  // experimental int8 shadow (the caller built it: MLVDB_I8=1); ld/128 chunks, even
-                return launch_scan_asm<SPACE, 4, 8, true, 208, false, 2, true>(a, row_begin, row_end, s, info);
             if (nw == 8 && nkc % 2 == 0 && env_int("MLVDB_SCAN_PRIO", 0) != 0)
                 return launch_scan_asm<SPACE, 4, 8, true, 4, true>(a, row_begin, row_end, s, info);
             if (nkc % 2 == 0 && env_int("MLVDB_SCAN_NT", 1) == 0)

@@ -254,7 +254,7 @@ def test_range_capacity_overflow_is_reported_then_resolved():
 
 
 SCAN_VARIANTS = [
-    {},                                              # defaults: int8 shadow body for cosine with dim % 256 == 0, else the bf16 body below
+    {},                                              # defaults: int8 shadow body where dim % 256 == 0, else the bf16 body below
     {"MLVDB_I8": "0"},                               # bf16 body: one 8-wave workgroup per CU, Q by LDS-DMA
     {"MLVDB_I8": "0", "MLVDB_SCAN_DMA": "0"},        # Q staged through registers (global -> VGPR -> ds_write)
     {"MLVDB_I8": "0", "MLVDB_SCAN_NW": "4"},         # two 4-wave workgroups per CU
@@ -287,7 +287,7 @@ def test_small_batches_through_the_filter_agree_with_oracle(space, d, nq, n, nar
 
 
 @pytest.mark.parametrize("variant", SCAN_VARIANTS, ids=lambda v: ",".join(f"{k[6:]}={x}" for k, x in v.items()) or "default")
-@pytest.mark.parametrize("space,d", [("cosine", 128), ("l2", 192), ("ip", 64), ("cosine", 768), ("l2", 1536)])
+@pytest.mark.parametrize("space,d", [("cosine", 128), ("l2", 192), ("ip", 64), ("cosine", 768), ("l2", 1536), ("ip", 768), ("l2", 256)])
 def test_scan_kernel_variants_agree_with_oracle(variant, space, d, monkeypatch):
     """Every generated geometry of the filter scan (the variable is read per launch), on corpora with more
     tiles than resident workgroups (persistent tile loop, prefetch across tile boundaries), ragged last
@@ -299,7 +299,7 @@ def test_scan_kernel_variants_agree_with_oracle(variant, space, d, monkeypatch):
     deleted = deleted_mask(7, n, 0.05)
     got, stats = run_hip(rows, qs, 10, space, "filter", deleted, append_chunks=3)
     assert stats["strategy_used"] == 2 and stats["fallback_queries"] == 0
-    assert stats["bound_dtype"] == (2 if space == "cosine" and d % 256 == 0 and variant.get("MLVDB_I8") != "0" else 1)
+    assert stats["bound_dtype"] == (2 if d % 256 == 0 and variant.get("MLVDB_I8") != "0" else 1)
     assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"variant {variant}/{space}/d{d}")
 
 
@@ -389,43 +389,44 @@ def test_save_index_load_index_round_trip_on_device(tmp_path, monkeypatch):
     b.close()
 
 
-@pytest.mark.parametrize("d,nq,k", [(768, 40, 10), (256, 256, 64), (1536, 7, 1)])
-def test_int8_shadow_follows_appends_tombstones_compaction_and_masks(d, nq, k):
-    """The int8 shadow of a cosine index is maintained lazily: rows appended, tombstoned or compacted away after a
+@pytest.mark.parametrize("space,d,nq,k", [("cosine", 768, 40, 10), ("cosine", 256, 256, 64), ("cosine", 1536, 7, 1),
+                                          ("l2", 768, 40, 10), ("ip", 512, 300, 5), ("l2", 256, 3, 10)])
+def test_int8_shadow_follows_appends_tombstones_compaction_and_masks(space, d, nq, k):
+    """The int8 shadow is maintained lazily: rows appended, tombstoned or compacted away after a
     search must be reflected in the next one (ids == oracle each time); a row-mask search falls back to bf16."""
     n = 30_000
     rows, qs = make_case(900 + d, n, d, nq, dup=True)
-    eng = HipScanEngine(d, "cosine", device=0, strategy="filter")
+    eng = HipScanEngine(d, space, device=0, strategy="filter")
     try:
         eng.append(rows[:20_000])
         got = eng.search(qs, k)
         assert eng.last_stats()["bound_dtype"] == 2
-        assert_knn_matches(got, oracle_knn(qs, rows[:20_000], k, "cosine"), "i8/first")
+        assert_knn_matches(got, oracle_knn(qs, rows[:20_000], k, space), "i8/first")
         eng.append(rows[20_000:])  # not a multiple of the panel: the shared panel is rewritten
         deleted = deleted_mask(3, n, 0.1)
         eng.tombstone(np.nonzero(deleted)[0])
         got = eng.search(qs, k)
         assert eng.last_stats()["bound_dtype"] == 2 and eng.last_stats()["fallback_queries"] == 0
-        assert_knn_matches(got, oracle_knn(qs, rows, k, "cosine", deleted), "i8/append+tombstone")
+        assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), "i8/append+tombstone")
         # tombstone the current best hit of every query: it must disappear
         best = np.unique(got[0][:, 0])
         deleted[best] = True
         eng.tombstone(best)
         got = eng.search(qs, k)
-        assert_knn_matches(got, oracle_knn(qs, rows, k, "cosine", deleted), "i8/tombstoned best")
+        assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), "i8/tombstoned best")
         mask = (np.arange(n) % 3 != 0).astype(np.uint8)
         got = eng.search(qs, k, mask=mask)
         assert eng.last_stats()["bound_dtype"] == 1
-        assert_knn_matches(got, oracle_knn(qs, rows, k, "cosine", deleted | (mask == 0)), "i8/mask")
+        assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted | (mask == 0)), "i8/mask")
         old = eng.compact()
         live = rows[old]
         got = eng.search(qs, k)
         assert eng.last_stats()["bound_dtype"] == 2
-        assert_knn_matches(got, oracle_knn(qs, live, k, "cosine"), "i8/compacted")
+        assert_knn_matches(got, oracle_knn(qs, live, k, space), "i8/compacted")
         eng.reset()
         eng.append(rows[5_000:9_000])
         got = eng.search(qs, k)
-        assert_knn_matches(got, oracle_knn(qs, rows[5_000:9_000], k, "cosine"), "i8/reset")
+        assert_knn_matches(got, oracle_knn(qs, rows[5_000:9_000], k, space), "i8/reset")
     finally:
         eng.close()
 

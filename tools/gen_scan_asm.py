@@ -47,6 +47,7 @@ MT = 2
 CHUNK_BYTES = 0x8000      # 256 queries x 64 columns x 2 B
 WG_CAP = 16384            # kWgCap: append entries per workgroup (split evenly over its waves)
 SPACES = {"l2": 0, "cosine": 1, "ip": 2}
+I8_SPACE = None
 I8 = False     # generate(): int8 shadow -- v_mfma_i32_16x16x64_i8, k-steps of 64 columns, integer accumulators
 STAG = False   # generate(): the later-dispatched half of the waves runs half a tile behind (see generate)
 DBG = set()   # timing diagnostics only (wrong results): 'nolds' drops the B-fragment reads, 'nox' the X refills
@@ -273,6 +274,14 @@ def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False, dma=False):
         # |x| of this lane's 4*MT rows (rows 4g..4g+3 of every panel) for the admission test
         for j in range(4 * MT):
             off = (j >> 2) * 64 + (j & 3) * 4
+            if I8:
+                # per-row pairs {a, b}: cosine a = sx/(|x|+1e-30) (b unused); l2 / ip a = sx, b = |x| (NaN: tombstoned)
+                if I8_SPACE == "cosine":
+                    s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{2 * off}" if off else ""), ("rn", j))
+                else:
+                    s.vmem(f"buffer_load_dword %[s{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{2 * off}" if off else ""), ("rn", j))
+                    s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen offset:{2 * off + 4}", ("rn", j))
+                continue
             s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{off}" if off else ""),
                    ("rn", j))
     for ch in range(R // 2):
@@ -302,11 +311,10 @@ def gen_admission(space):
     # cosine p0 = 1/(|x|+1e-30), u = a*p0 + ke; ip p0 = |x|, u = a + ke*p0; l2 p0 = |x|, p1 = -|x|^2 (1-slack),
     # u = sq*(a + ke*p0) + p1
     NR = 4 * MT
-    if I8:
+    if I8 and space == "cosine":
         # int8 shadow, cosine: r_j = sx/(|x|+1e-30) of the row (NaN: tombstoned), accumulators are exact integer dot
         # products I; the test is float(I)*r_j >= T[q] with T = (thr - ke)/sq rounded down (filter_scan_asm_kernel);
         # the append path stores w = float(I)*r_j, filter_scatter_kernel turns it into the bound u = w*sq + ke
-        assert space == "cosine"
         s.lds(f"ds_read_b32 %[e0], %[thra]", ("thr", 0))
         for n in range(16):
             if n + 1 < 16:
@@ -358,6 +366,14 @@ def gen_admission(space):
         for j in range(NR):
             m, i = j >> 2, j & 3
             a(f"v_accvgpr_read_b32 %[u{j}], a{(m * 16 + n) * 4 + i}")
+        if I8:
+            # int8 shadow, l2 / ip: w = float(I) * sx_j takes the place of the bf16 dot product; the per-query constants in
+            # LDS are rescaled by the query's scale (filter_scan_asm_kernel): ip  w + ke' |x| >= thr/sq8 (the append path
+            # stores that, filter_scatter_kernel multiplies by sq8), l2  sq' (w + ke' |x|) + p1 >= thr
+            for j in range(NR):
+                a(f"v_cvt_f32_i32 %[u{j}], %[u{j}]")
+            for j in range(NR):
+                a(f"v_mul_f32 %[u{j}], %[u{j}], %[s{j}]")
         s.need_lg(("ke", n), *([("sq", n)] if space == "l2" else []))
         for j in range(NR):
             if space == "cosine":
@@ -495,10 +511,11 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     wrapping at the end of the panel; the shared Q chunk stream is the same for everybody) and therefore reaches its
     admission test while its SIMD partner is in mid-tile; the early half sits out nkc/2 periods at the end.
     hc = 0 (and xrot = 0) turns it off at run time."""
-    global MT, STAG, I8
+    global MT, STAG, I8, I8_SPACE
     MT = mt
     STAG = stag
     I8 = i8
+    I8_SPACE = space if i8 else None
     assert R in (2, 4, 6) and 2 <= QD <= 8 and mt in (2, 4)
     assert not stag or (dma and mt == 2 and R * 1024 <= 4096)
     KQ = 1024 // (NW * 64)
@@ -513,7 +530,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     a("s_mov_b32 s87, s83")
     a("s_mov_b32 s88, %[rnlo]")
     a("s_mov_b32 s89, %[rnhi]")
-    a(f"s_movk_i32 s90, 0x{16 * MT * 4:x}")   # this wave's rows x 4 B
+    a(f"s_movk_i32 s90, 0x{16 * MT * (8 if i8 else 4):x}")   # this wave's rows x 4 B (int8 shadow: pairs)
     a("s_mov_b32 s91, s83")
     a("s_mov_b32 %[tl], %[ntiles]")
     a("s_mov_b32 %[trow], %[row0]")
@@ -659,6 +676,9 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     if space == "l2":
         for j in range(4 * MT):
             ops_out.append(f'[p{j}] "=&v"(vp[{j}])')
+    if i8 and space != "cosine":
+        for j in range(4 * MT):
+            ops_out.append(f'[s{j}] "=&v"(vs[{j}])')
     for j in range(4 * MT):
         ops_out.append(f'[u{j}] "=&v"(vu[{j}])')
     for j in range(13):
@@ -702,7 +722,7 @@ CONFIGS = [(sp, nw, r, True, 4, False, 2, False, False) for sp in SPACES for nw 
     (sp, 4, r, True, 4, False, 4, False, False) for sp in SPACES for r in (2, 4)] + [
     (sp, 8, r, True, 4, False, 2, True, False) for sp in SPACES for r in (2, 4)] + [
     (sp, 8, 4, True, 4, False, 2, True, True) for sp in SPACES]
-I8_CONFIGS = [("cosine", 8, 4, True, 4, False, 2, True, False)]   # int8 shadow (experimental): QD slot 208 in the dispatch
+I8_CONFIGS = [(sp, 8, 4, True, 4, False, 2, True, False) for sp in SPACES]   # int8 shadow: QD slot 208 in the dispatch
 # timing diagnostics (cosine, NW=8, R=4, nt): QD slot carries the knob: 101 = nolds, 102 = nox, 103 = both
 DIAG = {101: {"nolds"}, 102: {"nox"}, 103: {"nolds", "nox"}, 104: {"nolds", "nox", "nobar"},
         107: {"nohit"}, 108: {"stamp"}, 109: {"noadm"}}
@@ -718,7 +738,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + ["scan_asm_cosine_i8.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8.inc" for sp in SPACES] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -726,7 +746,7 @@ def main():
         space, nw, r, nt, qd, prio, mt, dma, stag = c
         (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag))
     for space, nw, r, nt, qd, prio, mt, dma, stag in I8_CONFIGS:
-        (Path(args.outdir) / "scan_asm_cosine_i8.inc").write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag, True))
+        (Path(args.outdir) / f"scan_asm_{space}_i8.inc").write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag, True))
     for code, knobs in DIAG.items():
         DBG.clear()
         DBG.update(knobs)
@@ -739,8 +759,9 @@ def main():
                 f" && STAG == {'true' if stag else 'false'}")
         disp.append(("if" if i == 0 else "} else if") + f" constexpr ({cond}) {{")
         disp.append(f'#include "{inc_name(space, nw, r, nt, qd, prio, mt, dma, stag)}"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 208 && PRIO == false && MT == 2 && DMA == true && STAG == false) {")
-    disp.append('#include "scan_asm_cosine_i8.inc"')
+    for sp, code in SPACES.items():
+        disp.append(f"}} else if constexpr (SPACE == {code} && NW == 8 && R == 4 && NT == true && QD == 208 && PRIO == false && MT == 2 && DMA == true && STAG == false) {{")
+        disp.append(f'#include "scan_asm_{sp}_i8.inc"')
     disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
     for code in DIAG:
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2 && DMA == false && STAG == false) {{")
