@@ -303,7 +303,7 @@ def main() -> None:
             # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
             # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); counters cannot be read from inside the process
             traffic = json.loads(tfile.read_text())["traffic_bytes_per_launch_avg"]
-        flops = 2.0 * float(rows_scanned) * d * 256 * passes
+        flops = 2.0 * float(rows_scanned) * d * 256  # rows_scanned sums the launches of every 256-query pass
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": f"profiles/r01/{tfile.name} (rocprofv3 --pmc, separate passes)" if traffic else None,
