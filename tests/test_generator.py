@@ -1,0 +1,24 @@
+"""The committed scan bodies (mlvectordb_amd/csrc/scan_asm_*.inc) are exactly what tools/gen_scan_asm.py emits, and the
+dispatch header covers every generated body (CPU only: text generation, no assembler)."""
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+CSRC = ROOT / "mlvectordb_amd" / "csrc"
+
+
+def test_committed_scan_bodies_match_the_generator(tmp_path):
+    gen = ROOT / "tools" / "gen_scan_asm.py"
+    names = subprocess.run([sys.executable, str(gen), "--list"], check=True, capture_output=True, text=True).stdout.split()
+    subprocess.run([sys.executable, str(gen), "--outdir", str(tmp_path)], check=True, capture_output=True)
+    assert names and sorted(p.name for p in tmp_path.iterdir()) == sorted(names)
+    dispatch = (tmp_path / "scan_asm_dispatch.inc").read_text()
+    for name in names:
+        fresh = (tmp_path / name).read_text()
+        assert (CSRC / name).read_text() == fresh, f"{name}: regenerate with `make -C mlvectordb_amd/csrc`"
+        if name.startswith("scan_asm_") and name not in ("scan_asm_dispatch.inc", "scan_asm_consts.inc"):
+            assert f'#include "{name}"' in dispatch, f"{name} is generated but never dispatched"
+            assert fresh.count("asm volatile(") == 1  # one statement: nothing in flight crosses compiler-managed code
+    body = (tmp_path / "scan_asm_cosine_i8.inc").read_text()
+    assert "v_mfma_i32_16x16x64_i8" in body and "v_mfma_f32_16x16x32_bf16" not in body
