@@ -252,7 +252,7 @@ struct FilterWs {
 
 int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const double* qaux, const float* qerr, int32_t nq) {
     HIP_TRY(h, h->qimg.ensure(filter_qimg_bytes(h->ld)));
-    HIP_TRY(h, h->fmisc.ensure(5 * kFilterQueries * sizeof(uint32_t)));
+    HIP_TRY(h, h->fmisc.ensure(8 * kFilterQueries * sizeof(uint32_t)));
     HIP_TRY(h, h->cand.ensure((size_t)kFilterQueries * kCandCap * sizeof(CandEntry)));
     if (h->Xb) {  // the assembly scan appends through workgroup-private buffers
         HIP_TRY(h, h->wgbuf.ensure((size_t)kScanMaxGrid * kWgCap * sizeof(WgEntry)));
@@ -277,6 +277,9 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     fa.cnt = h->fmisc.as<uint32_t>() + 2 * kFilterQueries;
     fa.overflow = h->fmisc.as<uint32_t>() + 3 * kFilterQueries;
     fa.ke = h->fmisc.as<float>() + 4 * kFilterQueries;
+    fa.keb = h->fmisc.as<float>() + 5 * kFilterQueries;
+    fa.ke8 = h->fmisc.as<float>() + 6 * kFilterQueries;  // 257 floats
+    fa.sqmin = h->fmisc.as<uint32_t>() + 7 * kFilterQueries + 128;
     fa.cand = h->cand.as<CandEntry>();
     fa.wgbuf = h->wgbuf.as<WgEntry>();
     fa.wgcnt = h->wgcnt.as<uint32_t>();
@@ -331,10 +334,10 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
         HIP_TRY(h, hipMemcpyAsync(&h->i8_err, h->rowerr8.p, sizeof(float), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
     }
-    // One scale per row: a row with an outlier component quantises badly, and the index-wide error term would then
-    // admit everything.  Typical data sits at 0.008-0.015; beyond 0.03 the bf16 shadow (error relative per component)
-    // gives the tighter bounds.
-    if (!(h->i8_err <= 0.03f)) return MLVDB_OK;
+    // One scale per row: a row with an outlier component quantises badly.  Cosine bounds carry every row's own error;
+    // l2 / ip still use the index-wide maximum, which would then admit everything: beyond 0.03 (typical data sits at
+    // 0.008-0.015) they keep to the bf16 shadow, whose error is relative per component.
+    if (!(h->i8_err <= (h->space == kSpaceCosine ? 0.5f : 0.03f))) return MLVDB_OK;
     HIP_TRY(h, h->qimg8.ensure((size_t)kFilterQueries * h->ld));
     HIP_TRY(h, h->sq8.ensure(kFilterQueries * sizeof(float)));
     fa.X8 = h->x8.p;

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void filter_range_thr_kernel(const FilterArgs 
 // row0 = first of this lane's rows; dump = this lane's column of a [4*kMT][64] LDS scratch per wave.
 template <int SPACE, int kMT, bool DENSE, int NQT = 16, bool I8 = false>
 __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (&acc)[kMT][NQT], const float4 (&rnv)[kMT],
-                                              const int32_t row0, const int32_t base_row,
+                                              const float4 (&rbv)[kMT], const int32_t row0, const int32_t base_row,
                                               const float* thr_l, const float* sq_l, const float* ke_l, float* dump,
                                               const int c16) {
     // ke = the query's error term (filter_prep_kernel).  Per-row constants:
@@ -172,9 +172,10 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
         const float nr[4] = {rnv[m].x, rnv[m].y, rnv[m].z, rnv[m].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (I8) {  // int8 shadow (cosine): acc = float(integer dot), rnv = rp8 = sx/(|x|+1e-30), sq = the query's scale
+            if (I8) {  // int8 shadow (cosine): acc = float(integer dot), rnv = sx/(|x|+1e-30), rbv = the row's error x K
+                const float nb[4] = {rbv[m].x, rbv[m].y, rbv[m].z, rbv[m].w};
                 p0[m][i] = nr[i];
-                p1[m][i] = 0.f;
+                p1[m][i] = nb[i];
             } else if (SPACE == kSpaceCosine) {
                 p0[m][i] = 1.0f / (nr[i] + 1e-30f);
                 p1[m][i] = 0.f;
@@ -186,7 +187,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
     }
     auto bound = [&](int m, int i, int n, float sq, float ke) __attribute__((always_inline)) {
         const float av = acc[m][n][i];
-        if (I8) return __builtin_fmaf(av * p0[m][i], sq, ke);
+        if (I8) return __builtin_fmaf(__builtin_fmaf(av, p0[m][i], p1[m][i]), sq, ke);  // sq8 (w + b K) + ke8
         if (SPACE == kSpaceCosine) return __builtin_fmaf(av, p0[m][i], ke);
         if (SPACE == kSpaceIp) return __builtin_fmaf(ke, p0[m][i], av);
         return __builtin_fmaf(sq, __builtin_fmaf(ke, p0[m][i], av), p1[m][i]);
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void filter_scan_kernel(const FilterArgs a,
     for (int b = 0; b < R; ++b) load_x(xr[b]);
 
     auto epilogue = [&](const int64_t ti) __attribute__((always_inline)) {
-        scan_epilogue<SPACE, kMT, DENSE>(a, acc, rnv, (int32_t)(tile_of(ti) * kFilterTileRows) + wave * (16 * kMT) + g * 4,
+        scan_epilogue<SPACE, kMT, DENSE>(a, acc, rnv, rnv, (int32_t)(tile_of(ti) * kFilterTileRows) + wave * (16 * kMT) + g * 4,
                                          (int32_t)(tile_begin * kFilterTileRows), thr_l, sq_l, ke_l,
                                          hit_l + wave * (4 * kMT * 64) + lane, c16);
     };
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
     if (threadIdx.x < kFilterQueries) {
         thr_l[threadIdx.x] = a.thr[threadIdx.x];
         sq_l[threadIdx.x] = I8 ? a.sq8[threadIdx.x] : a.qscale[threadIdx.x];
-        ke_l[threadIdx.x] = a.ke[threadIdx.x];
+        ke_l[threadIdx.x] = I8 ? a.ke8[threadIdx.x] : a.ke[threadIdx.x];
     }
     // query image (filter_prep_kernel's [kc][n][ks][lane] order) -> LDS [2kc+ks][n < NQT][lane]
     {
@@ -495,7 +496,8 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
 
     typename std::conditional<I8, i32x4, f32x4>::type acc[kMT][NQT];
     float4 xr[R][kMT];
-    float4 rnv[kMT];
+    float4 rnv[kMT], rbv[kMT];
+    const float kq = I8 ? a.ke8[kFilterQueries] : 0.f;
     const uint32_t panel_bytes = (uint32_t)ld * (I8 ? 16 : 32);  // 16 rows of int8 / bf16
     const uint32_t wave_bytes = kMT * panel_bytes;
     const uint64_t tile_stride_bytes = (uint64_t)gridDim.x * (NW * wave_bytes);
@@ -530,6 +532,7 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
             if constexpr (I8) {  // pairs per row: keep the first components (sx/(|x|+1e-30))
                 const float4 lo = buf_load_f4(rn_rsrc, g * 32, m * 128), hi = buf_load_f4(rn_rsrc, g * 32 + 16, m * 128);
                 rnv[m] = make_float4(lo.x, lo.z, hi.x, hi.z);
+                rbv[m] = make_float4(lo.y * kq, lo.w * kq, hi.y * kq, hi.w * kq);  // the rows' own errors x K
             } else {
                 rnv[m] = buf_load_f4(rn_rsrc, g * 16, m * 64);
             }
@@ -569,7 +572,7 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
                 if constexpr (I8) accf[m][n] = __builtin_convertvector(acc[m][n], f32x4);  // |I| < 2^24 for d <= 1040: exact; beyond: 1 ulp, inside the slack
                 else accf[m][n] = acc[m][n];
             }
-        scan_epilogue<SPACE, kMT, DENSE, NQT, I8>(a, accf, rnv, (int32_t)(tile * kFilterTileRows) + wave * (16 * kMT) + g * 4,
+        scan_epilogue<SPACE, kMT, DENSE, NQT, I8>(a, accf, rnv, rbv, (int32_t)(tile * kFilterTileRows) + wave * (16 * kMT) + g * 4,
                                               (int32_t)(tile_begin * kFilterTileRows), thr_l, sq_l, ke_l,
                                               hit_l + wave * (4 * kMT * 64) + lane, c16);
     }
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(256) void filter_scatter_kernel(const FilterArgs a,
             if (slot < (uint32_t)kCandCap) {
                 CandEntry e;
                 // int8 scan: the stored value is in units of the query's scale (cosine: w, ip: w + ke' |x|)
-                e.u = i8 == 1 ? __builtin_fmaf(bu[i], a.sq8[q], a.ke[q]) : (i8 == 2 ? bu[i] * a.sq8[q] : bu[i]);
+                e.u = i8 == 1 ? __builtin_fmaf(bu[i], a.sq8[q], a.ke8[q]) : (i8 == 2 ? bu[i] * a.sq8[q] : bu[i]);
                 e.row = br[i];
                 a.cand[(size_t)q * kCandCap + slot] = e;
             }
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
             if (SPACE == kSpaceCosine) {  // w >= T:  u = w*sq8 + ke >= thr  <=>  w >= (thr - ke)/sq8, rounded down
                 if (thr > 1.0e30f) thr = 3.4e38f;
                 else if (thr < -1.0e30f) thr = -3.4e38f;
-                else thr = float_below(((double)thr - (double)kev) / sq8);
+                else thr = float_below(((double)thr - (double)a.ke8[t]) / sq8);
             } else if (SPACE == kSpaceIp) {  // w + ke' |x| >= thr/sq8  (the scatter multiplies the stored value by sq8)
                 if (thr > 1.0e30f) thr = 3.4e38f;
                 else if (thr < -1.0e30f) thr = -3.4e38f;
@@ -720,7 +723,9 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
         qsrd[2] = qbytes;
         qsrd[3] = 0x00020000u;
     }
-    const float k1 = -(1.0f - kSlack);
+    // l2: p1 = k1 |x|^2; int8 cosine: K = 1.016 / min sq8, the factor of the rows' own errors (filter_prep8_fin_kernel)
+    const float k1 = I8 && SPACE == kSpaceCosine ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a.ke8[kFilterQueries])))
+                                                 : -(1.0f - kSlack);
     // the later-dispatched half of the workgroup's waves (readfirstlane: an "s" operand must live in an SGPR)
     const uint32_t wtype = __builtin_amdgcn_readfirstlane(wave >= NW / 2 ? 1u : 0u);
     (void)wtype;
@@ -1279,17 +1284,39 @@ __global__ __launch_bounds__(256) void filter_prep8_kernel(const FilterArgs a) {
     if (threadIdx.x == 0) {
         const double eq8 = __builtin_sqrt(dred[0] + dred[1] + dred[2] + dred[3]) * 1.000001 + 1e-12;
         a.sq8[q] = sq;
-        // E = eq8 + (1 + eq8) rmax8 (eq8 <= 2^-6), + the bf16 term as a floor (the seeding pass computes bf16 bounds),
-        // + rounding of float(I) * rp8 * sq8 (three roundings of a value <= ~1) and the usual slack
-        const double e8 = (q < a.nq ? eq8 : 0.0) + 1.016 * (double)*a.row_err8 + 4.0 * 5.9604644775390625e-08;
-        const double eb = (q < a.nq ? (double)a.qerr[q] : 0.0) + 1.00390625 * (double)*a.row_err + (double)ld * 2.384185791015625e-07;
-        float ke = (float)((e8 > eb ? e8 : eb) * 1.000001) + (a.space == kSpaceCosine ? 2.0f : 1.0f) * kSlack;
-        a.ke[q] = __uint_as_float(__float_as_uint(ke) + 1u);
+        a.ke8[q] = q < a.nq ? float_above(eq8) : 0.f;  // finished by filter_prep8_fin_kernel
+        if (q < a.nq) atomicMin(a.sqmin, __float_as_uint(sq));  // positive floats order like their bits
     }
 }
 
+// Second phase (one block): the error terms that need the smallest query scale of the pass.
+//   cosine  rows carry their own error b: the scan tests  w + b K >= (thr - ke8)/sq8  with K = 1.016/min sq8, i.e. the
+//           bound u = sq8 w + ke8 + 1.016 b sq8/min sq8 >= <q^,x>/|x|;  ke8 = eq8 + roundings + slack
+//   l2, ip  index-wide row error: ke = eq8 + 1.016 rmax8 + roundings + slack (x |x|)
+//   keb     the bf16 term (filter_prep_kernel's ke): what the bf16 seeding pass adds to its bounds
+//   ke      covers both kinds of entry (the update kernel's lower bounds u - 2 eps): the larger of the two, with the
+//           int8 row term at its index-wide maximum
+__global__ __launch_bounds__(256) void filter_prep8_fin_kernel(const FilterArgs a) {
+    const int q = threadIdx.x;
+    const float sqmin = __uint_as_float(*a.sqmin);
+    const double eq8 = (double)a.ke8[q];
+    const double ratio = a.space == kSpaceCosine && q < a.nq ? (double)a.sq8[q] / (double)sqmin * 1.000001 : 1.0;
+    const double rnd = 4.0 * 5.9604644775390625e-08;  // float(I) * rp8 (+ b K) * sq8: roundings of a value <= ~1
+    const double slack = (a.space == kSpaceCosine ? 2.0 : 1.0) * (double)kSlack;
+    const double e8 = eq8 + 1.016 * (double)*a.row_err8 * ratio + rnd;
+    const double eb = (double)a.ke[q];  // bf16 term incl. its slack (filter_prep_kernel)
+    a.keb[q] = a.ke[q];
+    const double big = (e8 * 1.000001 + slack) > eb ? (e8 * 1.000001 + slack) : eb;
+    a.ke[q] = float_above(big);
+    a.ke8[q] = float_above((eq8 + rnd) * 1.000001 + slack);
+    if (q == 0) a.ke8[kFilterQueries] = float_above(1.016 / (double)sqmin * 1.000001);
+}
+
 hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(a.sqmin, 0x7f, sizeof(unsigned int), s);  // 3.39e38: above every scale
+    if (e != hipSuccess) return e;
     filter_prep8_kernel<<<kFilterQueries, 256, 0, s>>>(a);
+    filter_prep8_fin_kernel<<<1, kFilterQueries, 0, s>>>(a);
     return hipGetLastError();
 }
 
@@ -1579,25 +1606,29 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
     hipError_t e;
     const bool xb = a.Xb != nullptr;
     if (filter_narrow_ok(a)) {
-        e = a.space == kSpaceL2       ? launch_scan_narrow<kSpaceL2, true>(a, 0, rows, s)
-            : a.space == kSpaceCosine ? launch_scan_narrow<kSpaceCosine, true>(a, 0, rows, s)
-                                      : launch_scan_narrow<kSpaceIp, true>(a, 0, rows, s);
+        FilterArgs b = a;
+        if (a.X8 && a.space != kSpaceCosine) b.ke = a.keb;  // l2 / ip: the narrow kernel is the bf16 one
+        e = a.space == kSpaceL2       ? launch_scan_narrow<kSpaceL2, true>(b, 0, rows, s)
+            : a.space == kSpaceCosine ? launch_scan_narrow<kSpaceCosine, true>(b, 0, rows, s)
+                                      : launch_scan_narrow<kSpaceIp, true>(b, 0, rows, s);
         if (e != hipSuccess) return e;
         if (a.X8 && (e = launch_filter_refine_thr(a, k, (int32_t)rows, s)) != hipSuccess) return e;
         return launch_update(a, k, (int32_t)rows, s);
     }
+    FilterArgs b = a;
+    if (a.X8) b.ke = a.keb;  // bf16 bounds get the bf16 error term; `a.ke` (update, below) covers int8 entries too
     switch (a.space) {
         case kSpaceL2:
-            e = xb ? launch_scan_one<kSpaceL2, true, true>(a, 0, rows, s)
-                   : launch_scan_one<kSpaceL2, false, true>(a, 0, rows, s);
+            e = xb ? launch_scan_one<kSpaceL2, true, true>(b, 0, rows, s)
+                   : launch_scan_one<kSpaceL2, false, true>(b, 0, rows, s);
             break;
         case kSpaceCosine:
-            e = xb ? launch_scan_one<kSpaceCosine, true, true>(a, 0, rows, s)
-                   : launch_scan_one<kSpaceCosine, false, true>(a, 0, rows, s);
+            e = xb ? launch_scan_one<kSpaceCosine, true, true>(b, 0, rows, s)
+                   : launch_scan_one<kSpaceCosine, false, true>(b, 0, rows, s);
             break;
         default:
-            e = xb ? launch_scan_one<kSpaceIp, true, true>(a, 0, rows, s)
-                   : launch_scan_one<kSpaceIp, false, true>(a, 0, rows, s);
+            e = xb ? launch_scan_one<kSpaceIp, true, true>(b, 0, rows, s)
+                   : launch_scan_one<kSpaceIp, false, true>(b, 0, rows, s);
             break;
     }
     if (e != hipSuccess) return e;

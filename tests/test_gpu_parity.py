@@ -431,19 +431,21 @@ def test_int8_shadow_follows_appends_tombstones_compaction_and_masks(space, d, n
         eng.close()
 
 
-def test_int8_shadow_steps_aside_for_rows_with_outlier_components():
+@pytest.mark.parametrize("space,dtype", [("cosine", 2), ("l2", 1)])
+def test_int8_shadow_and_rows_with_outlier_components(space, dtype):
     """One scale per row: a row with one component ~30x the others has a large int8 error (its scale is set by the
-    outlier, its norm is not); the index then keeps to the bf16 bounds (relative per component) instead of admitting
-    everything -- same ids either way."""
+    outlier, its norm is not).  Cosine bounds carry every row's own error, so only those rows are admitted more often;
+    l2 / ip use the index-wide maximum and keep to the bf16 bounds (relative per component).  Same ids either way."""
     rows, qs = make_case(77, 20_000, 768, 24)
     rows[123, 5] = 30.0
     rows[9_000, 700] = -25.0
-    eng = HipScanEngine(768, "cosine", device=0, strategy="filter")
+    eng = HipScanEngine(768, space, device=0, strategy="filter")
     try:
         eng.append(rows)
         got = eng.search(qs, 10)
         st = eng.last_stats()
-        assert st["bound_dtype"] == 1 and st["fallback_queries"] == 0
-        assert_knn_matches(got, oracle_knn(qs, rows, 10, "cosine"), "i8/outliers")
+        assert st["bound_dtype"] == dtype and st["fallback_queries"] == 0
+        assert st["candidates_rescored"] < 24 * 2000
+        assert_knn_matches(got, oracle_knn(qs, rows, 10, space), "i8/outliers")
     finally:
         eng.close()

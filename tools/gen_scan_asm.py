@@ -276,8 +276,9 @@ def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False, dma=False):
             off = (j >> 2) * 64 + (j & 3) * 4
             if I8:
                 # per-row pairs {a, b}: cosine a = sx/(|x|+1e-30) (b unused); l2 / ip a = sx, b = |x| (NaN: tombstoned)
-                if I8_SPACE == "cosine":
+                if I8_SPACE == "cosine":   # {sx/(|x|+1e-30), the row's own error}
                     s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{2 * off}" if off else ""), ("rn", j))
+                    s.vmem(f"buffer_load_dword %[p{j}], %[rnvoff], {RNS}, 0 offen offset:{2 * off + 4}", ("rn", j))
                 else:
                     s.vmem(f"buffer_load_dword %[s{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{2 * off}" if off else ""), ("rn", j))
                     s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen offset:{2 * off + 4}", ("rn", j))
@@ -312,9 +313,12 @@ def gen_admission(space):
     # u = sq*(a + ke*p0) + p1
     NR = 4 * MT
     if I8 and space == "cosine":
-        # int8 shadow, cosine: r_j = sx/(|x|+1e-30) of the row (NaN: tombstoned), accumulators are exact integer dot
-        # products I; the test is float(I)*r_j >= T[q] with T = (thr - ke)/sq rounded down (filter_scan_asm_kernel);
-        # the append path stores w = float(I)*r_j, filter_scatter_kernel turns it into the bound u = w*sq + ke
+        # int8 shadow, cosine: r_j = sx/(|x|+1e-30) of the row (NaN: tombstoned), p_j = the row's own rounding error,
+        # accumulators = exact integer dot products I; the test is float(I)*r_j + p_j*K >= T[q] with T = (thr - ke8)/sq8
+        # rounded down and K = 1.016/min sq8 (filter_scan_asm_kernel); the append path stores the left-hand side,
+        # filter_scatter_kernel turns it into the bound u = w*sq8 + ke8
+        for j in range(NR):
+            a(f"v_mul_f32 %[p{j}], %[k1], %[p{j}]")
         s.lds(f"ds_read_b32 %[e0], %[thra]", ("thr", 0))
         for n in range(16):
             if n + 1 < 16:
@@ -325,7 +329,7 @@ def gen_admission(space):
             for j in range(NR):
                 a(f"v_cvt_f32_i32 %[u{j}], %[u{j}]")
             for j in range(NR):
-                a(f"v_mul_f32 %[u{j}], %[u{j}], %[r{j}]")
+                a(f"v_fma_f32 %[u{j}], %[u{j}], %[r{j}], %[p{j}]")
             a("v_max3_f32 %[e4], %[u0], %[u1], %[u2]")
             a("v_max3_f32 %[e5], %[u3], %[u4], %[u5]")
             for j in range(6, NR, 4):
@@ -673,7 +677,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
         ops_out.append(f'[t{i}] "=&v"(qt[{i}])')
     for j in range(4 * MT):
         ops_out.append(f'[r{j}] "=&v"(vr[{j}])')
-    if space == "l2":
+    if space == "l2" or (i8 and space == "cosine"):
         for j in range(4 * MT):
             ops_out.append(f'[p{j}] "=&v"(vp[{j}])')
     if i8 and space != "cosine":
@@ -694,7 +698,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
                '[pb] "s"(pb)', '[qbytes] "s"(qbytes)', '[nb] "s"(nb)', '[qcur0] "s"(qcur0)', '[qc1] "s"(qc1)',
                '[wtype] "s"(wtype)', '[wgbu] "s"(wgbu)', '[wgbr] "s"(wgbr)', '[wgbq] "s"(wgbq)', '[wgcp] "s"(wgcp)',
                '[ovfb] "s"(ovfb)']
-    if space == "l2":
+    if space == "l2" or (i8 and space == "cosine"):
         ops_in.append('[k1] "s"(k1)')
     if dma:
         ops_in.append('[wave2k] "s"(wave2k)')
