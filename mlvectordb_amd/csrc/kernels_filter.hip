@@ -1557,8 +1557,13 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
             if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true, 4, false, 4>(a, row_begin, row_end, s, info);
             return launch_scan_asm<SPACE, 2, 4, true, 4, false, 4>(a, row_begin, row_end, s, info);
         }
-        if (a.X8 && a.ld % 256 == 0)  // int8 shadow (the caller attached it): ld/128 chunks, an even number
+        if (a.X8 && a.ld % 256 == 0) {  // int8 shadow (the caller attached it): ld/128 chunks, an even number
+            // progress-based wave priorities: +2 % on the int8 body (profiles/r01/scan_ab_i8_prio_4m.txt); 3 % slower on the
+            // power-bound bf16 body, where they stay off
+            if (env_int("MLVDB_SCAN_PRIO", 1))
+                return launch_scan_asm<SPACE, 4, 8, true, 208, true, 2, true>(a, row_begin, row_end, s, info);
             return launch_scan_asm<SPACE, 4, 8, true, 208, false, 2, true>(a, row_begin, row_end, s, info);
+        }
         if constexpr (SPACE == kSpaceCosine) {
             if (nw == 8 && nkc % 2 == 0 && env_int("MLVDB_SCAN_PRIO", 0) != 0)
                 return launch_scan_asm<SPACE, 4, 8, true, 4, true>(a, row_begin, row_end, s, info);

@@ -255,6 +255,7 @@ def test_range_capacity_overflow_is_reported_then_resolved():
 
 SCAN_VARIANTS = [
     {},                                              # defaults: int8 shadow body where dim % 256 == 0, else the bf16 body below
+    {"MLVDB_SCAN_PRIO": "0"},                        # int8 body without the progress-based wave priorities
     {"MLVDB_I8": "0"},                               # bf16 body: one 8-wave workgroup per CU, Q by LDS-DMA
     {"MLVDB_I8": "0", "MLVDB_SCAN_DMA": "0"},        # Q staged through registers (global -> VGPR -> ds_write)
     {"MLVDB_I8": "0", "MLVDB_SCAN_NW": "4"},         # two 4-wave workgroups per CU

@@ -726,7 +726,9 @@ CONFIGS = [(sp, nw, r, True, 4, False, 2, False, False) for sp in SPACES for nw 
     (sp, 4, r, True, 4, False, 4, False, False) for sp in SPACES for r in (2, 4)] + [
     (sp, 8, r, True, 4, False, 2, True, False) for sp in SPACES for r in (2, 4)] + [
     (sp, 8, 4, True, 4, False, 2, True, True) for sp in SPACES]
-I8_CONFIGS = [(sp, 8, 4, True, 4, False, 2, True, False) for sp in SPACES]   # int8 shadow: QD slot 208 in the dispatch
+# int8 shadow bodies (QD slot 208 in the dispatch), with and without progress-based wave priorities: the int8 body is
+# not pinned by the power cap (pipe 56 % busy at 1.95 GHz), so evening out the barrier parking pays here (+2 %)
+I8_CONFIGS = [(sp, 8, 4, True, 4, pr, 2, True, False) for sp in SPACES for pr in (False, True)]
 # timing diagnostics (cosine, NW=8, R=4, nt): QD slot carries the knob: 101 = nolds, 102 = nox, 103 = both
 DIAG = {101: {"nolds"}, 102: {"nox"}, 103: {"nolds", "nox"}, 104: {"nolds", "nox", "nobar"},
         107: {"nohit"}, 108: {"stamp"}, 109: {"noadm"}}
@@ -742,7 +744,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8.inc" for sp in SPACES] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -750,7 +752,7 @@ def main():
         space, nw, r, nt, qd, prio, mt, dma, stag = c
         (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag))
     for space, nw, r, nt, qd, prio, mt, dma, stag in I8_CONFIGS:
-        (Path(args.outdir) / f"scan_asm_{space}_i8.inc").write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag, True))
+        (Path(args.outdir) / f"scan_asm_{space}_i8{'_pr' if prio else ''}.inc").write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag, True))
     for code, knobs in DIAG.items():
         DBG.clear()
         DBG.update(knobs)
@@ -764,8 +766,9 @@ def main():
         disp.append(("if" if i == 0 else "} else if") + f" constexpr ({cond}) {{")
         disp.append(f'#include "{inc_name(space, nw, r, nt, qd, prio, mt, dma, stag)}"')
     for sp, code in SPACES.items():
-        disp.append(f"}} else if constexpr (SPACE == {code} && NW == 8 && R == 4 && NT == true && QD == 208 && PRIO == false && MT == 2 && DMA == true && STAG == false) {{")
-        disp.append(f'#include "scan_asm_{sp}_i8.inc"')
+        for pr in (False, True):
+            disp.append(f"}} else if constexpr (SPACE == {code} && NW == 8 && R == 4 && NT == true && QD == 208 && PRIO == {'true' if pr else 'false'} && MT == 2 && DMA == true && STAG == false) {{")
+            disp.append(f'#include "scan_asm_{sp}_i8{"_pr" if pr else ""}.inc"')
     disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
     for code in DIAG:
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2 && DMA == false && STAG == false) {{")
