@@ -127,9 +127,9 @@ struct FilterArgs {
     const float* row_err8;  // device scalar: max over rows of |x - scale * x8| / |x| (rounded up)
     void* qimg8;            // int8 query image
     float* sq8;             // [256] scale of the query image
-    float* ke8;             // [257] cosine: the query's own int8 error term (row errors are per row); [256] = K = 1.016/min sq8
+    float* ke8;             // [257] cosine: the query's own int8 error term (row errors are per row); [256] = K = (1 + max eq8)/min sq8
     float* keb;             // [256] the bf16 error term: what the (bf16) seeding pass adds, while `ke` covers both kinds of entry
-    unsigned int* sqmin;    // device scalar: bits of the smallest sq8 of the pass's queries
+    unsigned int* sqmin;    // two device scalars: bits of the smallest sq8 / of the largest query error of the pass's queries
     WgEntry* wgbuf;         // [kScanMaxGrid][kWgCap] append buffers of one scan launch, one slice per wave
     uint32_t* wgcnt;        // [kScanMaxGrid * 8] entries appended per wave (may exceed the slice: the excess was flagged as overflow)
 };

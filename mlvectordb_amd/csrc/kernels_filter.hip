@@ -1285,35 +1285,41 @@ __global__ __launch_bounds__(256) void filter_prep8_kernel(const FilterArgs a) {
         const double eq8 = __builtin_sqrt(dred[0] + dred[1] + dred[2] + dred[3]) * 1.000001 + 1e-12;
         a.sq8[q] = sq;
         a.ke8[q] = q < a.nq ? float_above(eq8) : 0.f;  // finished by filter_prep8_fin_kernel
-        if (q < a.nq) atomicMin(a.sqmin, __float_as_uint(sq));  // positive floats order like their bits
+        if (q < a.nq) {
+            atomicMin(a.sqmin, __float_as_uint(sq));                    // positive floats order like their bits
+            atomicMax(a.sqmin + 1, __float_as_uint(float_above(eq8)));  // the largest query error of the pass
+        }
     }
 }
 
 // Second phase (one block): the error terms that need the smallest query scale of the pass.
-//   cosine  rows carry their own error b: the scan tests  w + b K >= (thr - ke8)/sq8  with K = 1.016/min sq8, i.e. the
-//           bound u = sq8 w + ke8 + 1.016 b sq8/min sq8 >= <q^,x>/|x|;  ke8 = eq8 + roundings + slack
-//   l2, ip  index-wide row error: ke = eq8 + 1.016 rmax8 + roundings + slack (x |x|)
+//   cosine  rows carry their own error b: the scan tests  w + b K >= (thr - ke8)/sq8  with K = (1 + max eq8)/min sq8,
+//           i.e. the bound u = sq8 w + ke8 + (1 + max eq8) b sq8/min sq8 >= <q^,x>/|x|;  ke8 = eq8 + roundings + slack
+//           (|q8 image| <= 1 + eq8: a query with one dominant component quantises its small ones badly, eq8 ~ 0.1)
+//   l2, ip  index-wide row error: ke = eq8 + (1 + eq8) rmax8 + roundings + slack (x |x|)
 //   keb     the bf16 term (filter_prep_kernel's ke): what the bf16 seeding pass adds to its bounds
 //   ke      covers both kinds of entry (the update kernel's lower bounds u - 2 eps): the larger of the two, with the
 //           int8 row term at its index-wide maximum
 __global__ __launch_bounds__(256) void filter_prep8_fin_kernel(const FilterArgs a) {
     const int q = threadIdx.x;
-    const float sqmin = __uint_as_float(*a.sqmin);
+    const float sqmin = __uint_as_float(a.sqmin[0]);
+    const double eqmax = (double)__uint_as_float(a.sqmin[1]);
     const double eq8 = (double)a.ke8[q];
     const double ratio = a.space == kSpaceCosine && q < a.nq ? (double)a.sq8[q] / (double)sqmin * 1.000001 : 1.0;
     const double rnd = 4.0 * 5.9604644775390625e-08;  // float(I) * rp8 (+ b K) * sq8: roundings of a value <= ~1
     const double slack = (a.space == kSpaceCosine ? 2.0 : 1.0) * (double)kSlack;
-    const double e8 = eq8 + 1.016 * (double)*a.row_err8 * ratio + rnd;
+    const double e8 = eq8 + (1.0 + (a.space == kSpaceCosine ? eqmax : eq8)) * 1.000001 * (double)*a.row_err8 * ratio + rnd;
     const double eb = (double)a.ke[q];  // bf16 term incl. its slack (filter_prep_kernel)
     a.keb[q] = a.ke[q];
     const double big = (e8 * 1.000001 + slack) > eb ? (e8 * 1.000001 + slack) : eb;
     a.ke[q] = float_above(big);
     a.ke8[q] = float_above((eq8 + rnd) * 1.000001 + slack);
-    if (q == 0) a.ke8[kFilterQueries] = float_above(1.016 / (double)sqmin * 1.000001);
+    if (q == 0) a.ke8[kFilterQueries] = float_above((1.0 + eqmax) / (double)sqmin * 1.000001);
 }
 
 hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s) {
     hipError_t e = hipMemsetAsync(a.sqmin, 0x7f, sizeof(unsigned int), s);  // 3.39e38: above every scale
+    if (e == hipSuccess) e = hipMemsetAsync(a.sqmin + 1, 0, sizeof(unsigned int), s);  // largest query error so far
     if (e != hipSuccess) return e;
     filter_prep8_kernel<<<kFilterQueries, 256, 0, s>>>(a);
     filter_prep8_fin_kernel<<<1, kFilterQueries, 0, s>>>(a);

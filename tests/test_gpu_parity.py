@@ -450,3 +450,27 @@ def test_int8_shadow_and_rows_with_outlier_components(space, dtype):
         assert_knn_matches(got, oracle_knn(qs, rows, 10, space), "i8/outliers")
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("space", ["cosine", "l2", "ip"])
+def test_int8_bounds_hold_for_queries_with_a_dominant_component(space):
+    """A query with one dominant component quantises its small components badly (int8 error ~0.1 of its norm, and
+    the norm of its int8 image exceeds 1): the error term must follow (1 + eq8), not a constant.  Rows of the same
+    kind make the top of the ranking a field of near-ties."""
+    rng = np.random.default_rng(5)
+    n, d, nq = 40_000, 768, 48
+    rows = rng.standard_normal((n, d)).astype(np.float32)
+    qs = (0.004 * rng.standard_normal((nq, d))).astype(np.float32)
+    axes = rng.integers(0, d, nq)
+    qs[np.arange(nq), axes] = 1.0
+    peaky = rng.choice(n, 4000, replace=False)  # rows dominated by one of the queries' axes, with individual noise
+    rows[peaky] *= 0.05
+    rows[peaky, axes[rng.integers(0, nq, peaky.size)]] = rng.uniform(2.0, 3.0, peaky.size).astype(np.float32)
+    eng = HipScanEngine(d, space, device=0, strategy="filter")
+    try:
+        eng.append(rows)
+        got = eng.search(qs, 10)
+        assert eng.last_stats()["strategy_used"] == 2
+        assert_knn_matches(got, oracle_knn(qs, rows, 10, space), f"i8/peaky/{space}")
+    finally:
+        eng.close()

@@ -315,7 +315,7 @@ def gen_admission(space):
     if I8 and space == "cosine":
         # int8 shadow, cosine: r_j = sx/(|x|+1e-30) of the row (NaN: tombstoned), p_j = the row's own rounding error,
         # accumulators = exact integer dot products I; the test is float(I)*r_j + p_j*K >= T[q] with T = (thr - ke8)/sq8
-        # rounded down and K = 1.016/min sq8 (filter_scan_asm_kernel); the append path stores the left-hand side,
+        # rounded down and K = (1 + max eq8)/min sq8 (filter_prep8_fin_kernel); the append path stores the left-hand side,
         # filter_scatter_kernel turns it into the bound u = w*sq8 + ke8
         for j in range(NR):
             a(f"v_mul_f32 %[p{j}], %[k1], %[p{j}]")
