@@ -377,8 +377,11 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
         HIP_TRY(h, launch_filter_scatter(fa, info, s));
         h->stats.scan_launches += 1;
         h->stats.rows_scanned += e - b;
-        if (fa.X8) HIP_TRY(h, launch_filter_refine_thr(fa, k, -1, s));  // exact thresholds (the int8 bounds are loose)
-        HIP_TRY(h, launch_filter_update(fa, k, s));
+        // int8 bounds are loose: thresholds from exact scores of the k best bounds; the same kernel prunes the lists
+        // (the update kernel's bound-derived threshold could only be lower) unless the query does not fit beside them
+        const bool fuse = fa.X8 && filter_refine_can_fuse(fa);
+        if (fa.X8) HIP_TRY(h, launch_filter_refine_thr(fa, k, -1, fuse, s));
+        if (!fuse) HIP_TRY(h, launch_filter_update(fa, k, s));
     }
     // counters: [0] rescored pairs, [1] fallback queries (accumulated over the passes of a call), [2] flag count
     unsigned long long* stats = h->counters.as<unsigned long long>();

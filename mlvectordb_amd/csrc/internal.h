@@ -149,7 +149,8 @@ struct ScanInfo {
 hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t row_begin,
                                int64_t row_end, int32_t ld, int32_t space, hipStream_t s);
 hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s);
-hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s);
+bool filter_refine_can_fuse(const FilterArgs& a);
+hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, bool fuse, hipStream_t s);
 hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info);
 hipError_t launch_filter_scatter(const FilterArgs& a, const ScanInfo& info, hipStream_t s);
 // dense seeding pass over rows [0,row_end), row_end <= kSeedRows: all bounds -> candidate lists -> thresholds (update)

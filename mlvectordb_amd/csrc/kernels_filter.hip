@@ -1330,30 +1330,39 @@ hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s) {
 // smallest of those k scores is a lower bound of the final k-th best score, however loose the bounds are.
 // Runs before filter_update_kernel, which keeps the larger of this and its own bound-derived threshold.
 template <int SPACE>
-__global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs a, const int32_t k, const int32_t forced_cnt) {
+__global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs a, const int32_t k, const int32_t forced_cnt,
+                                                                const bool fuse) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* qs = reinterpret_cast<double*>(smem);                                   // [ld]
     unsigned long long* red = reinterpret_cast<unsigned long long*>(qs + a.ld);     // [4]
     int32_t* pick = reinterpret_cast<int32_t*>(red + 4);                            // [64] rows picked
     double* smin = reinterpret_cast<double*>(pick + 64);                            // [4]
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smin + 4);     // [kCandCap]
+    CandEntry* stage = reinterpret_cast<CandEntry*>(keys + kCandCap);               // [kCandCap] (fuse only)
+    uint32_t* s_scan = reinterpret_cast<uint32_t*>(stage + kCandCap);               // [8] (fuse only)
     const int q = blockIdx.x;
     if (q >= a.nq || a.overflow[q]) return;
     const uint32_t cnt = forced_cnt >= 0 ? (uint32_t)forced_cnt : a.cnt[q];
-    if (cnt > (uint32_t)kCandCap || cnt < (uint32_t)k || k > 64) return;
+    if (cnt > (uint32_t)kCandCap) {  // cannot happen without the flag, but never index past the list
+        if (fuse && threadIdx.x == 0) a.overflow[q] = 1u;
+        return;
+    }
+    bool ok = cnt >= (uint32_t)k && k <= 64;  // block-uniform: enough entries to take an exact threshold from
+    if (!ok && !fuse) return;
     const int ld = a.ld;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const CandEntry* list = a.cand + (int64_t)q * kCandCap;
+    CandEntry* list = a.cand + (int64_t)q * kCandCap;
     for (int c = threadIdx.x; c < ld; c += 256) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
     // keys (order key of u, list index) once into LDS; 0 = not a candidate (NaN bound: tombstoned / padding row)
     for (uint32_t idx = threadIdx.x; idx < cnt; idx += 256) {
-        const float u = list[idx].u;
-        keys[idx] = u == u ? ((unsigned long long)float_order_key(u) << 32) | (0xffffffffu - idx) : 0ull;
+        const CandEntry e = list[idx];
+        if (fuse) stage[idx] = e;
+        keys[idx] = e.u == e.u ? ((unsigned long long)float_order_key(e.u) << 32) | (0xffffffffu - idx) : 0ull;
     }
     __syncthreads();
     // k rounds of argmax, each strictly below the previous pick
     unsigned long long prev = ~0ull;
-    for (int i = 0; i < k; ++i) {
+    for (int i = 0; ok && i < k; ++i) {
         unsigned long long best = 0;
         for (uint32_t idx = threadIdx.x; idx < cnt; idx += 256) {
             const unsigned long long key = keys[idx];
@@ -1368,7 +1377,10 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
         __syncthreads();
         best = red[0];
         for (int w = 1; w < 4; ++w) best = red[w] > best ? red[w] : best;
-        if (best == 0) return;  // fewer than k valid entries (uniform: every thread sees the same value)
+        if (best == 0) {  // fewer than k valid entries (uniform: every thread sees the same value)
+            ok = false;
+            break;
+        }
         if (threadIdx.x == 0) pick[i] = list[0xffffffffu - (uint32_t)(best & 0xffffffffu)].row;
         prev = best;
     }
@@ -1377,7 +1389,7 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
     const int g = lane >> 4, r = lane & 15;
     const double qinv = a.qaux[q];
     double smallest = __builtin_inf();
-    for (int i0 = wave * 16; i0 < k; i0 += 64) {
+    for (int i0 = wave * 16; ok && i0 < k; i0 += 64) {
         const int idx = i0 + r;
         const bool have = idx < k;
         const int32_t row = have ? pick[idx] : 0;
@@ -1398,19 +1410,53 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
     }
     if (lane == 0) smin[wave] = smallest;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    float thr = a.thr[q];
+    if (ok) {
         double sm = smin[0];
         for (int w = 1; w < 4; ++w) sm = smin[w] < sm ? smin[w] : sm;
         if (sm > -1.0e300 && sm < 1.0e300) {
             const double mag = SPACE == kSpaceL2 ? qinv * qinv + __builtin_fabs(sm) : __builtin_fabs(sm) + 1.0;
             const float t = float_below(sm - 1e-9 * mag);
-            if (t > a.thr[q]) a.thr[q] = t;
+            if (t > thr) thr = t;
         }
+    }
+    if (!fuse) {
+        if (threadIdx.x == 0) a.thr[q] = thr;
+        return;
+    }
+    // fused threshold update (what filter_update_kernel does after its own, bound-derived threshold): survivors
+    // (u >= thr; NaN bounds drop out) are compacted through LDS in list order
+    uint32_t keep = 0;
+    for (uint32_t idx = threadIdx.x * 32; idx < min(cnt, threadIdx.x * 32 + 32); ++idx) keep += stage[idx].u >= thr ? 1u : 0u;
+    uint32_t incl = keep;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    uint32_t pos = incl - keep;
+    for (int w = 0; w < wave; ++w) pos += s_scan[w];
+    const uint32_t new_cnt = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    if (new_cnt != cnt) {
+        for (uint32_t idx = threadIdx.x * 32; idx < min(cnt, threadIdx.x * 32 + 32); ++idx) {
+            const CandEntry e = stage[idx];
+            if (e.u >= thr) list[pos++] = e;
+        }
+    }
+    if (threadIdx.x == 0) {
+        a.thr[q] = thr;
+        a.cnt[q] = new_cnt;
     }
 }
 
-hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s) {
-    const size_t lds = (size_t)a.ld * sizeof(double) + 4 * 8 + 64 * 4 + 4 * 8 + (size_t)kCandCap * 8;
+// fuse: also do the threshold update's pruning (then filter_update_kernel is not needed for the round); possible while
+// the lists' LDS copy fits beside the query (ld <= 2048)
+bool filter_refine_can_fuse(const FilterArgs& a) { return a.ld <= 2048; }
+
+hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, bool fuse, hipStream_t s) {
+    const size_t lds = (size_t)a.ld * sizeof(double) + 4 * 8 + 64 * 4 + 4 * 8 + (size_t)kCandCap * 8 +
+                       (fuse ? (size_t)kCandCap * sizeof(CandEntry) + 8 * 4 : 0);
     auto kern = a.space == kSpaceL2 ? filter_refine_thr_kernel<kSpaceL2>
                 : a.space == kSpaceCosine ? filter_refine_thr_kernel<kSpaceCosine> : filter_refine_thr_kernel<kSpaceIp>;
     static bool configured[3] = {false, false, false};
@@ -1419,7 +1465,7 @@ hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forc
         if (e != hipSuccess) return e;
         configured[a.space] = true;
     }
-    kern<<<a.nq, 256, lds, s>>>(a, k, forced_cnt);
+    kern<<<a.nq, 256, lds, s>>>(a, k, forced_cnt, fuse);
     return hipGetLastError();
 }
 
@@ -1623,7 +1669,10 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
             : a.space == kSpaceCosine ? launch_scan_narrow<kSpaceCosine, true>(b, 0, rows, s)
                                       : launch_scan_narrow<kSpaceIp, true>(b, 0, rows, s);
         if (e != hipSuccess) return e;
-        if (a.X8 && (e = launch_filter_refine_thr(a, k, (int32_t)rows, s)) != hipSuccess) return e;
+        if (a.X8) {
+            const bool fuse = filter_refine_can_fuse(a);
+            if ((e = launch_filter_refine_thr(a, k, (int32_t)rows, fuse, s)) != hipSuccess || fuse) return e;
+        }
         return launch_update(a, k, (int32_t)rows, s);
     }
     FilterArgs b = a;
@@ -1643,7 +1692,10 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
             break;
     }
     if (e != hipSuccess) return e;
-    if (a.X8 && (e = launch_filter_refine_thr(a, k, (int32_t)rows, s)) != hipSuccess) return e;
+    if (a.X8) {
+        const bool fuse = filter_refine_can_fuse(a);
+        if ((e = launch_filter_refine_thr(a, k, (int32_t)rows, fuse, s)) != hipSuccess || fuse) return e;
+    }
     return launch_update(a, k, (int32_t)rows, s);  // lists -> thresholds; cnt[q] = survivors
 }
 
