@@ -663,14 +663,15 @@ int mlvdb_index_tombstone(mlvdb_index* h, const int64_t* labels, int64_t n, int6
     HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, sizeof(unsigned long long), h->stream));
     HIP_TRY(h, launch_tombstone(h->rn, h->labels_in.as<int64_t>(), n, h->total, h->counters.as<unsigned long long>(),
                                 h->stream));
+    if (h->rp8.p && h->i8_rows > 0) {  // the int8 shadow's row constants carry the tombstones too (before the sync below:
+                                       // a search on another stream may follow this call at once)
+        tombstone_rp8_kernel<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(h->labels_in.as<int64_t>(), n, h->rp8.as<float>(), h->i8_rows);
+        HIP_TRY(h, hipGetLastError());
+    }
     unsigned long long changed = 0;
     HIP_TRY(h, hipMemcpyAsync(&changed, h->counters.p, sizeof changed, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->deleted += (int64_t)changed;
-    if (h->rp8.p && h->i8_rows > 0) {  // the int8 shadow's row constants carry the tombstones too
-        tombstone_rp8_kernel<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(h->labels_in.as<int64_t>(), n, h->rp8.as<float>(), h->i8_rows);
-        HIP_TRY(h, hipGetLastError());
-    }
     if (newly_deleted) *newly_deleted = (int64_t)changed;
     return MLVDB_OK;
 }
