@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Randomised exactness campaign for the bound filters (int8 / bf16) on one GPU: for many (distribution, shape, space, batch, k,
+tombstone) draws, the filter strategy must return exactly the ids (and float32 distances) of the exact fp64 scan.
+Distributions are chosen to stress the error bounds: Gaussian, clustered (near-ties), heavy-tailed, sparse, rows and
+queries with dominant components, wide dynamic range of norms.  Prints one line per case and a summary; exits non-zero
+on any mismatch.  Not part of the test suite (minutes of GPU time)."""
+import argparse, sys, time
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from mlvectordb_amd.engine import HipScanEngine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=60)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--max-rows", type=int, default=200_000)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+
+
+def draw(kind, n, d):
+    if kind == "gauss":
+        return rng.standard_normal((n, d), dtype=np.float32)
+    if kind == "clustered":
+        c = rng.standard_normal((32, d), dtype=np.float32)
+        return (c[rng.integers(0, 32, n)] + 0.02 * rng.standard_normal((n, d), dtype=np.float32)).astype(np.float32)
+    if kind == "heavy":
+        return rng.standard_t(2.5, (n, d)).astype(np.float32)
+    if kind == "sparse":
+        x = rng.standard_normal((n, d), dtype=np.float32)
+        x[rng.random((n, d)) < 0.9] = 0.0
+        return x
+    if kind == "peaky":
+        x = (0.01 * rng.standard_normal((n, d))).astype(np.float32)
+        x[np.arange(n), rng.integers(0, d, n)] = rng.uniform(0.5, 3.0, n).astype(np.float32)
+        return x
+    if kind == "norms":
+        return (rng.standard_normal((n, d)) * np.exp(rng.uniform(-6, 6, (n, 1)))).astype(np.float32)
+    raise ValueError(kind)
+
+
+KINDS = ["gauss", "clustered", "heavy", "sparse", "peaky", "norms"]
+bad = 0
+t0 = time.time()
+for case in range(args.cases):
+    kind, qkind = KINDS[rng.integers(len(KINDS))], KINDS[rng.integers(len(KINDS))]
+    d = int(rng.choice([256, 512, 768, 1024, 320, 128]))
+    n = int(rng.integers(20_000, args.max_rows))
+    nq = int(rng.choice([1, 3, 8, 9, 40, 256, 300]))
+    k = int(rng.choice([1, 5, 10, 64]))
+    space = str(rng.choice(["cosine", "l2", "ip"]))
+    rows = draw(kind, n, d)
+    qs = draw(qkind, nq, d)
+    if rng.random() < 0.3:  # queries that are (noisy) copies of rows: exact and near matches
+        src = rng.integers(0, n, nq)
+        qs = (rows[src] * (1 + 0.001 * rng.standard_normal((nq, d)))).astype(np.float32)
+    eng = HipScanEngine(d, space, device=0, strategy="filter")
+    eng.append(rows)
+    if rng.random() < 0.5:
+        eng.tombstone(np.nonzero(rng.random(n) < 0.1)[0])
+    fl, fd, fc = eng.search(qs, k)
+    st = eng.last_stats()
+    eng.set_strategy("exact")
+    el, ed, ec = eng.search(qs, k)
+    eng.close()
+    ok = np.array_equal(fl, el) and np.array_equal(fc, ec) and np.array_equal(fd, ed)
+    bad += not ok
+    print(f"case {case:3d} {'ok ' if ok else 'BAD'} rows {kind:9s} queries {qkind:9s} {space:6s} n {n:6d} d {d:4d} nq {nq:3d} k {k:2d} "
+          f"dtype {st['bound_dtype']} fallback {st['fallback_queries']:3d} rescored/q {st['candidates_rescored'] / max(1, nq):8.1f}", flush=True)
+print(f"{args.cases - bad} of {args.cases} cases identical to the exact scan in {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
