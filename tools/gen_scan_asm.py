@@ -317,6 +317,10 @@ def gen_admission(space):
         # accumulators = exact integer dot products I; the test is float(I)*r_j + p_j*K >= T[q] with T = (thr - ke8)/sq8
         # rounded down and K = (1 + max eq8)/min sq8 (filter_prep8_fin_kernel); the append path stores the left-hand side,
         # filter_scatter_kernel turns it into the bound u = w*sq8 + ke8
+        if "noadm" in DBG:   # timing diagnostic: no admission test at all (labels only: the hit stubs refer to them)
+            for n in range(16):
+                a(f".Lback{n}_%=:")
+            return s.lines
         for j in range(NR):
             a(f"v_mul_f32 %[p{j}], %[k1], %[p{j}]")
         s.lds(f"ds_read_b32 %[e0], %[thra]", ("thr", 0))
@@ -744,7 +748,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -758,6 +762,9 @@ def main():
         DBG.update(knobs)
         (Path(args.outdir) / f"scan_asm_diag{code}.inc").write_text(generate("cosine", 4, 4, 8, True, False))
         DBG.clear()
+    DBG.update({"noadm"})   # 209: the int8 body (cosine, wave priorities) without its admission test
+    (Path(args.outdir) / "scan_asm_diag209.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True))
+    DBG.clear()
     disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT, DMA, STAG>."]
     for i, (space, nw, r, nt, qd, prio, mt, dma, stag) in enumerate(CONFIGS):
         cond = (f"SPACE == {SPACES[space]} && NW == {nw} && R == {r} && NT == {'true' if nt else 'false'} && QD == {qd}"
@@ -773,6 +780,8 @@ def main():
     for code in DIAG:
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2 && DMA == false && STAG == false) {{")
         disp.append(f'#include "scan_asm_diag{code}.inc"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 209 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
+    disp.append('#include "scan_asm_diag209.inc"')
     disp.append("#endif")
     disp.append("} else {")
     disp.append('    static_assert(SPACE < 0, "configuration not generated: add it to CONFIGS in tools/gen_scan_asm.py");')
