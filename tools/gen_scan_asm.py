@@ -329,7 +329,8 @@ def gen_admission(space):
                 s.lds(f"ds_read_b32 %[e{(n + 1) & 1}], %[thra] offset:{(n + 1) * 64}", ("thr", n + 1))
             for j in range(NR):
                 m, i = j >> 2, j & 3
-                a(f"v_accvgpr_read_b32 %[u{j}], a{(m * 16 + n) * 4 + i}")
+                if "noread" not in DBG:   # timing diagnostic: the test's arithmetic on stale registers
+                    a(f"v_accvgpr_read_b32 %[u{j}], a{(m * 16 + n) * 4 + i}")
             for j in range(NR):
                 a(f"v_cvt_f32_i32 %[u{j}], %[u{j}]")
             for j in range(NR):
@@ -343,7 +344,8 @@ def gen_admission(space):
             a("v_max_f32 %[e4], %[e4], %[e5]")
             s.need_lg(("thr", n))
             a(f"v_cmp_ge_f32 vcc, %[e4], %[e{n & 1}]")
-            a(f"s_cbranch_vccnz .Lhit{n}_%=")
+            if "nohit" not in DBG:
+                a(f"s_cbranch_vccnz .Lhit{n}_%=")
             a(f".Lback{n}_%=:")
         return s.lines
     for j in range(NR):
@@ -748,7 +750,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -764,6 +766,9 @@ def main():
         DBG.clear()
     DBG.update({"noadm"})   # 209: the int8 body (cosine, wave priorities) without its admission test
     (Path(args.outdir) / "scan_asm_diag209.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True))
+    DBG.clear()
+    DBG.update({"noread", "nohit"})   # 210: ... with the test's arithmetic but without the accumulator reads (and no hits)
+    (Path(args.outdir) / "scan_asm_diag210.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True))
     DBG.clear()
     disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT, DMA, STAG>."]
     for i, (space, nw, r, nt, qd, prio, mt, dma, stag) in enumerate(CONFIGS):
@@ -782,6 +787,8 @@ def main():
         disp.append(f'#include "scan_asm_diag{code}.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 209 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_diag209.inc"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 210 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
+    disp.append('#include "scan_asm_diag210.inc"')
     disp.append("#endif")
     disp.append("} else {")
     disp.append('    static_assert(SPACE < 0, "configuration not generated: add it to CONFIGS in tools/gen_scan_asm.py");')
