@@ -9,11 +9,12 @@ GPU is present.
 from .interfaces import (IndexProtocol, QueryProcessorProtocol, SearchResultProtocol, VectorDTO,  # noqa: F401
                          VectorProtocol)
 from .vector import Vector  # noqa: F401
+from .simple_vector import SimpleVector  # noqa: F401
 from .index import Index, SearchResult  # noqa: F401
 from .query_processor import QueryProcessor  # noqa: F401
 from .storage import InMemoryStorage  # noqa: F401
 from .engine import HipScanEngine, ScanEngine  # noqa: F401
 
-__all__ = ["Index", "SearchResult", "QueryProcessor", "InMemoryStorage", "Vector", "VectorDTO",
+__all__ = ["Index", "SearchResult", "QueryProcessor", "InMemoryStorage", "Vector", "SimpleVector", "VectorDTO",
            "VectorProtocol", "IndexProtocol", "SearchResultProtocol", "QueryProcessorProtocol",
            "HipScanEngine", "ScanEngine"]

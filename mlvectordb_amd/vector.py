@@ -12,6 +12,8 @@ from uuid import UUID
 
 import numpy as np
 
+from . import pairwise
+
 
 class Vector:
     __slots__ = ("_id", "_values", "_metadata")
@@ -35,6 +37,17 @@ class Vector:
 
     def shape(self) -> tuple:
         return self._values.shape
+
+    # ---- pairwise arithmetic (reference README.md:30-41,178-181 names the methods; definitions: pairwise.py)
+    def distance(self, other, metric: str = "euclidean") -> float:
+        return pairwise.distance(self._values, getattr(other, "values", other), metric)
+
+    def similarity(self, other, metric: str = "cosine") -> float:
+        return pairwise.similarity(self._values, getattr(other, "values", other), metric)
+
+    def normalize(self) -> "Vector":
+        """A new vector (new id, same metadata) with values x / (|x| + 1e-30)."""
+        return Vector(pairwise.normalize(self._values), self._metadata)
 
     def __repr__(self) -> str:
         return f"Vector(id={self._id}, dim={self.shape()}, metadata={self._metadata})"
