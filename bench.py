@@ -30,6 +30,16 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+def kernel_source_sha16() -> str:
+    """Hash of the sources the scan kernels are built from: ties a committed PMC measurement to a kernel version."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for rel in ("mlvectordb_amd/csrc/kernels_filter.hip", "mlvectordb_amd/csrc/scan_common.h", "tools/gen_scan_asm.py"):
+        h.update((ROOT / rel).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def log(msg: str) -> None:
     print(f"[bench r{os.environ.get('RANK', '0')}] {msg}", file=sys.stderr, flush=True)
 
@@ -89,6 +99,46 @@ def config1_side(device: int) -> dict:
     return res
 
 
+def config4_side(eng_l2, q_host: np.ndarray, k: int) -> dict:
+    """BASELINE configs[3]: squared-l2 kNN + range query (radius = mean k-th neighbour distance) over the
+    same 10M x 768 rows, batch 256, host-pointer entries (PCIe of queries / results included).  Parity: kNN and range
+    hits of every query against the exact fp64 scans."""
+    nq = q_host.shape[0]
+    labels, dist, _ = eng_l2.search(q_host, k)
+    st = eng_l2.last_stats()
+    eng_l2.set_strategy("exact")
+    ex_l, ex_d, _ = eng_l2.search(q_host, k)
+    eng_l2.set_strategy("auto")
+    t = []
+    for _ in range(10):
+        ts = time.perf_counter()
+        eng_l2.search(q_host, k)
+        t.append(time.perf_counter() - ts)
+    knn_ms = float(np.median(t)) * 1e3
+    radius = float(dist[:, k - 1].mean())
+    hits = eng_l2.range(q_host, radius, 8192)
+    st_r = eng_l2.last_stats()
+    t = []
+    for _ in range(10):
+        ts = time.perf_counter()
+        eng_l2.range(q_host, radius, 8192)
+        t.append(time.perf_counter() - ts)
+    range_ms = float(np.median(t)) * 1e3
+    eng_l2.set_strategy("exact")
+    hits_exact = eng_l2.range(q_host, radius, 8192)
+    eng_l2.set_strategy("auto")
+    nh = [len(h[0]) for h in hits]
+    range_ok = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(hits, hits_exact))
+    return {"knn_ms_per_wave_host_io": round(knn_ms, 3), "knn_qps": round(nq / knn_ms * 1e3, 1),
+            "knn_bound_dtype": {1: "bf16", 2: "i8"}.get(st.get("bound_dtype"), "?"),
+            "range_ms_per_wave_host_io": round(range_ms, 3), "range_qps": round(nq / range_ms * 1e3, 1),
+            "range_over_knn": round(range_ms / knn_ms, 3), "range_fallback_queries": int(st_r["fallback_queries"]),
+            "radius_squared_l2": radius, "mean_hits_per_query": float(np.mean(nh)), "max_hits": int(max(nh)),
+            "parity": {"knn_ids_equal_exact_scan_all_queries": bool(np.array_equal(labels, ex_l)),
+                       "knn_max_abs_err": float(np.abs(dist - ex_d).max()),
+                       "range_hits_equal_exact_range_scan_all_queries": bool(range_ok)}}
+
+
 def main() -> None:
     args = parse_args()
     # stdout carries exactly one JSON line: libraries that print there (gloo's rendezvous banner does) go to stderr
@@ -127,9 +177,15 @@ def main() -> None:
     # ---- shard: seeded N(0,1) rows, generated on the host in 1M-row chunks, appended to HBM
     t0 = time.perf_counter()
     eng = HipScanEngine(d, args.space, device=local_rank, capacity_hint=n_local, strategy=args.strategy)
+    # BASELINE configs[3] (squared-l2 kNN + range query on the same rows) is measured beside the headline at N=1:
+    # its index is filled from the same generated pieces (one more upload per piece, no second generation)
+    want_cfg4 = world == 1 and not args.no_extras and args.space == "cosine" and args.tombstones == 0.0
+    eng_l2 = HipScanEngine(d, "l2", device=local_rank, capacity_hint=n_local) if want_cfg4 else None
     sample_rows = None
     for off, rows in synth.iter_corpus(row0, n_local, d, threads=threads):
         eng.append(rows)
+        if eng_l2 is not None:
+            eng_l2.append(rows)
         if rank == 0 and off == 0:
             sample_rows = rows.copy()  # first 250k rows, reused for the parity gate
     if args.tombstones > 0.0:
@@ -212,11 +268,12 @@ def main() -> None:
     local_wave()
     torch.cuda.synchronize()
     stats0 = eng.last_stats()
-    fast_ids = lab[:8].cpu().numpy().copy()
-    fast_dist = dst[:8].cpu().numpy().copy()
+    fast_ids = lab.cpu().numpy().copy()
+    fast_dist = dst.cpu().numpy().copy()
     eng.set_strategy("exact")
-    ex_l, ex_d, _ = eng.search(q_host[:8], k)
+    ex_l, ex_d, _ = eng.search(q_host, k)  # every query of the wave against the exact fp64 scan of the whole shard
     eng.set_strategy(args.strategy)
+    verify["queries_compared"] = int(batch)
     verify["filter_equals_exact_scan_ids"] = bool(np.array_equal(fast_ids, ex_l))
     verify["filter_equals_exact_scan_max_abs_err"] = float(np.abs(fast_dist - ex_d).max())
     if rank == 0 and sample_rows is not None:
@@ -242,8 +299,24 @@ def main() -> None:
         if rank == 0:
             verify["sharded_merge_equals_exact_ids"] = bool(np.array_equal(merged_fast[0], merged_exact[0]))
             verify["sharded_merge_max_abs_err"] = float(np.abs(merged_fast[1] - merged_exact[1]).max())
-    if not verify["filter_equals_exact_scan_ids"] or verify.get("oracle_ids_equal") is False:
+    gate_red = (not verify["filter_equals_exact_scan_ids"] or verify["filter_equals_exact_scan_max_abs_err"] > 1e-5
+                or verify.get("oracle_ids_equal") is False or verify.get("oracle_max_abs_err", 0.0) > 1e-5
+                or verify.get("sharded_merge_equals_exact_ids") is False)
+    if world > 1:  # one red rank fails the whole job: every rank learns it and exits non-zero after this exchange
+        flag = torch.tensor([1.0 if gate_red else 0.0], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        gate_red = bool(flag.item() > 0)
+    if gate_red:
         log(f"PARITY GATE FAILED: {verify}")
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps({"metric": "queries/sec, exact cosine kNN k=10 over a row-sharded Nx768 fp32 corpus (10M rows per GPU)",
+                                           "value": None, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+                                           "warmup": args.warmup, "error": "parity gate failed: results differ from the exact scan / oracle",
+                                           "parity_gate": verify}) + "\n").encode())
+        if world > 1:
+            dist.destroy_process_group()
+        sys.exit(1)
 
     # ---- timed region
     def barrier():
@@ -278,14 +351,22 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    # latency of a single wave (host-synchronised), measured outside the throughput region
-    per_step = []
+    # latency of a single wave (host-synchronised), measured outside the throughput region.  Device-resident: queries
+    # and outputs already in HBM.  host_io (SURVEY 8d's latency definition): the host-pointer entry, i.e. H2D of the
+    # queries and D2H of labels / distances / counts included.
+    per_step, per_step_io = [], []
     for _ in range(10):
         torch.cuda.synchronize()
         ts = time.perf_counter()
         step()
         torch.cuda.current_stream().synchronize()
         per_step.append(time.perf_counter() - ts)
+    if world == 1:
+        for _ in range(12):
+            ts = time.perf_counter()
+            eng.search(q_host, k)
+            per_step_io.append(time.perf_counter() - ts)
+        per_step_io = per_step_io[2:]
 
     ms_per_step = elapsed / args.steps * 1e3
     shard_queries_per_s = world * batch * args.steps / elapsed  # one unit = one query against one 10M-row shard
@@ -295,26 +376,51 @@ def main() -> None:
     alg_bytes_scan = float(rows_scanned) * (d * 4 + 4) + args.steps * passes * (256 * d * 2)
     roofline = None
     if scan_ms > 0:
-        achieved = alg_bytes_scan / (scan_ms * 1e-3) / 1e9
-        traffic = None
-        i8 = stats0.get("bound_dtype") == 2  # the int8 shadow computed the bounds (cosine, dim % 256 == 0)
-        tfile = ROOT / "profiles" / "r01" / ("pmc_traffic_i8.json" if i8 else "pmc_traffic.json")
-        if stats0["strategy_used"] == 2 and n_local == 10_000_000 and d == 768 and tfile.exists():
-            # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-            # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); counters cannot be read from inside the process
-            traffic = json.loads(tfile.read_text())["traffic_bytes_per_launch_avg"]
-        flops = 2.0 * float(rows_scanned) * d * 256  # rows_scanned sums the launches of every 256-query pass
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                    "traffic_source": f"profiles/r01/{tfile.name} (rocprofv3 --pmc, separate passes)" if traffic else None,
-                    "hbm_actual_frac": round(traffic * scan_launches / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-                    # matrix-core rate of the scan against the dense peak of its operand type (bf16 2.5 PFLOP/s, int8 5 POP/s)
-                    "mfma_dtype": ("i8" if i8 else "bf16") if stats0["strategy_used"] == 2 else None,
-                    "mfma_frac": round(flops / (scan_ms * 1e-3) / (5.0e15 if i8 else 2.5e15), 4) if stats0["strategy_used"] == 2 else None,
-                    "kernel": "filter_scan_asm_kernel" if stats0["strategy_used"] == 2 else "exact_scan_kernel",
+        scan_s = scan_ms * 1e-3
+        filt = stats0["strategy_used"] == 2
+        i8 = filt and stats0.get("bound_dtype") == 2  # the int8 shadow computed the bounds (dim % 256 == 0)
+        # Two physical floors of the scan kernel as built: the matrix-core time of 2*rows*d*256 multiply-adds
+        # at the dense peak of the operand type, and the HBM time of the bytes the kernel has to move -- the shadow it
+        # streams (1 B / 2 B per element) + 8 B / 4 B of row constants per row + the query image.  The roof that binds
+        # is the slower floor; `frac` = that floor / measured time (<= 1 by construction).  SURVEY 8d's accounting (the
+        # fp32 corpus bytes, which this kernel does not read) stays beside it as alg_hbm_*.
+        elem = 1 if i8 else (2 if filt else 4)
+        rowc = 8 if i8 else 4
+        min_bytes = float(rows_scanned) * (d * elem + rowc) + args.steps * passes * 3 * (256 * d * elem)
+        mfma_peak = (5.0e15 if i8 else 2.5e15) if filt else 157.3e12
+        flops = 2.0 * float(rows_scanned) * d * 256 if filt else 2.0 * float(rows_scanned) * d * min(batch, 8)
+        t_mfma, t_hbm = flops / mfma_peak, min_bytes / (HBM_PEAK_GBS * 1e9)
+        bound = "mfma" if (filt and t_mfma >= t_hbm) else "hbm"
+        # measured HBM traffic: rocprofv3 PMC passes of this same command (separate runs; counters cannot be read from
+        # inside the process).  The file records the hash of the kernel sources it was measured on: stale = ignored.
+        traffic, tsrc = None, None
+        tfile = ROOT / "profiles" / "r02" / ("pmc_traffic_i8.json" if i8 else "pmc_traffic.json")
+        if filt and n_local == 10_000_000 and d == 768 and tfile.exists():
+            tj = json.loads(tfile.read_text())
+            if tj.get("kernel_source_sha16") == kernel_source_sha16():
+                traffic = tj["traffic_bytes_per_launch_avg"]
+                tsrc = f"profiles/r02/{tfile.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same kernel sources)"
+            else:
+                tsrc = f"profiles/r02/{tfile.name} is stale (kernel sources changed since it was measured): not reported"
+        if bound == "mfma":
+            achieved, peak, unit = flops / scan_s / 1e12, mfma_peak / 1e12, "TFLOP/s"
+        else:
+            achieved, peak, unit = min_bytes / scan_s / 1e9, HBM_PEAK_GBS, "GB/s"
+        roofline = {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                    "kernel": "filter_scan_asm_kernel" if filt else "exact_scan_kernel",
+                    "operand_dtype": ("i8" if i8 else "bf16") if filt else "f32->f64",
                     "avg_launch_ms": round(scan_ms / max(1, scan_launches), 4), "launches": scan_launches,
+                    "floors_ms_per_launch": {"mfma": round(t_mfma / max(1, scan_launches) * 1e3, 4),
+                                             "hbm_min_bytes": round(t_hbm / max(1, scan_launches) * 1e3, 4)},
+                    "min_bytes_per_launch": round(min_bytes / max(1, scan_launches)),
+                    "mfma_frac": round(flops / scan_s / mfma_peak, 4) if filt else None,
+                    "hbm_min_bytes_frac": round(min_bytes / scan_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "hbm_actual_frac": round(traffic * scan_launches / scan_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                    # SURVEY 8d accounting (fp32 corpus bytes per wave; > 1 means: the kernel streams a narrower shadow)
                     "alg_bytes_per_launch": round(alg_bytes_scan / max(1, scan_launches)),
-                    "whole_wave_frac": round(alg_bytes_wave * passes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    "alg_hbm_frac": round(alg_bytes_scan / scan_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "alg_hbm_whole_wave_frac": round(alg_bytes_wave * passes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                     if world == 1 else None}
 
     if rank != 0:
@@ -340,6 +446,7 @@ def main() -> None:
                    "sharding": f"row-wise over {world} ranks, host merge of per-shard top-k"},
         "whole_corpus_qps": round(batch * args.steps / elapsed, 1),
         "p50_ms_per_wave": round(float(np.median(per_step)) * 1e3, 3),
+        "p50_ms_per_wave_host_io": round(float(np.median(per_step_io)) * 1e3, 3) if per_step_io else None,
         "roofline": roofline,
         "candidates_rescored_per_query": round(rescored / max(1, args.steps * batch), 1),
         "fallback_queries": int(fallbacks),
@@ -409,6 +516,16 @@ def main() -> None:
             out["config2_1Mx768_batch1"] = side
         if not args.no_extras:
             out["config1_10kx128_find_similar"] = config1_side(local_rank)
+    if eng_l2 is not None:
+        out["config4_10Mx768_l2_range"] = config4_side(eng_l2, q_host, k)
+        eng_l2.close()
+        c4 = out["config4_10Mx768_l2_range"]["parity"]
+        if not (c4["knn_ids_equal_exact_scan_all_queries"] and c4["range_hits_equal_exact_range_scan_all_queries"]):
+            log(f"PARITY GATE FAILED (configs[3]): {c4}")
+            out["value"] = None
+            out["error"] = "configs[3] parity failed"
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+            sys.exit(1)
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
