@@ -176,18 +176,25 @@ def main() -> None:
 
     # ---- shard: seeded N(0,1) rows, generated on the host in 1M-row chunks, appended to HBM
     t0 = time.perf_counter()
-    eng = HipScanEngine(d, args.space, device=local_rank, capacity_hint=n_local, strategy=args.strategy)
+    # The shard is filled through the Protocol-level objects (QueryProcessor -> ArrayStorage + Index.add_arrays: ids
+    # minted, rows appended to HBM, no host copy kept); the engine-level measurements below drive the namespace's
+    # mlvdb_index directly, the protocol-level one (protocol_qps) goes back through QueryProcessor.
+    from mlvectordb_amd import ArrayStorage, Index, QueryProcessor
+
+    index = Index(space=args.space, device=local_rank, strategy=args.strategy, capacity_hint=n_local)
+    qp = QueryProcessor(ArrayStorage(), index)
     # BASELINE configs[3] (squared-l2 kNN + range query on the same rows) is measured beside the headline at N=1:
     # its index is filled from the same generated pieces (one more upload per piece, no second generation)
     want_cfg4 = world == 1 and not args.no_extras and args.space == "cosine" and args.tombstones == 0.0
     eng_l2 = HipScanEngine(d, "l2", device=local_rank, capacity_hint=n_local) if want_cfg4 else None
     sample_rows = None
     for off, rows in synth.iter_corpus(row0, n_local, d, threads=threads):
-        eng.append(rows)
+        qp.upsert_arrays(rows, "bench", keep_host_copy=False)
         if eng_l2 is not None:
             eng_l2.append(rows)
         if rank == 0 and off == 0:
             sample_rows = rows.copy()  # first 250k rows, reused for the parity gate
+    eng = index._ns["bench"].engine
     if args.tombstones > 0.0:
         dead = np.nonzero(np.random.default_rng([99, rank]).random(n_local) < args.tombstones)[0].astype(np.int64)
         eng.tombstone(dead)
@@ -516,6 +523,39 @@ def main() -> None:
             out["config2_1Mx768_batch1"] = side
         if not args.no_extras:
             out["config1_10kx128_find_similar"] = config1_side(local_rank)
+    # ---- the same workload through the Protocol surface: QueryProcessor.find_similar_many over Index.search_many
+    # (reference query_processor.py:26-49 batched).  Every hit comes back as {"id": UUID, "values": float32[d],
+    # "metadata", "score"}; values are gathered from the index's rows in HBM.  "stream" = find_similar_stream: the scan
+    # of wave i+1 overlaps the enrichment of wave i (one worker thread inside the GIL-free ctypes call).
+    if world == 1 and args.tombstones == 0.0 and not args.no_extras:
+        wave_hits = qp.find_similar_many(q_host, top_k=k, namespace="bench", metric=args.space)  # warm-up + check
+        table = index._ns["bench"].ids
+        proto_ok = all([h["id"] for h in wave_hits[i]] == table.uuids_at(fast_ids[i]).tolist() for i in range(batch))
+        proto_ok = proto_ok and all(np.array_equal(h["values"], eng.get_rows(int(l), 1)[0])
+                                    for i in (0, batch - 1) for h, l in zip(wave_hits[i], fast_ids[i]))
+        lat = []
+        for _ in range(8):
+            ts = time.perf_counter()
+            qp.find_similar_many(q_host, top_k=k, namespace="bench", metric=args.space)
+            lat.append(time.perf_counter() - ts)
+        n_hits, ts = 0, time.perf_counter()
+        for hits in qp.find_similar_stream((q_host for _ in range(args.steps)), top_k=k, namespace="bench", metric=args.space):
+            n_hits += sum(len(h) for h in hits)
+        t_stream = time.perf_counter() - ts
+        out["protocol_qps"] = round(batch * args.steps / t_stream, 1)
+        out["protocol"] = {"path": "QueryProcessor.find_similar_stream -> Index.search_many -> mlvdb_search_batch_ex; "
+                                   "ArrayStorage (ids + metadata on the host, values gathered from HBM)",
+                           "ms_per_wave_stream": round(t_stream / args.steps * 1e3, 3),
+                           "p50_ms_find_similar_many": round(float(np.median(lat)) * 1e3, 3),
+                           "protocol_over_engine_qps": round(batch * args.steps / t_stream / shard_queries_per_s, 3),
+                           "hits_materialised_per_wave": n_hits // args.steps,
+                           "ids_and_values_equal_engine_level_result": bool(proto_ok)}
+        if not proto_ok:
+            log("PARITY GATE FAILED (protocol path): ids / values differ from the engine-level result")
+            out["value"] = None
+            out["error"] = "protocol-level results differ from the engine-level results"
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+            sys.exit(1)
     if eng_l2 is not None:
         out["config4_10Mx768_l2_range"] = config4_side(eng_l2, q_host, k)
         eng_l2.close()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLVDB_ABI_VERSION 2
+#define MLVDB_ABI_VERSION 3
 
 /* status codes */
 #define MLVDB_OK 0
@@ -126,6 +126,10 @@ int mlvdb_index_reset(mlvdb_index* h, int32_t space);
 
 /* Copy rows [first, first+n) back to the host in row-major order (tombstoned rows included). */
 int mlvdb_index_get_rows(mlvdb_index* h, int64_t first, int64_t n, float* out_rows);
+/* Copy the rows of `labels` (host, n entries, any order, repeats allowed) back to the host: out_rows [n, dim].
+ * What a caller without a second copy of the corpus uses to enrich the hits of a query wave with their values
+ * (QueryProcessor.find_similar's "values" field: query_processor.py:42-47). */
+int mlvdb_index_get_rows_at(mlvdb_index* h, const int64_t* labels, int64_t n, float* out_rows);
 
 /*
  * Batched exact kNN.  Replaces hnswlib knn_query (index.py:111) for nq >= 1 queries.
@@ -156,6 +160,14 @@ int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64
  */
 int mlvdb_search_batch_filtered(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, const uint8_t* row_mask,
                                 int64_t* out_labels, float* out_dist, int32_t* out_counts);
+
+/*
+ * The general host-pointer form: row_mask (optional, NULL = no restriction) as in mlvdb_search_batch_filtered, and
+ * out_dist64 (optional, NULL = not wanted) [nq, k] the unrounded fp64 distances -- what a caller that merges the
+ * answers of several indexes (row shards of one namespace: one mlvdb_index per GPU) must rank on.
+ */
+int mlvdb_search_batch_ex(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, const uint8_t* row_mask,
+                          int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_dist64);
 
 /*
  * Batched range query: every live row with distance <= radius (distance in the

@@ -10,11 +10,11 @@ from .interfaces import (IndexProtocol, QueryProcessorProtocol, SearchResultProt
                          VectorProtocol)
 from .vector import Vector  # noqa: F401
 from .simple_vector import SimpleVector  # noqa: F401
-from .index import Index, SearchResult  # noqa: F401
+from .index import BatchHits, Index, SearchResult  # noqa: F401
 from .query_processor import QueryProcessor  # noqa: F401
-from .storage import InMemoryStorage  # noqa: F401
+from .storage import ArrayStorage, InMemoryStorage  # noqa: F401
 from .engine import HipScanEngine, ScanEngine  # noqa: F401
 
-__all__ = ["Index", "SearchResult", "QueryProcessor", "InMemoryStorage", "Vector", "SimpleVector", "VectorDTO",
+__all__ = ["Index", "SearchResult", "BatchHits", "QueryProcessor", "InMemoryStorage", "ArrayStorage", "Vector", "SimpleVector", "VectorDTO",
            "VectorProtocol", "IndexProtocol", "SearchResultProtocol", "QueryProcessorProtocol",
            "HipScanEngine", "ScanEngine"]

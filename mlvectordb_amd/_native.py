@@ -18,7 +18,7 @@ SPACE_CODES = {"l2": 0, "cosine": 1, "ip": 2}
 STRATEGY_CODES = {"auto": 0, "exact": 1, "filter": 2}
 MAX_TOPK = 64
 MAX_TOPK_PAGED = 16384
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class Stats(C.Structure):
@@ -51,8 +51,10 @@ SIGNATURES = {
     "mlvdb_index_counts": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mlvdb_index_reset": (C.c_int, [_P, C.c_int32]),
     "mlvdb_index_get_rows": (C.c_int, [_P, C.c_int64, C.c_int64, _P]),
+    "mlvdb_index_get_rows_at": (C.c_int, [_P, _P, C.c_int64, _P]),
     "mlvdb_search_batch": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P]),
     "mlvdb_search_batch_filtered": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P]),
+    "mlvdb_search_batch_ex": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
     "mlvdb_search_batch_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
     "mlvdb_range_batch": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int64, _P, _P, _P]),
     "mlvdb_index_set_strategy": (C.c_int, [_P, C.c_int32]),

@@ -56,6 +56,8 @@ struct mlvdb_index {
     float* rn = nullptr;  // row norms, NaN = tombstoned / not a row
     int64_t capacity = 0, total = 0, deleted = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;  // mlvdb_index_get_rows_at: a hit-enrichment gather must not queue behind the next scan
+    DevBuf gather_out, gather_lab;     // its private buffers (a search may be running on `stream` from another host thread)
     // workspaces (grow only)
     DevBuf stage, qpad, qaux, partial, qsel, seed_lab, seed_dist, seed_cnt, seed_d64;
     DevBuf row_mask, rn_masked;  // filtered search
@@ -65,7 +67,7 @@ struct mlvdb_index {
     int64_t i8_rows = 0;      // rows [0, i8_rows) of the int8 shadow are current (0 after compact / reset / regrowth)
     float i8_err = 0.f;       // host copy of rowerr8 (read back whenever rows were converted)
     bool mask_active = false;  // h->rn is a masked copy (mlvdb_search_batch_filtered): the int8 rp8 knows no masks
-    DevBuf qimg, fmisc, cand, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, counters, labels_in;
+    DevBuf qimg, fmisc, cand, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, io_d64, counters, labels_in;
     DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
     uint32_t* host_flags = nullptr;  // pinned, kFilterQueries words
     bool host_overflow[256] = {};    // flags of the last collect_overflow
@@ -569,7 +571,8 @@ int mlvdb_index_create(int device, int32_t dim, int32_t space, int64_t capacity_
         delete h;
         return fail(nullptr, MLVDB_ERR_HIP, "hipStreamCreate", e);
     }
-    e = h->counters.ensure(64);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = h->counters.ensure(64);
     if (e != hipSuccess) {
         mlvdb_index_destroy(h);
         return fail(nullptr, MLVDB_ERR_HIP, "hipMalloc(counters)", e);
@@ -595,7 +598,7 @@ int mlvdb_index_destroy(mlvdb_index* h) {
     if (h->rn) (void)hipFree(h->rn);
     if (h->Xb) (void)hipFree(h->Xb);
     for (DevBuf* b : {&h->stage, &h->qpad, &h->qaux, &h->partial, &h->qsel, &h->seed_lab, &h->seed_dist, &h->seed_cnt,
-                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->qerr, &h->rowerr, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt,
+                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->qerr, &h->rowerr, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt, &h->io_d64, &h->gather_out, &h->gather_lab, &h->x8, &h->rp8, &h->rowerr8, &h->qimg8, &h->sq8,
                       &h->counters, &h->labels_in, &h->page_lab, &h->page_dist, &h->page_cnt, &h->page_d64, &h->cur_d,
                       &h->cur_l})
         b->release();
@@ -607,6 +610,7 @@ int mlvdb_index_destroy(mlvdb_index* h) {
     for (auto& ev : h->total_events)
         if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     delete h;
     return MLVDB_OK;
 }
@@ -775,6 +779,29 @@ int mlvdb_index_get_rows(mlvdb_index* h, int64_t first, int64_t n, float* out_ro
     return MLVDB_OK;
 }
 
+int mlvdb_index_get_rows_at(mlvdb_index* h, const int64_t* labels, int64_t n, float* out_rows) {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!labels || !out_rows))) return fail(h, MLVDB_ERR_INVALID_ARG, "bad labels / n / out_rows");
+    for (int64_t i = 0; i < n; ++i)
+        if (labels[i] < 0 || labels[i] >= h->total) return fail(h, MLVDB_ERR_INVALID_ARG, "label out of range");
+    // Own stream and buffers: rows are immutable once appended, so this may overlap a search that another host thread
+    // has in flight on h->stream (QueryProcessor.find_similar_stream enriches wave i while wave i+1 is scanned).
+    hipStream_t s = h->aux_stream;
+    const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(64u << 20) / ((int64_t)h->dim * 4));
+    for (int64_t done = 0; done < n; done += chunk_rows) {
+        const int64_t m = std::min(chunk_rows, n - done);
+        HIP_TRY(h, h->gather_out.ensure((size_t)m * h->dim * sizeof(float)));
+        HIP_TRY(h, h->gather_lab.ensure((size_t)m * sizeof(int64_t)));
+        HIP_TRY(h, hipMemcpyAsync(h->gather_lab.p, labels + done, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(h, launch_gather_rows_at(h->X, h->gather_out.as<float>(), h->gather_lab.as<int64_t>(), m, h->dim, h->ld, s));
+        HIP_TRY(h, hipMemcpyAsync(out_rows + (size_t)done * h->dim, h->gather_out.p, (size_t)m * h->dim * sizeof(float),
+                                  hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+    }
+    return MLVDB_OK;
+}
+
 int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64_t nq, int32_t k,
                               int64_t* out_labels_device, float* out_dist_device, int32_t* out_counts_device,
                               double* out_dist64_device, void* stream) {
@@ -825,10 +852,9 @@ int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64
     return end_call(h, s);
 }
 
-int mlvdb_search_batch(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, int64_t* out_labels,
-                       float* out_dist, int32_t* out_counts) {
-    int rc = check_handle(h);
-    if (rc) return rc;
+namespace {
+int search_host(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, int64_t* out_labels, float* out_dist,
+                int32_t* out_counts, double* out_dist64) {
     if (nq < 0 || nq > (1 << 24)) return fail(h, MLVDB_ERR_INVALID_ARG, "nq out of range");
     if (k < 1) return fail(h, MLVDB_ERR_INVALID_ARG, "k must be >= 1");
     if (k > MLVDB_MAX_TOPK_PAGED) return fail(h, MLVDB_ERR_UNSUPPORTED, "k above MLVDB_MAX_TOPK_PAGED");
@@ -838,23 +864,26 @@ int mlvdb_search_batch(mlvdb_index* h, const float* queries, int64_t nq, int32_t
     HIP_TRY(h, h->io_lab.ensure((size_t)nq * k * sizeof(int64_t)));
     HIP_TRY(h, h->io_dist.ensure((size_t)nq * k * sizeof(float)));
     HIP_TRY(h, h->io_cnt.ensure((size_t)nq * sizeof(int32_t)));
+    if (out_dist64) HIP_TRY(h, h->io_d64.ensure((size_t)nq * k * sizeof(double)));
     HIP_TRY(h, hipMemcpyAsync(h->io_q.p, queries, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    rc = mlvdb_search_batch_device(h, h->io_q.as<float>(), nq, k, h->io_lab.as<int64_t>(), h->io_dist.as<float>(),
-                                   h->io_cnt.as<int32_t>(), nullptr, h->stream);
+    int rc = mlvdb_search_batch_device(h, h->io_q.as<float>(), nq, k, h->io_lab.as<int64_t>(), h->io_dist.as<float>(),
+                                       h->io_cnt.as<int32_t>(), out_dist64 ? h->io_d64.as<double>() : nullptr, h->stream);
     if (rc) return rc;
     HIP_TRY(h, hipMemcpyAsync(out_labels, h->io_lab.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(out_dist, h->io_dist.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(out_counts, h->io_cnt.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if (out_dist64)
+        HIP_TRY(h, hipMemcpyAsync(out_dist64, h->io_d64.p, (size_t)nq * k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     return MLVDB_OK;
 }
+}  // namespace
 
-int mlvdb_search_batch_filtered(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, const uint8_t* row_mask,
-                                int64_t* out_labels, float* out_dist, int32_t* out_counts) {
+int mlvdb_search_batch_ex(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, const uint8_t* row_mask,
+                          int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_dist64) {
     int rc = check_handle(h);
     if (rc) return rc;
-    if (!row_mask) return mlvdb_search_batch(h, queries, nq, k, out_labels, out_dist, out_counts);
-    if (h->total == 0) return mlvdb_search_batch(h, queries, nq, k, out_labels, out_dist, out_counts);
+    if (!row_mask || h->total == 0) return search_host(h, queries, nq, k, out_labels, out_dist, out_counts, out_dist64);
     HIP_TRY(h, h->row_mask.ensure((size_t)h->total));
     HIP_TRY(h, h->rn_masked.ensure((size_t)h->capacity * sizeof(float)));
     HIP_TRY(h, hipMemcpyAsync(h->row_mask.p, row_mask, (size_t)h->total, hipMemcpyHostToDevice, h->stream));
@@ -862,10 +891,20 @@ int mlvdb_search_batch_filtered(mlvdb_index* h, const float* queries, int64_t nq
     float* const all_rows = h->rn;  // every kernel of the call reads the masked norms instead
     h->rn = h->rn_masked.as<float>();
     h->mask_active = true;
-    rc = mlvdb_search_batch(h, queries, nq, k, out_labels, out_dist, out_counts);
+    rc = search_host(h, queries, nq, k, out_labels, out_dist, out_counts, out_dist64);
     h->rn = all_rows;
     h->mask_active = false;
     return rc;
+}
+
+int mlvdb_search_batch(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, int64_t* out_labels,
+                       float* out_dist, int32_t* out_counts) {
+    return mlvdb_search_batch_ex(h, queries, nq, k, nullptr, out_labels, out_dist, out_counts, nullptr);
+}
+
+int mlvdb_search_batch_filtered(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, const uint8_t* row_mask,
+                                int64_t* out_labels, float* out_dist, int32_t* out_counts) {
+    return mlvdb_search_batch_ex(h, queries, nq, k, row_mask, out_labels, out_dist, out_counts, nullptr);
 }
 
 int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float radius, int64_t capacity,

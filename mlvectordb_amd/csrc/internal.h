@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -11,6 +12,20 @@
 #include "wave_topk.h"
 
 namespace mlvdb {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is bound per device: one bit per device ordinal per call site, so a
+// second index on another GPU of the same process (Index(devices=[...])) configures its own copy of the kernel, and
+// host threads serving different handles do not race on a plain bool (setting the attribute twice is harmless).
+inline hipError_t ensure_dynamic_lds(std::atomic<uint64_t>& done, const void* kernel, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 
 // ---------------------------------------------------------------- layout kernels (kernels_layout.hip)
 // stage: row-major [n, dim] on the device -> panels; rows first_row..first_row+n-1
@@ -25,6 +40,9 @@ hipError_t launch_row_norms(const float* X, float* rn, int64_t first_row, int64_
 // panels -> row-major [n, dim]
 hipError_t launch_gather_rows(const float* X, float* out, int64_t first_row, int64_t n, int32_t dim, int32_t ld,
                               hipStream_t s);
+// labelled rows -> row-major [n, dim] (labels on the device, all within [0, total))
+hipError_t launch_gather_rows_at(const float* X, float* out, const int64_t* labels, int64_t n, int32_t dim, int32_t ld,
+                                 hipStream_t s);
 // rn[label] = NaN for each valid, live label; *changed += number of rows that changed state
 hipError_t launch_tombstone(float* rn, const int64_t* labels, int64_t n, int64_t total, unsigned long long* changed,
                             hipStream_t s);

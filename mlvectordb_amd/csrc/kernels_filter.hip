@@ -1459,12 +1459,9 @@ hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forc
                        (fuse ? (size_t)kCandCap * sizeof(CandEntry) + 8 * 4 : 0);
     auto kern = a.space == kSpaceL2 ? filter_refine_thr_kernel<kSpaceL2>
                 : a.space == kSpaceCosine ? filter_refine_thr_kernel<kSpaceCosine> : filter_refine_thr_kernel<kSpaceIp>;
-    static bool configured[3] = {false, false, false};
-    if (!configured[a.space]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        configured[a.space] = true;
-    }
+    static std::atomic<uint64_t> configured[3];
+    if (hipError_t e = ensure_dynamic_lds(configured[a.space], reinterpret_cast<const void*>(kern), 160 * 1024); e != hipSuccess)
+        return e;
     kern<<<a.nq, 256, lds, s>>>(a, k, forced_cnt, fuse);
     return hipGetLastError();
 }
@@ -1488,13 +1485,9 @@ static hipError_t launch_scan_one(const FilterArgs& a, int64_t row_begin, int64_
     const int max_grid = 256 * 2;  // workgroups resident per launch
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
     auto kern = filter_scan_kernel<SPACE, XB, DENSE>;
-    static bool configured = false;  // per instantiation
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};  // per instantiation
+    if (hipError_t e = ensure_dynamic_lds(configured, reinterpret_cast<const void*>(kern), (int)lds); e != hipSuccess)
+        return e;
     kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end);
     return hipGetLastError();
 }
@@ -1529,13 +1522,9 @@ static hipError_t launch_scan_narrow_n(const FilterArgs& a, int64_t row_begin, i
     const int grid = env_int("MLVDB_NARROW_BALANCE", 1) ? (int)((ntiles + rounds - 1) / rounds)
                                                         : (int)(ntiles < max_grid ? ntiles : max_grid);
     auto kern = filter_scan_narrow_kernel<SPACE, NQT, DENSE, R, NW, I8>;
-    static bool configured = false;  // per instantiation
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kNarrowLdsMax);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};  // per instantiation
+    if (hipError_t e = ensure_dynamic_lds(configured, reinterpret_cast<const void*>(kern), (int)kNarrowLdsMax); e != hipSuccess)
+        return e;
     kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end);
     return hipGetLastError();
 }
@@ -1578,13 +1567,9 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     const int max_grid = 256 * ((16 / MT) / NW);  // two waves per SIMD on every CU (<= kScanMaxGrid)  // two waves per SIMD on every CU
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
     auto kern = filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT, DMA, STAG>;
-    static bool configured = false;  // per instantiation
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};  // per instantiation
+    if (hipError_t e = ensure_dynamic_lds(configured, reinterpret_cast<const void*>(kern), (int)lds); e != hipSuccess)
+        return e;
     kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end);
     info->scatter_grid = grid;  // the caller runs launch_filter_scatter next (outside its timing window)
     info->nw = NW;
@@ -1724,13 +1709,9 @@ hipError_t launch_filter_scatter(const FilterArgs& a, const ScanInfo& info, hipS
 
 static hipError_t launch_update(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s) {
     const size_t lds = (size_t)kCandCap * (sizeof(CandEntry) + sizeof(uint32_t)) + 256 * 4 + 64;  // hist + s_scan[16]
-    static bool configured = false;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(filter_update_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};
+    if (hipError_t e = ensure_dynamic_lds(configured, reinterpret_cast<const void*>(filter_update_kernel), (int)lds); e != hipSuccess)
+        return e;
     filter_update_kernel<<<a.nq, kUpdThreads, lds, s>>>(a, k, forced_cnt);
     return hipGetLastError();
 }

@@ -61,6 +61,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     }
 }
 
+// out[i][:] = row labels[i]: one block per output row, coalesced on the output side
+__global__ __launch_bounds__(256) void gather_rows_at_kernel(const float* __restrict__ X, float* __restrict__ out,
+                                                             const int64_t* __restrict__ labels, int32_t dim, int32_t ld) {
+    const int64_t row = labels[blockIdx.x];
+    for (int32_t col = threadIdx.x; col < dim; col += blockDim.x)
+        out[(int64_t)blockIdx.x * dim + col] = X[layout_offset(row, col, ld)];
+}
+
 // One wave per panel; lane 16*g + r sums the squares of row r over its column slices.
 // Also maintains *rel_err_max = max over rows of |x - bf16(x)| / |x| (RNE, the conversion the filter scan and the
 // shadow use): the row half of the filter's rounding bound (kernels_filter.hip).  Non-negative floats order like
@@ -185,6 +193,13 @@ hipError_t launch_gather_rows(const float* X, float* out, int64_t first_row, int
                               hipStream_t s) {
     if (n <= 0) return hipSuccess;
     gather_rows_kernel<<<grid_for(n * dim, 256), 256, 0, s>>>(X, out, first_row, n, dim, ld);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_rows_at(const float* X, float* out, const int64_t* labels, int64_t n, int32_t dim, int32_t ld,
+                                 hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    gather_rows_at_kernel<<<(unsigned)n, 256, 0, s>>>(X, out, labels, dim, ld);
     return hipGetLastError();
 }
 

@@ -31,10 +31,13 @@ class ScanEngine(Protocol):
 
     def get_rows(self, first: int, n: int) -> np.ndarray: ...
 
+    def get_rows_at(self, labels: np.ndarray) -> np.ndarray: ...
+
     def search(self, queries: np.ndarray, k: int, mask: np.ndarray | None = None
                ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]: ...
 
-    def range(self, queries: np.ndarray, radius: float, capacity: int) -> List[Tuple[np.ndarray, np.ndarray]]: ...
+    def range(self, queries: np.ndarray, radius: float, capacity: int, truncate: bool = False
+              ) -> List[Tuple[np.ndarray, np.ndarray]]: ...
 
     def close(self) -> None: ...
 
@@ -130,8 +133,24 @@ class HipScanEngine:
         self._check(self._lib.mlvdb_index_get_rows(self._h, int(first), int(n), out.ctypes.data), "get_rows")
         return out
 
+    def get_rows_at(self, labels: np.ndarray) -> np.ndarray:
+        labels = np.ascontiguousarray(labels, dtype=np.int64).ravel()
+        out = np.empty((labels.size, self.dim), dtype=np.float32)
+        self._check(self._lib.mlvdb_index_get_rows_at(self._h, labels.ctypes.data, labels.size, out.ctypes.data),
+                    "get_rows_at")
+        return out
+
+    def search64(self, queries: np.ndarray, k: int, mask: np.ndarray | None = None):
+        """kNN; ``mask`` (optional, one byte per row, non-zero = allowed) restricts the search to those rows.
+        Returns (labels int64, dist float32, counts int32, dist64 float64): the last is what a merge over several
+        engines (row shards) has to rank on."""
+        return self._search(queries, k, mask, True)
+
     def search(self, queries: np.ndarray, k: int, mask: np.ndarray | None = None):
-        """kNN; ``mask`` (optional, one byte per row, non-zero = allowed) restricts the search to those rows."""
+        """kNN -> (labels int64 [nq, k], dist float32 [nq, k], counts int32 [nq]); ``mask`` as in ``search64``."""
+        return self._search(queries, k, mask, False)
+
+    def _search(self, queries: np.ndarray, k: int, mask, want64: bool):
         queries = np.ascontiguousarray(queries, dtype=np.float32)
         if queries.ndim != 2 or queries.shape[1] != self.dim:
             raise RuntimeError(f"Wrong dimensionality of the vectors: got {queries.shape}, index dim {self.dim}")
@@ -139,17 +158,16 @@ class HipScanEngine:
         labels = np.empty((nq, k), dtype=np.int64)
         dist = np.empty((nq, k), dtype=np.float32)
         counts = np.empty(nq, dtype=np.int32)
-        if mask is None:
-            self._check(self._lib.mlvdb_search_batch(self._h, queries.ctypes.data, nq, int(k), labels.ctypes.data,
-                                                     dist.ctypes.data, counts.ctypes.data), "search_batch")
-        else:
+        d64 = np.empty((nq, k), dtype=np.float64) if want64 else None
+        if mask is not None:
             mask = np.ascontiguousarray(mask, dtype=np.uint8)
             if mask.shape != (self.counts()[0],):
                 raise RuntimeError(f"row mask has shape {mask.shape}, the index holds {self.counts()[0]} rows")
-            self._check(self._lib.mlvdb_search_batch_filtered(self._h, queries.ctypes.data, nq, int(k), mask.ctypes.data,
-                                                              labels.ctypes.data, dist.ctypes.data, counts.ctypes.data),
-                        "search_batch_filtered")
-        return labels, dist, counts
+        self._check(self._lib.mlvdb_search_batch_ex(self._h, queries.ctypes.data, nq, int(k),
+                                                    None if mask is None else mask.ctypes.data, labels.ctypes.data,
+                                                    dist.ctypes.data, counts.ctypes.data,
+                                                    None if d64 is None else d64.ctypes.data), "search_batch")
+        return (labels, dist, counts, d64) if want64 else (labels, dist, counts)
 
     def search_device(self, q_ptr: int, nq: int, k: int, labels_ptr: int, dist_ptr: int, counts_ptr: int,
                       dist64_ptr: int = 0, stream: int = 0) -> None:
@@ -162,12 +180,17 @@ class HipScanEngine:
             self._h, C.c_void_p(q_ptr), int(nq), int(k), C.c_void_p(labels_ptr), C.c_void_p(dist_ptr),
             C.c_void_p(counts_ptr), C.c_void_p(dist64_ptr or None), C.c_void_p(stream or None)), "search_batch_device")
 
-    def range(self, queries: np.ndarray, radius: float, capacity: int):
+    def range(self, queries: np.ndarray, radius: float, capacity: int, truncate: bool = False):
+        """Per query (labels, fp32 distances) of the live rows within ``radius``, nearest first.
+
+        ``truncate=False``: ``capacity`` is an initial size; the call is repeated once with the exact largest count,
+        so every hit comes back (up to MLVDB_MAX_TOPK_PAGED = 16384 per query, the most one call can rank: beyond
+        that the nearest 16384 are returned).  ``truncate=True``: at most ``capacity`` hits per query, the nearest."""
         queries = np.ascontiguousarray(queries, dtype=np.float32)
         if queries.ndim != 2 or queries.shape[1] != self.dim:
             raise RuntimeError(f"Wrong dimensionality of the vectors: got {queries.shape}, index dim {self.dim}")
         nq = queries.shape[0]
-        capacity = max(1, int(capacity))
+        capacity = max(1, min(int(capacity), _native.MAX_TOPK_PAGED))
         while True:
             labels = np.empty((nq, capacity), dtype=np.int64)
             dist = np.empty((nq, capacity), dtype=np.float32)
@@ -175,10 +198,12 @@ class HipScanEngine:
             rc = self._check(self._lib.mlvdb_range_batch(self._h, queries.ctypes.data, nq, float(radius), capacity,
                                                          labels.ctypes.data, dist.ctypes.data, counts.ctypes.data),
                              "range_batch", allow=(_native.ERR_OVERFLOW,))
-            if rc == _native.OK:
+            if rc == _native.OK or truncate or capacity == _native.MAX_TOPK_PAGED:
                 break
-            capacity = int(counts.max())  # exact hit counts are reported even on overflow: retry once, sized
-        return [(labels[i, :counts[i]].copy(), dist[i, :counts[i]].copy()) for i in range(nq)]
+            # exact hit counts are reported even on overflow: retry once, sized
+            capacity = min(int(counts.max()), _native.MAX_TOPK_PAGED)
+        got = np.minimum(counts, capacity)
+        return [(labels[i, :got[i]].copy(), dist[i, :got[i]].copy()) for i in range(nq)]
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -25,12 +25,14 @@ from __future__ import annotations
 import json
 import os
 from dataclasses import dataclass
+from collections.abc import Sequence as SequenceABC
 from typing import Callable, Dict, Iterable, List, Mapping, Optional, Sequence
 from uuid import UUID
 
 import numpy as np
 
 from .engine import HipScanEngine, ScanEngine
+from .idtable import IdTable, mint_uuid4_bytes
 from .interfaces import VectorDTO, VectorProtocol
 
 _SPACE_ALIASES = {"l2": "l2", "cosine": "cosine", "ip": "ip", "euclidean": "l2"}
@@ -45,16 +47,90 @@ class SearchResult:
 class _Namespace:
     """Host-side bookkeeping for one namespace (reference index.py:19-29, per key)."""
 
-    __slots__ = ("engine", "dim", "uuid_to_label", "label_to_uuid", "total", "deleted", "rebuild_required")
+    __slots__ = ("engine", "dim", "ids", "total", "deleted", "rebuild_required")
 
     def __init__(self, engine: ScanEngine, dim: int) -> None:
         self.engine = engine
         self.dim = dim
-        self.uuid_to_label: Dict[UUID, int] = {}
-        self.label_to_uuid: Dict[int, UUID] = {}
+        self.ids = IdTable()  # label <-> UUID (arrays, not dicts: idtable.py)
         self.total = 0
         self.deleted = 0
         self.rebuild_required = False
+
+
+class BatchHits(SequenceABC):
+    """What ``search_many`` returns: a sequence of ``nq`` hit lists (entry ``i`` is exactly what ``search`` returns for
+    query ``i``) whose ``SearchResult`` objects are only built when an entry is read.  The arrays behind it are public,
+    so a batched caller (``QueryProcessor.find_similar_many``) never pays a Python object per hit it does not look at:
+
+    ``labels``  int64 [nq, k]   row labels, -1 = padding
+    ``scores``  float64 [nq, k] the post-processed score (``1 - d`` for metric "cosine", index.py:125-127)
+    ``counts``  int32 [nq]      valid prefix of each row
+    ``ids()``   object [nq, k]  ``uuid.UUID`` per hit (``None`` at padding)
+    """
+
+    __slots__ = ("labels", "scores", "counts", "_table", "_ids", "_rows")
+
+    def __init__(self, labels: np.ndarray, scores: np.ndarray, counts: np.ndarray, table: Optional[IdTable]) -> None:
+        self.labels, self.scores, self.counts = labels, scores, counts
+        self._table = table
+        self._ids: Optional[np.ndarray] = None
+        self._rows: Dict[int, List[SearchResult]] = {}
+
+    @classmethod
+    def empty(cls, nq: int) -> "BatchHits":
+        return cls(np.full((nq, 0), -1, dtype=np.int64), np.zeros((nq, 0)), np.zeros(nq, dtype=np.int32), None)
+
+    def valid(self) -> np.ndarray:
+        """bool [nq, k]: which slots hold a hit."""
+        return np.arange(self.labels.shape[1])[None, :] < self.counts[:, None]
+
+    def id_bytes(self) -> np.ndarray:
+        """uint8 [nq, k, 16]: the hits' UUID bytes (zeros at padding); no Python object per hit."""
+        if self._table is None:
+            return np.zeros(self.labels.shape + (16,), dtype=np.uint8)
+        v = self.valid()
+        out = self._table.raw[np.where(v, self.labels, 0)]
+        out[~v] = 0
+        return out
+
+    def handles(self) -> np.ndarray:
+        """int64 [nq, k]: the caller's per-row payload given to ``add_arrays`` (-1 = none / padding)."""
+        if self._table is None:
+            return np.full(self.labels.shape, -1, dtype=np.int64)
+        v = self.valid()
+        return np.where(v, self._table.handles[np.where(v, self.labels, 0)], -1)
+
+    def ids(self) -> np.ndarray:
+        if self._ids is None:
+            valid = np.arange(self.labels.shape[1])[None, :] < self.counts[:, None]
+            lab = np.where(valid, self.labels, -1)
+            self._ids = (self._table.uuids_at(lab) if self._table is not None
+                         else np.full(self.labels.shape, None, dtype=object))
+        return self._ids
+
+    def __len__(self) -> int:
+        return int(self.labels.shape[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        row = self._rows.get(i)
+        if row is None:
+            n = int(self.counts[i])
+            row = [SearchResult(vector_id=u, score=s)
+                   for u, s in zip(self.ids()[i, :n].tolist(), self.scores[i, :n].tolist()) if u is not None]
+            self._rows[i] = row
+        return row
+
+    def __eq__(self, other) -> bool:
+        if isinstance(other, (list, BatchHits)):
+            return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+        return NotImplemented
 
 
 EngineFactory = Callable[[int, str], ScanEngine]
@@ -62,7 +138,8 @@ EngineFactory = Callable[[int, str], ScanEngine]
 
 class Index:
     def __init__(self, space: str = "l2", ef_construction: int = 200, M: int = 16,
-                 rebuild_threshold: float = 0.2, *, device: int = 0, strategy: str = "auto",
+                 rebuild_threshold: float = 0.2, *, device: int = 0, devices: Optional[Sequence[int]] = None,
+                 strategy: str = "auto", capacity_hint: int = 0,
                  engine_factory: Optional[EngineFactory] = None) -> None:
         # ef_construction / M are HNSW build knobs (index.py:18,37); an exhaustive scan has none.
         self._space = space
@@ -70,7 +147,11 @@ class Index:
         self._M = M
         self._rebuild_threshold = float(rebuild_threshold)
         self._device = device
+        # devices=[0, 1, ...]: every namespace is row-sharded over these GPUs inside this one process (SURVEY 8e,
+        # multi_device.py); a device may be listed more than once (logical shards on one GPU)
+        self._devices = None if devices is None else [int(x) for x in devices]
         self._strategy = strategy
+        self._capacity_hint = int(capacity_hint)  # rows to reserve per namespace (and shard) up front: no regrowth copies
         self._engine_factory = engine_factory
         self._ns: Dict[str, _Namespace] = {}
 
@@ -79,9 +160,18 @@ class Index:
         native_space = _SPACE_ALIASES.get(space)
         if native_space is None:
             raise RuntimeError(f"Space name must be one of l2, ip, cosine or euclidean (got {space!r})")
+        if self._devices is not None and len(self._devices) > 1:
+            from .multi_device import MultiDeviceEngine
+
+            factory = self._engine_factory
+            per_shard = -(-self._capacity_hint // len(self._devices))
+            return MultiDeviceEngine(dim, native_space, self._devices, strategy=self._strategy, capacity_hint=per_shard,
+                                     shard_factory=None if factory is None else (lambda dev: factory(dim, native_space)))
         if self._engine_factory is not None:
             return self._engine_factory(dim, native_space)
-        return HipScanEngine(dim, native_space, device=self._device, strategy=self._strategy)
+        device = self._devices[0] if self._devices else self._device
+        return HipScanEngine(dim, native_space, device=device, strategy=self._strategy,
+                             capacity_hint=self._capacity_hint)
 
     def _get_or_create(self, namespace: str, dim: int, space: str) -> _Namespace:
         ns = self._ns.get(namespace)
@@ -92,22 +182,33 @@ class Index:
 
     @staticmethod
     def _stack_rows(vectors: Sequence[VectorProtocol], dim: int) -> np.ndarray:
-        rows = np.empty((len(vectors), dim), dtype=np.float32)
+        try:  # one C-level pass when every row has the right shape (the only case that succeeds)
+            rows = np.asarray([v.values for v in vectors], dtype=np.float32)
+            if rows.shape == (len(vectors), dim):
+                return rows
+        except ValueError:
+            pass
         for i, v in enumerate(vectors):
             vals = np.asarray(v.values, dtype=np.float32)
             if vals.shape != (dim,):
                 raise RuntimeError(f"Wrong dimensionality of the vectors: row {i} has shape {vals.shape}, index dim {dim}")
-            rows[i] = vals
-        return rows
+        raise RuntimeError(f"Wrong dimensionality of the vectors: expected [{len(vectors)}, {dim}]")
+
+    @staticmethod
+    def _check_finite(rows: np.ndarray) -> None:
+        # A non-finite row would get a NaN norm, which the scan kernels read as "tombstoned": the row would vanish from
+        # every search without being counted as deleted.  hnswlib accepts such rows and returns garbage; this index
+        # refuses them.
+        if not np.isfinite(rows).all():
+            bad = int(np.flatnonzero(~np.isfinite(rows).all(axis=1))[0])
+            raise RuntimeError(f"row {bad} of the batch holds a non-finite value (NaN / inf): not indexable")
 
     def _append(self, ns: _Namespace, vectors: Sequence[VectorProtocol]) -> None:
         rows = self._stack_rows(vectors, ns.dim)
+        self._check_finite(rows)
         first = ns.engine.append(rows)
-        if first != ns.total:
+        if first != ns.total or ns.ids.append_uuids([v.id for v in vectors]) != first:
             raise RuntimeError(f"engine label base {first} != host row count {ns.total}")
-        for i, v in enumerate(vectors):
-            ns.uuid_to_label[v.id] = first + i
-            ns.label_to_uuid[first + i] = v.id
         ns.total += len(vectors)
 
     # ------------------------------------------------------------------ IndexProtocol
@@ -120,20 +221,44 @@ class Index:
         ns = self._get_or_create(namespace, dim, self._space)
         self._append(ns, vectors)
 
+    def add_arrays(self, rows: np.ndarray, namespace: str, ids: Optional[np.ndarray] = None,
+                   handles: Optional[np.ndarray] = None) -> np.ndarray:
+        """Additive bulk form of ``add``: ``rows`` is a float ``[n, dim]`` matrix, ``ids`` an optional ``[n, 16] uint8``
+        table of UUID bytes (minted as uuid4 when omitted), ``handles`` an optional int64 payload per row that comes
+        back with every hit (``BatchHits.handles``: a storage row number).  No Python object per row is created;
+        returns the id table.  Same label rule as ``add`` (index.py:56-63)."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2:
+            raise RuntimeError(f"Wrong dimensionality of the vectors: expected a matrix, got shape {rows.shape}")
+        n = rows.shape[0]
+        ids = mint_uuid4_bytes(n) if ids is None else np.ascontiguousarray(ids, dtype=np.uint8).reshape(-1, 16)
+        if ids.shape[0] != n:
+            raise RuntimeError(f"{n} rows but {ids.shape[0]} ids")
+        if n == 0:
+            return ids
+        ns = self._get_or_create(namespace, rows.shape[1], self._space)
+        if rows.shape[1] != ns.dim:
+            raise RuntimeError(f"Wrong dimensionality of the vectors: got {rows.shape}, index dim {ns.dim}")
+        self._check_finite(rows)
+        first = ns.engine.append(rows)
+        if handles is not None and np.asarray(handles).shape != (n,):
+            raise RuntimeError(f"{n} rows but handles of shape {np.asarray(handles).shape}")
+        if first != ns.total or ns.ids.append_raw(ids, handles) != first:
+            raise RuntimeError(f"engine label base {first} != host row count {ns.total}")
+        ns.total += n
+        return ids
+
     def remove(self, ids: Sequence[UUID], namespace: str) -> None:
         """Tombstone rows; raise the rebuild flag at deleted/total >= threshold (index.py:69-89)."""
         ns = self._ns.get(namespace)
         if ns is None:
             return
-        labels = []
-        for uid in ids:
-            label = ns.uuid_to_label.pop(uid, None)
-            if label is not None:
-                ns.label_to_uuid.pop(label, None)
-                labels.append(label)
-        if labels:
-            ns.engine.tombstone(np.asarray(labels, dtype=np.int64))
-        ns.deleted += len(labels)
+        labels = ns.ids.lookup(ids)
+        labels = np.unique(labels[labels >= 0])
+        if labels.size:
+            ns.engine.tombstone(labels)
+            ns.ids.kill(labels)
+        ns.deleted += int(labels.size)
         if ns.deleted / max(1, ns.total) >= self._rebuild_threshold:
             ns.rebuild_required = True
 
@@ -170,65 +295,57 @@ class Index:
         if ns is None:
             return False
         old = ns.engine.compact()  # old[new label] = old label
-        new_l2u: Dict[int, UUID] = {}
-        for new, prev in enumerate(old.tolist()):
-            uid = ns.label_to_uuid.get(prev)
-            if uid is None:
-                raise RuntimeError(f"compaction kept label {prev}, which the host maps do not know")
-            new_l2u[new] = uid
-        ns.label_to_uuid = new_l2u
-        ns.uuid_to_label = {uid: label for label, uid in new_l2u.items()}
-        ns.total = len(new_l2u)
+        ns.ids = ns.ids.take(old)
+        ns.total = ns.ids.n
         ns.deleted = 0
         ns.rebuild_required = False
         return True
 
     # ------------------------------------------------------------------ additive: batches and ranges
+    @staticmethod
+    def _scores(dist: np.ndarray, metric: str) -> np.ndarray:
+        """``Index.search``'s score rule (index.py:125-127) on a whole array: the float32 distance as a Python float
+        (= float64), ``1 - d`` for metric "cosine"; additive: the square root for "euclidean"."""
+        score = dist.astype(np.float64)
+        if metric == "cosine":
+            score = 1 - score
+        elif metric == "euclidean":
+            score = np.sqrt(np.maximum(score, 0.0))
+        return score
+
     def search_many(self, queries, top_k: int, namespace: str, metric: str,
-                    allowed_ids: Optional[Iterable[UUID]] = None) -> List[List[SearchResult]]:
+                    allowed_ids: Optional[Iterable[UUID]] = None) -> BatchHits:
         """kNN for a batch of queries in one corpus scan.
 
         ``queries`` is an ``[nq, dim]`` array or a sequence of ``VectorDTO``.  Each entry of
-        the result is what ``search`` would return for that query.  ``allowed_ids`` (additive: the
-        row mask of a metadata-filtered search, README.md:121,130 intent) restricts the search to
-        those vectors; the answer is the exact top-k among them.
+        the result is what ``search`` would return for that query (``BatchHits``: a lazy sequence over the result
+        arrays).  ``allowed_ids`` (additive: the row mask of a metadata-filtered search, README.md:121,130 intent)
+        restricts the search to those vectors; the answer is the exact top-k among them.
         """
         q = self._coerce_queries(queries)
         nq = q.shape[0]
         ns = self._ns.get(namespace)
         if ns is None:
-            return [[] for _ in range(nq)]
+            return BatchHits.empty(nq)
         active = ns.total - ns.deleted
         if active <= 0 or top_k <= 0 or nq == 0:
-            return [[] for _ in range(nq)]
+            return BatchHits.empty(nq)
         if q.shape[1] != ns.dim:
-            return [[] for _ in range(nq)]  # reference: RuntimeError swallowed at index.py:110-119
+            return BatchHits.empty(nq)  # reference: RuntimeError swallowed at index.py:110-119
         mask = None
         if allowed_ids is not None:
+            picked = ns.ids.lookup(allowed_ids)
+            picked = picked[picked >= 0]
+            if not picked.size:
+                return BatchHits.empty(nq)
             mask = np.zeros(ns.total, dtype=np.uint8)
-            picked = [ns.uuid_to_label[u] for u in allowed_ids if u in ns.uuid_to_label]
-            if not picked:
-                return [[] for _ in range(nq)]
-            mask[np.asarray(picked, dtype=np.int64)] = 1
+            mask[picked] = 1
             active = int(mask.sum())
-        k = min(int(top_k), active)
+        k = min(int(top_k), active, self._MAX_TOP_K)  # the reference clamps to the live count (index.py:107)
         labels, dist, counts = self._search_engine(ns, q, k, mask)
-        sqrt_score = metric == "euclidean"
-        out: List[List[SearchResult]] = []
-        for i in range(nq):
-            hits: List[SearchResult] = []
-            for label, d in zip(labels[i, :counts[i]].tolist(), dist[i, :counts[i]].tolist()):
-                uid = ns.label_to_uuid.get(label)
-                if uid is None:
-                    continue
-                score = float(d)
-                if metric == "cosine":
-                    score = 1 - score
-                elif sqrt_score:
-                    score = float(np.sqrt(max(score, 0.0)))
-                hits.append(SearchResult(vector_id=uid, score=score))
-            out.append(hits)
-        return out
+        return BatchHits(labels, self._scores(dist, metric), counts, ns.ids)
+
+    _MAX_TOP_K = 16384  # MLVDB_MAX_TOPK_PAGED: the most neighbours one call returns per query
 
     def range_search(self, query: VectorDTO, radius: float, namespace: str, metric: str,
                      max_results: int = 1024) -> List[SearchResult]:
@@ -239,7 +356,8 @@ class Index:
 
     def range_search_many(self, queries, radius: float, namespace: str, metric: str,
                           max_results: int = 1024) -> List[List[SearchResult]]:
-        """Every live row within ``radius`` of each query, nearest first (ties by insertion order).
+        """The live rows within ``radius`` of each query, nearest first (ties by insertion order), at most
+        ``max_results`` per query (the nearest ones; ``None`` = all, up to the engine's 16384 per query).
 
         ``radius`` is a distance in the namespace's space (squared for l2; plain for
         ``metric="euclidean"``); scores are post-processed exactly like ``search``.
@@ -251,21 +369,13 @@ class Index:
         if ns is None or ns.total - ns.deleted <= 0 or nq == 0 or q.shape[1] != ns.dim:
             return [[] for _ in range(nq)]
         native_radius = float(radius) ** 2 if metric == "euclidean" else float(radius)
-        per_query = ns.engine.range(q, native_radius, max_results)
+        cap = self._MAX_TOP_K if max_results is None else max(1, int(max_results))
+        per_query = ns.engine.range(q, native_radius, cap, truncate=True)
         out: List[List[SearchResult]] = []
         for labels, dist in per_query:
-            hits = []
-            for label, d in zip(labels.tolist(), dist.tolist()):
-                uid = ns.label_to_uuid.get(label)
-                if uid is None:
-                    continue
-                score = float(d)
-                if metric == "cosine":
-                    score = 1 - score
-                elif metric == "euclidean":
-                    score = float(np.sqrt(max(score, 0.0)))
-                hits.append(SearchResult(vector_id=uid, score=score))
-            out.append(hits)
+            uids = ns.ids.uuids_at(labels).tolist()
+            scores = self._scores(dist, metric).tolist()
+            out.append([SearchResult(vector_id=u, score=s) for u, s in zip(uids, scores) if u is not None])
         return out
 
     # ------------------------------------------------------------------ helpers
@@ -288,6 +398,12 @@ class Index:
         ns = self._ns.get(namespace)
         return (0, 0) if ns is None else (ns.total, ns.deleted)
 
+    def fetch_values(self, namespace: str, labels: np.ndarray) -> np.ndarray:
+        """Additive: the stored float32 rows of ``labels`` read back from the index's own copy in HBM (bit-exact), so a
+        caller that keeps no second copy of the corpus on the host can still enrich hits with ``values``."""
+        ns = self._ns[namespace]
+        return ns.engine.get_rows_at(np.asarray(labels, dtype=np.int64))
+
     # ------------------------------------------------------------------ additive: persistence
     # Directory layout ("mlvdb-index-v1"): index.json + per namespace i
     #   ns<i>.rows.f32     raw row-major float32 [total, dim], every label incl. tombstoned ones (labels stay stable)
@@ -307,13 +423,11 @@ class Index:
             with open(os.path.join(path, f"ns{i}.rows.f32"), "wb") as f:
                 for first in range(0, ns.total, chunk):
                     f.write(ns.engine.get_rows(first, min(chunk, ns.total - first)).tobytes())
-            ids = np.zeros((ns.total, 16), dtype=np.uint8)
-            for label, uid in ns.label_to_uuid.items():
-                ids[label] = np.frombuffer(uid.bytes, dtype=np.uint8)
+            dead = ns.ids.dead_labels()
+            ids = ns.ids.raw[:ns.total].copy()
+            ids[dead] = 0
             ids.tofile(os.path.join(path, f"ns{i}.ids.u8"))
-            live = np.zeros(ns.total, dtype=bool)
-            live[list(ns.label_to_uuid.keys())] = True
-            np.nonzero(~live)[0].astype(np.int64).tofile(os.path.join(path, f"ns{i}.deleted.i64"))
+            dead.tofile(os.path.join(path, f"ns{i}.deleted.i64"))
             meta["namespaces"].append({"name": name, "dim": ns.dim, "space": ns.engine.space, "total": ns.total,
                                        "deleted": ns.deleted, "rebuild_required": ns.rebuild_required})
         tmp = os.path.join(path, "index.json.tmp")
@@ -353,13 +467,8 @@ class Index:
             deleted = np.fromfile(os.path.join(path, f"ns{i}.deleted.i64"), dtype=np.int64)
             if deleted.size:
                 ns.engine.tombstone(deleted)
-            ids = np.fromfile(os.path.join(path, f"ns{i}.ids.u8"), dtype=np.uint8).reshape(total, 16)
-            dead = set(deleted.tolist())
-            for label in range(total):
-                if label not in dead:
-                    uid = UUID(bytes=ids[label].tobytes())
-                    ns.label_to_uuid[label] = uid
-                    ns.uuid_to_label[uid] = label
+            ns.ids.append_raw(np.fromfile(os.path.join(path, f"ns{i}.ids.u8"), dtype=np.uint8).reshape(total, 16))
+            ns.ids.kill(deleted)
             ns.total = total
             ns.deleted = int(m["deleted"])
             ns.rebuild_required = bool(m["rebuild_required"])

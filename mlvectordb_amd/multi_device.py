@@ -1,0 +1,246 @@
+"""``MultiDeviceEngine``: one namespace row-sharded over several GPUs inside ONE process.
+
+The north star shards the corpus row-wise over the GPUs of a node with a per-shard top-k merged on the host; the
+reference constructs a single-process ``QueryProcessor(storage, index)`` (query_processor.py:12-14, server.py:54), so
+the sharded path has to live *behind* ``Index`` for a drop-in to reach it: ``Index(devices=[0, 1, ..., 7])`` hands
+every namespace to this engine instead of a single ``HipScanEngine``.  (The process-per-GPU form of the same
+algorithm, for ``torch.distributed`` launches, is sharded.py / bench.py.)
+
+* one ``mlvdb_index`` per entry of ``devices`` (a device may repeat: logical shards on one GPU, which is how the
+  path is tested on a one-GPU box);
+* ``append`` splits each batch into contiguous pieces that level the shards' row counts; global labels stay the
+  dense insertion-order labels the reference assigns (index.py:56-63), a pair of arrays maps them to
+  (shard, local label) and back.  Within a shard local order == global order, so a shard's tie-break by local label
+  is the global tie-break;
+* ``search`` runs every shard's scan concurrently -- one host thread per shard; the ctypes calls hold no GIL and each
+  blocks only on its own device's stream -- and merges the per-shard ``[nq, k]`` candidates by (fp64 distance, global
+  label) (``sharded.merge_topk``), the same order a single index ranks by, so ids equal a one-index search;
+* no collective: the only exchange is the ``G x nq x k x 20 B`` of candidates that come back over PCIe anyway.
+"""
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .engine import HipScanEngine, ScanEngine
+from .sharded import merge_topk
+
+
+class MultiDeviceEngine:
+    def __init__(self, dim: int, space: str, devices: Sequence[int], strategy: str = "auto", capacity_hint: int = 0,
+                 shard_factory: Optional[Callable[[int], ScanEngine]] = None) -> None:
+        if not devices:
+            raise RuntimeError("MultiDeviceEngine needs at least one device")
+        self.dim, self.space = int(dim), space
+        self.devices = [int(d) for d in devices]
+        make = shard_factory or (lambda dev: HipScanEngine(dim, space, device=dev, strategy=strategy,
+                                                           capacity_hint=capacity_hint))
+        self.shards: List[ScanEngine] = [make(dev) for dev in self.devices]
+        self._pool = ThreadPoolExecutor(max_workers=len(self.shards), thread_name_prefix="mlvdb-shard")
+        g = len(self.shards)
+        self._l2g: List[np.ndarray] = [np.zeros(0, dtype=np.int64) for _ in range(g)]  # local -> global, ascending
+        self._g2s = np.zeros(0, dtype=np.int16)   # global -> shard
+        self._g2l = np.zeros(0, dtype=np.int64)   # global -> local
+        self._total = 0
+        self._deleted = 0
+
+    # ------------------------------------------------------------------ helpers
+    def _each(self, fn, args_per_shard):
+        """Run ``fn(shard, *args)`` for every shard whose args are not None, concurrently; results by shard index."""
+        futures = [None if a is None else self._pool.submit(fn, s, *a) for s, a in zip(self.shards, args_per_shard)]
+        return [None if f is None else f.result() for f in futures]
+
+    def _split(self, n: int) -> List[int]:
+        """Rows of an ``n``-row batch per shard: contiguous pieces that level the shards' fill."""
+        loads = np.array([m.size for m in self._l2g], dtype=np.int64)
+        g = loads.size
+        target = -(-(int(loads.sum()) + n) // g)
+        want = np.maximum(target - loads, 0)
+        take = np.zeros(g, dtype=np.int64)
+        left = n
+        for s in np.argsort(loads, kind="stable").tolist():  # emptiest first
+            take[s] = min(left, int(want[s]))
+            left -= int(take[s])
+        take[int(np.argmin(loads))] += left
+        return take.tolist()
+
+    # ------------------------------------------------------------------ ScanEngine
+    def append(self, rows: np.ndarray) -> int:
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        if rows.ndim != 2 or rows.shape[1] != self.dim:
+            raise RuntimeError(f"Wrong dimensionality of the vectors: got {rows.shape}, index dim {self.dim}")
+        n, first = rows.shape[0], self._total
+        if n == 0:
+            return first
+        take = self._split(n)
+        bounds = np.concatenate([[0], np.cumsum(take)])
+        pieces = [None if take[s] == 0 else (rows[bounds[s]:bounds[s + 1]],) for s in range(len(self.shards))]
+        firsts = self._each(lambda sh, r: sh.append(r), pieces)
+        g2s = np.empty(n, dtype=np.int16)
+        g2l = np.empty(n, dtype=np.int64)
+        for s, f in enumerate(firsts):
+            if f is None:
+                continue
+            if f != self._l2g[s].size:
+                raise RuntimeError(f"shard {s}: label base {f} != rows held {self._l2g[s].size}")
+            lo, hi = int(bounds[s]), int(bounds[s + 1])
+            g2s[lo:hi] = s
+            g2l[lo:hi] = np.arange(f, f + hi - lo)
+            self._l2g[s] = np.concatenate([self._l2g[s], np.arange(first + lo, first + hi, dtype=np.int64)])
+        self._g2s = np.concatenate([self._g2s, g2s])
+        self._g2l = np.concatenate([self._g2l, g2l])
+        self._total += n
+        return first
+
+    def _by_shard(self, labels: np.ndarray) -> List[Optional[Tuple[np.ndarray, np.ndarray]]]:
+        """Per shard (positions in ``labels``, local labels) or None."""
+        which = self._g2s[labels]
+        out = []
+        for s in range(len(self.shards)):
+            pos = np.flatnonzero(which == s)
+            out.append(None if not pos.size else (pos, self._g2l[labels[pos]]))
+        return out
+
+    def tombstone(self, labels: np.ndarray) -> int:
+        labels = np.asarray(labels, dtype=np.int64).ravel()
+        labels = labels[(labels >= 0) & (labels < self._total)]
+        if not labels.size:
+            return 0
+        parts = self._by_shard(labels)
+        changed = self._each(lambda sh, loc: sh.tombstone(loc), [None if p is None else (p[1],) for p in parts])
+        n = int(sum(c for c in changed if c))
+        self._deleted += n
+        return n
+
+    def counts(self) -> Tuple[int, int]:
+        return self._total, self._deleted
+
+    def compact(self) -> np.ndarray:
+        olds = self._each(lambda sh: sh.compact(), [() for _ in self.shards])
+        kept_global = [self._l2g[s][np.asarray(o, dtype=np.int64)] for s, o in enumerate(olds)]
+        old_of_new = np.sort(np.concatenate(kept_global)) if kept_global else np.zeros(0, dtype=np.int64)
+        n = old_of_new.size
+        self._g2s = np.empty(n, dtype=np.int16)
+        self._g2l = np.empty(n, dtype=np.int64)
+        for s, kg in enumerate(kept_global):
+            new_global = np.searchsorted(old_of_new, kg)
+            self._l2g[s] = new_global.astype(np.int64)
+            self._g2s[new_global] = s
+            self._g2l[new_global] = np.arange(kg.size)
+        self._total, self._deleted = n, 0
+        return old_of_new
+
+    def get_rows_at(self, labels: np.ndarray) -> np.ndarray:
+        labels = np.asarray(labels, dtype=np.int64).ravel()
+        if labels.size and (labels.min() < 0 or labels.max() >= self._total):
+            raise RuntimeError("row range out of bounds")
+        out = np.empty((labels.size, self.dim), dtype=np.float32)
+        parts = self._by_shard(labels) if labels.size else [None] * len(self.shards)
+        got = self._each(lambda sh, loc: sh.get_rows_at(loc), [None if p is None else (p[1],) for p in parts])
+        for p, rows in zip(parts, got):
+            if p is not None:
+                out[p[0]] = rows
+        return out
+
+    def get_rows(self, first: int, n: int) -> np.ndarray:
+        if first < 0 or n < 0 or first + n > self._total:
+            raise RuntimeError("row range out of bounds")
+        return self.get_rows_at(np.arange(first, first + n, dtype=np.int64))
+
+    def search64(self, queries: np.ndarray, k: int, mask: Optional[np.ndarray] = None):
+        """(labels int64 [nq, k] global, dist float32, counts int32, dist64 float64): the merged answer."""
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        if queries.ndim != 2 or queries.shape[1] != self.dim:
+            raise RuntimeError(f"Wrong dimensionality of the vectors: got {queries.shape}, index dim {self.dim}")
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+            if mask.shape != (self._total,):
+                raise RuntimeError(f"row mask has shape {mask.shape}, the index holds {self._total} rows")
+        args = []
+        for s in range(len(self.shards)):
+            if not self._l2g[s].size:
+                args.append(None)
+            else:
+                args.append((queries, k, None if mask is None else np.ascontiguousarray(mask[self._l2g[s]])))
+        res = self._each(lambda sh, q, kk, m: sh.search64(q, kk, m), args)
+        labs, d64s = [], []
+        for s, r in enumerate(res):
+            if r is None:
+                continue
+            lab = r[0]
+            labs.append(np.where(lab >= 0, self._l2g[s][np.maximum(lab, 0)], -1))
+            d64s.append(r[3])
+        nq = queries.shape[0]
+        if not labs:
+            return (np.full((nq, k), -1, dtype=np.int64), np.full((nq, k), np.inf, dtype=np.float32),
+                    np.zeros(nq, dtype=np.int32), np.full((nq, k), np.inf))
+        return merge_topk(labs, d64s, k, return_dist64=True)
+
+    def search(self, queries: np.ndarray, k: int, mask: Optional[np.ndarray] = None):
+        lab, dist, cnt, _ = self.search64(queries, k, mask)
+        return lab, dist, cnt
+
+    def range(self, queries: np.ndarray, radius: float, capacity: int, truncate: bool = False):
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        res = self._each(lambda sh, q: sh.range(q, radius, capacity, truncate),
+                         [None if not self._l2g[s].size else (queries,) for s in range(len(self.shards))])
+        out = []
+        for i in range(queries.shape[0]):
+            labs = [self._l2g[s][r[i][0]] for s, r in enumerate(res) if r is not None]
+            dists = [r[i][1] for r in res if r is not None]
+            src = [np.full(r[i][0].size, s, dtype=np.int16) for s, r in enumerate(res) if r is not None]
+            if not labs:
+                out.append((np.zeros(0, np.int64), np.zeros(0, np.float32)))
+                continue
+            lab, d, sh = np.concatenate(labs), np.concatenate(dists), np.concatenate(src)
+            order = np.lexsort((lab, d))
+            lab, d, sh = lab[order], d[order], sh[order]
+            lab = self._resolve_fp32_ties(queries[i], lab, d, sh)
+            if truncate:
+                lab, d = lab[:capacity], d[:capacity]
+            out.append((lab, d))
+        return out
+
+    def _resolve_fp32_ties(self, q: np.ndarray, lab: np.ndarray, d: np.ndarray, sh: np.ndarray) -> np.ndarray:
+        """A single index ranks hits by the fp64 distance and returns its fp32 rounding; shards return only the
+        rounding.  Hits of different shards whose fp32 distances are equal are re-ranked here by the fp64 distance
+        recomputed on the host from the stored rows (rare: a handful of rows per query at most)."""
+        if lab.size < 2:
+            return lab
+        same = np.flatnonzero(d[1:] == d[:-1])
+        if not same.size:
+            return lab
+        lab = lab.copy()
+        edges = np.flatnonzero(d[1:] != d[:-1]) + 1
+        for a, b in zip(np.concatenate([[0], edges]).tolist(), np.concatenate([edges, [lab.size]]).tolist()):
+            if b - a < 2 or (sh[a:b] == sh[a]).all():
+                continue
+            rows = self.get_rows_at(lab[a:b]).astype(np.float64)
+            q64 = q.astype(np.float64)
+            if self.space == "l2":
+                d64 = ((rows - q64) ** 2).sum(axis=1)
+            else:
+                dots = rows @ q64
+                if self.space == "cosine":
+                    dots = dots / ((np.sqrt((rows * rows).sum(axis=1)) + 1e-30) * (np.sqrt(q64 @ q64) + 1e-30))
+                d64 = 1.0 - dots
+            lab[a:b] = lab[a:b][np.lexsort((lab[a:b], d64))]
+        return lab
+
+    # ------------------------------------------------------------------ pass-throughs used by tests / benches
+    def set_strategy(self, strategy: str) -> None:
+        for sh in self.shards:
+            sh.set_strategy(strategy)
+
+    def last_stats(self) -> List[dict]:
+        return [sh.last_stats() for sh in self.shards]
+
+    def close(self) -> None:
+        for sh in self.shards:
+            sh.close()
+        self._pool.shutdown(wait=False)
+        self._l2g = [np.zeros(0, dtype=np.int64) for _ in self.shards]
+        self._g2s, self._g2l = np.zeros(0, dtype=np.int16), np.zeros(0, dtype=np.int64)
+        self._total = self._deleted = 0

@@ -56,6 +56,11 @@ class QueryProcessor:
 
     def find_similar(self, query: VectorDTO, top_k: int, namespace: str = "default",
                      metric: str = "cosine") -> List[dict]:
+        if hasattr(self._storage, "read_rows_raw") and hasattr(self._index, "search_many"):
+            values = np.asarray(query.values, dtype=np.float32)  # array-backed storage: the one-row case of the batch path
+            if values.ndim != 1:
+                return []
+            return self._enrich_many(self._index.search_many(values[None, :], top_k, namespace, metric), namespace)[0]
         hits = self._index.search(query, top_k=top_k, namespace=namespace, metric=metric)
         return self._enrich(hits, namespace)
 
@@ -67,13 +72,65 @@ class QueryProcessor:
         vector's metadata dict.  It is evaluated once over the namespace's stored vectors and handed to the
         index as a row mask, so the answer is the exact top-k among the matching vectors (not a post-filter of
         an unrestricted top-k)."""
+        return self._enrich_many(self._search_many(queries, top_k, namespace, metric, where), namespace)
+
+    def _search_many(self, queries, top_k: int, namespace: str, metric: str, where):
         if where is None:
-            per_query = self._index.search_many(queries, top_k=top_k, namespace=namespace, metric=metric)
+            return self._index.search_many(queries, top_k=top_k, namespace=namespace, metric=metric)
+        allowed = [v.id for v in self._storage.namespace_map.get(namespace, []) if where(v.metadata)]
+        return self._index.search_many(queries, top_k=top_k, namespace=namespace, metric=metric, allowed_ids=allowed)
+
+    def _enrich_many(self, per_query, namespace: str) -> List[List[dict]]:
+        """``_enrich`` for a whole batch.  With an array-backed storage and this package's ``Index`` the 2,560 hits of a
+        256-query wave are resolved by array operations -- id bytes -> storage rows by one sorted lookup, values by one
+        gather (from the storage's matrix, or from the index's rows in HBM) -- and Python only builds the result
+        dicts; any other storage / index goes hit list by hit list through ``_enrich``."""
+        fast = getattr(self._storage, "read_rows_raw", None)
+        if fast is None or not hasattr(per_query, "id_bytes"):
+            return [self._enrich(hits, namespace) for hits in per_query]
+        valid = per_query.valid()
+        counts = valid.sum(axis=1).tolist()
+        if not valid.any():
+            return [[] for _ in counts]
+        handles = per_query.handles()[valid] if hasattr(self._storage, "read_rows_at") else None
+        if handles is not None and (handles >= 0).all():
+            found, values, metas = self._storage.read_rows_at(handles, namespace)  # storage row numbers ride with the hits
         else:
-            allowed = [v.id for v in self._storage.namespace_map.get(namespace, []) if where(v.metadata)]
-            per_query = self._index.search_many(queries, top_k=top_k, namespace=namespace, metric=metric,
-                                                allowed_ids=allowed)
-        return [self._enrich(hits, namespace) for hits in per_query]
+            found, values, metas = fast(per_query.id_bytes()[valid], namespace)
+        if values is None:
+            values = self._index.fetch_values(namespace, per_query.labels[valid])
+        ids = per_query.ids()[valid].tolist()
+        scores = per_query.scores[valid].tolist()
+        rows = list(values)  # one ndarray view per hit
+        out, pos = [], 0
+        if found.all():
+            for n in counts:
+                out.append([{"id": ids[j], "values": rows[j], "metadata": metas[j], "score": scores[j]}
+                            for j in range(pos, pos + n)])
+                pos += n
+        else:
+            ok = found.tolist()
+            for n in counts:
+                out.append([{"id": ids[j], "values": rows[j], "metadata": metas[j], "score": scores[j]}
+                            for j in range(pos, pos + n) if ok[j]])
+                pos += n
+        return out
+
+    def find_similar_stream(self, batches, top_k: int, namespace: str = "default", metric: str = "cosine"):
+        """Additive: ``find_similar_many`` over an iterable of query batches, pipelined -- while the GPU scans batch
+        i+1 (a worker thread inside the ctypes call, which holds no GIL) this thread enriches batch i.  Yields one
+        ``List[List[dict]]`` per batch, in order."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pending = None
+            for q in batches:
+                nxt = pool.submit(self._search_many, q, top_k, namespace, metric, None)
+                if pending is not None:
+                    yield self._enrich_many(pending.result(), namespace)
+                pending = nxt
+            if pending is not None:
+                yield self._enrich_many(pending.result(), namespace)
 
     def find_similar_where(self, query: VectorDTO, top_k: int, where, namespace: str = "default",
                            metric: str = "cosine") -> List[dict]:
@@ -117,3 +174,25 @@ class QueryProcessor:
 
     def get_namespace_count(self, namespace: str) -> int:
         return len(self._storage.namespace_map.get(namespace, []))
+
+    def get_storage_info(self) -> Dict[str, Any]:
+        """Passthrough the REST layer relies on (query_processor.py:81-82; rest_api.py:283)."""
+        return self._storage.get_storage_info()
+
+    # ---- additive: bulk ingest without one Python object per row (ArrayStorage + Index.add_arrays)
+    def upsert_arrays(self, values: np.ndarray, namespace: str = "default", metadata=None, *,
+                      keep_host_copy: bool = True) -> np.ndarray:
+        """``upsert_many`` for an ``[n, dim]`` matrix: mints ids, hands the rows to the index and (ids, metadata and --
+        unless ``keep_host_copy=False`` -- the values) to the storage.  Returns the ``[n, 16] uint8`` id table."""
+        if not hasattr(self._storage, "write_arrays") or not hasattr(self._index, "add_arrays"):
+            raise RuntimeError("upsert_arrays needs an array-backed storage (ArrayStorage) and this package's Index")
+        from .idtable import mint_uuid4_bytes
+
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        if values.ndim != 2:
+            raise RuntimeError(f"Wrong dimensionality of the vectors: expected a matrix, got shape {values.shape}")
+        ids = mint_uuid4_bytes(values.shape[0])
+        first = self._storage.write_arrays(ids, namespace, values if keep_host_copy else None, metadata)
+        self._index.add_arrays(values, namespace, ids=ids,
+                               handles=np.arange(first, first + values.shape[0], dtype=np.int64))
+        return ids

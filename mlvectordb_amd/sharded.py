@@ -15,13 +15,14 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 
-def merge_topk(labels: Sequence[np.ndarray], dist64: Sequence[np.ndarray], k: int
-               ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+def merge_topk(labels: Sequence[np.ndarray], dist64: Sequence[np.ndarray], k: int, return_dist64: bool = False
+               ) -> Tuple[np.ndarray, ...]:
     """Merge per-shard results ``[nq, k_s]`` (global labels, -1 = padding) into the global top-k.
 
     Ranking is (distance ascending, label ascending) on the float64 distances -- the same
     order each shard used internally -- so the merged ids equal a single-index search.
-    Returns (labels int64 [nq, k], dist float32 [nq, k], counts int32 [nq]).
+    Returns (labels int64 [nq, k], dist float32 [nq, k], counts int32 [nq]) and, with ``return_dist64``, the merged
+    float64 distances [nq, k] as a fourth entry (for a caller that merges further).
     """
     lab = np.concatenate([np.asarray(l, dtype=np.int64) for l in labels], axis=1)
     d = np.concatenate([np.asarray(x, dtype=np.float64) for x in dist64], axis=1)
@@ -54,6 +55,10 @@ def merge_topk(labels: Sequence[np.ndarray], dist64: Sequence[np.ndarray], k: in
     out_l[:, :width] = np.where(valid, sel_l, -1)
     out_d[:, :width] = np.where(valid, sel_d, np.inf).astype(np.float32)
     counts = valid.sum(axis=1).astype(np.int32)
+    if return_dist64:
+        out_d64 = np.full((nq, k), np.inf, dtype=np.float64)
+        out_d64[:, :width] = np.where(valid, sel_d, np.inf)
+        return out_l, out_d, counts, out_d64
     return out_l, out_d, counts
 
 

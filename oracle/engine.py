@@ -56,8 +56,20 @@ class OracleScanEngine:
         deleted = self._deleted if mask is None else (self._deleted | (np.asarray(mask) == 0))
         return exact_scan.knn(queries, self._rows, k, self.space, deleted=deleted)
 
-    def range(self, queries: np.ndarray, radius: float, capacity: int):
-        return exact_scan.range_query(queries, self._rows, radius, self.space, deleted=self._deleted)
+    def get_rows_at(self, labels: np.ndarray) -> np.ndarray:
+        return self._rows[np.asarray(labels, dtype=np.int64).ravel()].copy()
+
+    def search64(self, queries: np.ndarray, k: int, mask=None):
+        labels, dist, counts = self.search(queries, k, mask)
+        d64 = np.full(labels.shape, np.inf)
+        if self._rows.shape[0]:
+            full = exact_scan.exact_distances(queries, self._rows, self.space)
+            d64 = np.where(labels >= 0, np.take_along_axis(full, np.maximum(labels, 0), axis=1), np.inf)
+        return labels, dist, counts, d64
+
+    def range(self, queries: np.ndarray, radius: float, capacity: int, truncate: bool = False):
+        hits = exact_scan.range_query(queries, self._rows, radius, self.space, deleted=self._deleted)
+        return [(l[:capacity], d[:capacity]) for l, d in hits] if truncate else hits
 
     def close(self) -> None:
         self._rows = np.zeros((0, self.dim), dtype=np.float32)

@@ -73,7 +73,7 @@ def test_labels_continue_and_are_never_reused_until_rebuild():
     i.remove([a[0].id], "ns")
     i.add(b, "ns")
     ns = i._ns["ns"]
-    assert ns.uuid_to_label[b[0].id] == 5 and ns.total == 10 and ns.deleted == 1
+    assert ns.ids.lookup([b[0].id])[0] == 5 and ns.total == 10 and ns.deleted == 1
 
 
 def test_rebuild_threshold_and_flag():
@@ -96,7 +96,7 @@ def test_rebuild_replaces_everything_and_uses_metric_as_space():
     i.rebuild({"A": a[:2]}, metric="cosine")
     assert i.search(VectorDTO(values=b[0].values, metadata={}), 1, "B", "l2") == []  # B wiped (index.py:136-143)
     assert i._ns["A"].engine.space == "cosine" and i._space == "l2"  # _space itself is untouched
-    assert i._ns["A"].uuid_to_label[a[1].id] == 1
+    assert i._ns["A"].ids.lookup([a[1].id])[0] == 1
 
 
 def test_query_processor_delete_rebuilds_all_namespaces_by_default_q4():
@@ -166,7 +166,8 @@ def test_compact_equals_rebuild_from_the_survivors():
     b.rebuild({"ns": survivors, "other": other}, metric="l2")
     assert a.namespace_counts("ns") == b.namespace_counts("ns") == (24, 0)
     assert not a.is_rebuild_required("ns")
-    assert a._ns["ns"].uuid_to_label == b._ns["ns"].uuid_to_label
+    assert np.array_equal(a._ns["ns"].ids.raw[:24], b._ns["ns"].ids.raw[:24])
+    assert a._ns["ns"].ids.lookup([x.id for x in survivors]).tolist() == list(range(24))
     rng = np.random.default_rng(9)
     for _ in range(5):
         q = VectorDTO(values=rng.standard_normal(6).tolist(), metadata={})
@@ -174,7 +175,7 @@ def test_compact_equals_rebuild_from_the_survivors():
         assert a.search(q, 2, "other", "l2") == b.search(q, 2, "other", "l2")
     more = vecs(3, d=6, seed=7)  # labels continue after the compacted rows
     a.add(more, "ns")
-    assert sorted(a._ns["ns"].uuid_to_label[m.id] for m in more) == [24, 25, 26]
+    assert a._ns["ns"].ids.lookup([m.id for m in more]).tolist() == [24, 25, 26]
 
 
 def test_query_processor_delete_compacts_instead_of_rebuilding():
