@@ -653,7 +653,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     constexpr int kTileRowsV = NW * kWaveRows;
     constexpr int kQBufs = 2;
     constexpr int kStageCap = MT == 4 ? kAsmStageCapNw4Mt4 : (NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4);  // entries a wave stages in LDS
-    constexpr bool I8 = QD == 208 || QD == 209 || QD == 210;  // int8 shadow: k-steps of 64 int8 columns, same bytes per step (209: timing diagnostic)
+    constexpr bool I8 = QD == 208 || QD == 209 || QD == 210 || QD == 211;  // int8 shadow (211: accumulators in ArchVGPRs): k-steps of 64 int8 columns, same bytes per step (209: timing diagnostic)
     // LDS: [2][32 KiB] Q chunks at offset 0, thr[256], qscale[256], ke[256], [NW waves] staging {u[], row[], q[]}
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* thr_l = reinterpret_cast<float*>(smem + kQBufs * kChunkVec * sizeof(uint4));
@@ -1574,7 +1574,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     info->scatter_grid = grid;  // the caller runs launch_filter_scatter next (outside its timing window)
     info->nw = NW;
     info->dbg = QD == 108 ? 1 : 0;
-    info->i8 = QD != 208 && QD != 209 && QD != 210 ? 0 : (SPACE == kSpaceCosine ? 1 : (SPACE == kSpaceIp ? 2 : 0));  // how the scatter turns stored values into bounds
+    info->i8 = QD != 208 && QD != 209 && QD != 210 && QD != 211 ? 0 : (SPACE == kSpaceCosine ? 1 : (SPACE == kSpaceIp ? 2 : 0));  // how the scatter turns stored values into bounds
     return hipGetLastError();
 }
 
@@ -1605,6 +1605,8 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                     return launch_scan_asm<SPACE, 4, 8, true, 210, true, 2, true>(a, row_begin, row_end, s, info);
             }
 #endif
+            if (env_int("MLVDB_SCAN_VA", 1))  // accumulators in ArchVGPRs: the admission test reads them directly
+                return launch_scan_asm<SPACE, 4, 8, true, 211, true, 2, true>(a, row_begin, row_end, s, info);
             if (env_int("MLVDB_SCAN_PRIO", 1))
                 return launch_scan_asm<SPACE, 4, 8, true, 208, true, 2, true>(a, row_begin, row_end, s, info);
             return launch_scan_asm<SPACE, 4, 8, true, 208, false, 2, true>(a, row_begin, row_end, s, info);

@@ -50,6 +50,8 @@ SPACES = {"l2": 0, "cosine": 1, "ip": 2}
 I8_SPACE = None
 I8 = False     # generate(): int8 shadow -- v_mfma_i32_16x16x64_i8, k-steps of 64 columns, integer accumulators
 STAG = False   # generate(): the later-dispatched half of the waves runs half a tile behind (see generate)
+VA = False     # generate(): accumulators in ArchVGPRs v[VA_BASE : VA_BASE + 64*MT), ring and B fragments in AccVGPRs (see generate)
+VA_BASE = 64   # v0..v63 stay with the compiler (the statement's "v" operands)
 DBG = set()   # timing diagnostics only (wrong results): 'nolds' drops the B-fragment reads, 'nox' the X refills
 
 
@@ -114,7 +116,14 @@ class Sched:
 
 def acc(m, n):
     b = (m * 16 + n) * 4
+    if VA:
+        return f"v[{VA_BASE + b}:{VA_BASE + b + 3}]"
     return f"a[{b}:{b + 3}]"
+
+
+def acc_reg(m, n, i):
+    """Register i (0..3: rows 4g+i of panel m) of the accumulator of (panel m, query tile n)."""
+    return f"v{VA_BASE + (m * 16 + n) * 4 + i}" if VA else f"a{(m * 16 + n) * 4 + i}"
 
 
 def ring(b, m):
@@ -306,8 +315,11 @@ def gen_admission(space):
     """After the k-loop of a tile: bounds, quick reject per query tile, calls into .Lslow."""
     s = Sched()
     a = s.emit
-    a("s_nop 15")   # XDL write -> v_accvgpr_read of the accumulators
-    a("s_nop 7")
+    if not VA:
+        a("s_nop 15")   # XDL write -> v_accvgpr_read of the accumulators
+        a("s_nop 7")
+    # (VA: the accumulators are ArchVGPRs, read by the VALU directly; query tile n's last MFMA was issued 2*(16-n)
+    # MFMAs and 22*n vector instructions before its first read here, far beyond the XDL-write -> VALU-read distance)
     # ke = the query's error term from LDS (filter_prep_kernel).  Per-row constants (scan_epilogue):
     # cosine p0 = 1/(|x|+1e-30), u = a*p0 + ke; ip p0 = |x|, u = a + ke*p0; l2 p0 = |x|, p1 = -|x|^2 (1-slack),
     # u = sq*(a + ke*p0) + p1
@@ -329,10 +341,13 @@ def gen_admission(space):
                 s.lds(f"ds_read_b32 %[e{(n + 1) & 1}], %[thra] offset:{(n + 1) * 64}", ("thr", n + 1))
             for j in range(NR):
                 m, i = j >> 2, j & 3
-                if "noread" not in DBG:   # timing diagnostic: the test's arithmetic on stale registers
+                if VA:
+                    a(f"v_cvt_f32_i32 %[u{j}], {acc_reg(m, n, i)}")
+                elif "noread" not in DBG:   # timing diagnostic: the test's arithmetic on stale registers
                     a(f"v_accvgpr_read_b32 %[u{j}], a{(m * 16 + n) * 4 + i}")
             for j in range(NR):
-                a(f"v_cvt_f32_i32 %[u{j}], %[u{j}]")
+                if not VA:
+                    a(f"v_cvt_f32_i32 %[u{j}], %[u{j}]")
             for j in range(NR):
                 a(f"v_fma_f32 %[u{j}], %[u{j}], %[r{j}], %[p{j}]")
             a("v_max3_f32 %[e4], %[u0], %[u1], %[u2]")
@@ -375,13 +390,17 @@ def gen_admission(space):
             fetch(n + 1)
         for j in range(NR):
             m, i = j >> 2, j & 3
-            a(f"v_accvgpr_read_b32 %[u{j}], a{(m * 16 + n) * 4 + i}")
+            if VA:
+                a(f"v_cvt_f32_i32 %[u{j}], {acc_reg(m, n, i)}")
+            else:
+                a(f"v_accvgpr_read_b32 %[u{j}], a{(m * 16 + n) * 4 + i}")
         if I8:
             # int8 shadow, l2 / ip: w = float(I) * sx_j takes the place of the bf16 dot product; the per-query constants in
             # LDS are rescaled by the query's scale (filter_scan_asm_kernel): ip  w + ke' |x| >= thr/sq8 (the append path
             # stores that, filter_scatter_kernel multiplies by sq8), l2  sq' (w + ke' |x|) + p1 >= thr
             for j in range(NR):
-                a(f"v_cvt_f32_i32 %[u{j}], %[u{j}]")
+                if not VA:
+                    a(f"v_cvt_f32_i32 %[u{j}], %[u{j}]")
             for j in range(NR):
                 a(f"v_mul_f32 %[u{j}], %[u{j}], %[s{j}]")
         s.need_lg(("ke", n), *([("sq", n)] if space == "l2" else []))
@@ -514,18 +533,26 @@ def gen_flush(NW):
             "s_waitcnt vmcnt(0)"]
 
 
-def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False):
+def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False):
     """stag: both waves of a SIMD reach the admission test (VALU only) together and leave the MFMA pipe idle for it.
     With the stagger the later-dispatched half of a workgroup's waves (wtype 1) runs half a tile behind: it sits out
     the first nkc/2 chunk periods (staging only), starts every row tile at column ld/2 (k origin rotated by xrot,
     wrapping at the end of the panel; the shared Q chunk stream is the same for everybody) and therefore reaches its
     admission test while its SIMD partner is in mid-tile; the early half sits out nkc/2 periods at the end.
     hc = 0 (and xrot = 0) turns it off at run time."""
-    global MT, STAG, I8, I8_SPACE
+    global MT, STAG, I8, I8_SPACE, VA
     MT = mt
     STAG = stag
     I8 = i8
     I8_SPACE = space if i8 else None
+    # va (int8 bodies): the 64*MT accumulator registers are ArchVGPRs, named explicitly (v[VA_BASE:...], clobbered), and
+    # the MFMA operands -- the X ring and the B fragments, which only loads and MFMAs ever touch -- are AccVGPRs
+    # (loads may target them: MUBUF / DS acc bit).  An MFMA's C and D must be of one register class (the assembler
+    # rejects v-dst with a-srcC), so "results straight into VGPRs" means the whole accumulator lives there; the
+    # admission test then reads it with no v_accvgpr_read and no XDL drain.  With two waves per SIMD the kernel
+    # descriptor becomes 192 ArchVGPRs + 48 AccVGPRs (accum_offset 192) instead of hipcc's 128 / 128 split.
+    VA = va
+    assert not va or (i8 and mt == 2 and dma and not stag)
     assert R in (2, 4, 6) and 2 <= QD <= 8 and mt in (2, 4)
     assert not stag or (dma and mt == 2 and R * 1024 <= 4096)
     KQ = 1024 // (NW * 64)
@@ -671,16 +698,17 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     a(".Ldone_%=:")
 
     ops_out, ops_in = [], []
+    opc = "a" if va else "v"   # register class of the MFMA A / B operands
     for b in range(R):
         for m in range(MT):
-            ops_out.append(f'[x{b * MT + m}] "=&v"(xring[{b * MT + m}])')
+            ops_out.append(f'[x{b * MT + m}] "=&{opc}"(xring[{b * MT + m}])')
     if not dma:
         for i in range(KQ):
             ops_out.append(f'[qa{i}] "=&v"(qsa[{i}])')
         for i in range(KQ):
             ops_out.append(f'[qb{i}] "=&v"(qsb[{i}])')
     for i in range(QD):
-        ops_out.append(f'[t{i}] "=&v"(qt[{i}])')
+        ops_out.append(f'[t{i}] "=&{opc}"(qt[{i}])')
     for j in range(4 * MT):
         ops_out.append(f'[r{j}] "=&v"(vr[{j}])')
     if space == "l2" or (i8 and space == "cosine"):
@@ -710,12 +738,14 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
         ops_in.append('[wave2k] "s"(wave2k)')
     if stag:
         ops_in += ['[xrot] "s"(xrot)', '[pbrot] "s"(pbrot)', '[pb2] "s"(pb2)', '[hc] "s"(hc)']
-    clobbers = ['"memory"', '"scc"', '"vcc"'] + (['"m0"'] if dma else []) + [f'"s{i}"' for i in range(60, 80)] + [f'"s{i}"' for i in range(80, 94)] + [f'"a{i}"' for i in range(64 * MT)]
+    clobbers = ['"memory"', '"scc"', '"vcc"'] + (['"m0"'] if dma else []) + [f'"s{i}"' for i in range(60, 80)] + [f'"s{i}"' for i in range(80, 94)] + (
+        [f'"v{i}"' for i in range(VA_BASE, VA_BASE + 64 * MT)] if va else [f'"a{i}"' for i in range(64 * MT)])
 
     text = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.",
             f"// filter scan body: space {space}, NW={NW} waves x {16 * MT} rows, ring R={R} k-steps, B fragments read {QD} ahead"
             f"{', X loads non-temporal' if nt else ''}{', progress-based wave priority' if prio else ''}{', Q staged by LDS-DMA' if dma else ''}"
-            f"{', late waves staggered by half a tile' if stag else ''}{', int8 shadow (v_mfma_i32_16x16x64_i8)' if i8 else ''}.",
+            f"{', late waves staggered by half a tile' if stag else ''}{', int8 shadow (v_mfma_i32_16x16x64_i8)' if i8 else ''}"
+            f"{', accumulators in ArchVGPRs' if va else ''}.",
             "asm volatile("]
     for ln in out:
         text.append(f'    "{ln}\\n\\t"')
@@ -750,7 +780,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -759,6 +789,8 @@ def main():
         (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag))
     for space, nw, r, nt, qd, prio, mt, dma, stag in I8_CONFIGS:
         (Path(args.outdir) / f"scan_asm_{space}_i8{'_pr' if prio else ''}.inc").write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag, True))
+    for space in SPACES:   # the int8 bodies with ArchVGPR accumulators (wave priorities on): QD slot 211
+        (Path(args.outdir) / f"scan_asm_{space}_i8_va.inc").write_text(generate(space, 4, 4, 8, True, True, 2, True, False, True, True))
     for code, knobs in DIAG.items():
         DBG.clear()
         DBG.update(knobs)
@@ -781,6 +813,9 @@ def main():
         for pr in (False, True):
             disp.append(f"}} else if constexpr (SPACE == {code} && NW == 8 && R == 4 && NT == true && QD == 208 && PRIO == {'true' if pr else 'false'} && MT == 2 && DMA == true && STAG == false) {{")
             disp.append(f'#include "scan_asm_{sp}_i8{"_pr" if pr else ""}.inc"')
+    for sp, code in SPACES.items():
+        disp.append(f"}} else if constexpr (SPACE == {code} && NW == 8 && R == 4 && NT == true && QD == 211 && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
+        disp.append(f'#include "scan_asm_{sp}_i8_va.inc"')
     disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
     for code in DIAG:
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2 && DMA == false && STAG == false) {{")
