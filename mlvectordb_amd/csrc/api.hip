@@ -376,6 +376,18 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
         HIP_TRY(h, launch_filter_scan(fa, b, e, s, &info));
         rc = scan_event(h, s, false);
         if (rc) return rc;
+        if (getenv("MLVDB_DEBUG_ENTRIES")) {  // tuning aid: entries appended by this scan launch (synchronises the stream)
+            std::vector<uint32_t> wc((size_t)kScanMaxGrid * 8, 0u);
+            HIP_TRY(h, hipMemcpyAsync(wc.data(), fa.wgcnt, wc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+            uint64_t sum = 0, mx = 0;
+            for (int i = 0; i < info.scatter_grid * info.nw; ++i) {
+                sum += wc[(size_t)i];
+                mx = std::max<uint64_t>(mx, wc[(size_t)i]);
+            }
+            fprintf(stderr, "[mlvdb] scan rows [%lld, %lld): %llu entries appended (%.1f per query), max per wave %llu\n",
+                    (long long)b, (long long)e, (unsigned long long)sum, (double)sum / fa.nq, (unsigned long long)mx);
+        }
         HIP_TRY(h, launch_filter_scatter(fa, info, s));
         h->stats.scan_launches += 1;
         h->stats.rows_scanned += e - b;

@@ -653,7 +653,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     constexpr int kTileRowsV = NW * kWaveRows;
     constexpr int kQBufs = 2;
     constexpr int kStageCap = MT == 4 ? kAsmStageCapNw4Mt4 : (NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4);  // entries a wave stages in LDS
-    constexpr bool I8 = QD == 208 || QD == 209 || QD == 210 || QD == 211;  // int8 shadow (211: accumulators in ArchVGPRs): k-steps of 64 int8 columns, same bytes per step (209: timing diagnostic)
+    constexpr bool I8 = QD == 208 || QD == 209 || QD == 210 || QD == 211 || QD == 212 || QD == 213;  // int8 shadow (211: accumulators in ArchVGPRs): k-steps of 64 int8 columns, same bytes per step (209: timing diagnostic)
     // LDS: [2][32 KiB] Q chunks at offset 0, thr[256], qscale[256], ke[256], [NW waves] staging {u[], row[], q[]}
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* thr_l = reinterpret_cast<float*>(smem + kQBufs * kChunkVec * sizeof(uint4));
@@ -757,8 +757,9 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     static_assert(kWgCap == 16384 && sizeof(WgEntry) == 16, "the assembly hard-codes the append buffer geometry");
 
     u32x4s xring[R * MT], qsa[kQPer], qsb[kQPer], qt[QD > 8 ? 4 : QD];
-    float vr[4 * MT], vp[4 * MT], vu[4 * MT], vs[4 * MT];
+    float vr[4 * MT], vp[4 * MT], vu[4 * MT], vs[4 * MT], vt[16];
     (void)vs;
+    (void)vt;
     uint32_t ve[13], ldr, ldw, s_sldw;
     const uint32_t wave2k = (uint32_t)wave * 2048u;  // LDS-DMA staging: this wave's piece offset inside a Q buffer
     (void)ldw;
@@ -1175,72 +1176,102 @@ __device__ __forceinline__ int64_t layout_offset_i8(int64_t row, int32_t col, in
            (col & 15);
 }
 
-// One wave per 16-row panel: lane 16g + r owns row r, columns 4g..4g+3 of every 16-column group (one coalesced
-// 1 KiB load per group, as everywhere); pass 1 finds the row maxima, pass 2 (the panel is in L2 by then) quantises
-// and measures the error.  Whole panels are (re)written: idempotent for rows converted before.
+// One wave per 32-row slab (two 16-row panels): lane 16g + r owns row r of each panel, columns 4g..4g+3 of every
+// 16-column group (one coalesced 1 KiB load per group, as everywhere); pass 1 finds the row maxima, pass 2 (the slab is
+// in L2 by then) quantises and measures the error.  Whole slabs are (re)written: idempotent for rows converted before.
+//
+// Scales.  l2 / ip: one scale per row, sx = max|x_i| / 127.  Cosine: the 8 rows that one lane of the scan holds for a
+// query tile -- rows 4g'..4g'+3 of both panels of the slab -- share ONE ratio sx / (|x| + 1e-30), the largest of their
+// own ratios (so nobody clips; the others quantise ~10 % coarser, and every row's error is still measured, not
+// assumed).  The scan's row constant a = sx/(|x|+1e-30) is then the same for the lane's 8 rows, which makes the
+// one-compare pre-test of the folded admission test (tools/gen_scan_asm.py, gen_pretest: max_j(I_j) * max_j(a_j) +
+// max_j(b_j K) >= T) as sharp as the 8 exact tests it stands for.
 __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const float* rn, int8_t* X8, float* rp8,
-                                                           unsigned int* row_err8, int64_t panel_begin, int64_t panel_end,
-                                                           int32_t ld, int32_t space) {
+                                                           unsigned int* row_err8, int64_t slab_begin, int64_t slab_end,
+                                                           int64_t panel_end, int32_t ld, int32_t space) {
     const int lane = threadIdx.x & 63;
-    const int64_t panel = panel_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (panel >= panel_end) return;
+    const int64_t slab = slab_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slab >= slab_end) return;
     const int g = lane >> 4, r = lane & 15;
-    const float4* src = reinterpret_cast<const float4*>(X + panel * (int64_t)(kPanelRows * ld) + lane_group_offset(lane));
     const int ngroups = ld / 16;
-    float amax = 0.f;
-    for (int cg = 0; cg < ngroups; ++cg) {
-        const float4 v = src[cg * (kGroupFloats / 4)];
-        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y))),
-                               __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
-    }
-    amax = __builtin_fmaxf(amax, __shfl_xor(amax, 16));
-    amax = __builtin_fmaxf(amax, __shfl_xor(amax, 32));
-    const float sx = amax > 0.f ? amax / 127.0f : 1.0f;
-    const float inv = 1.0f / sx;
-    double err2 = 0.0, n2 = 0.0;
-    uint32_t* dst = reinterpret_cast<uint32_t*>(X8 + panel * (int64_t)(kPanelRows * ld)) + r * 4 + g;
-    for (int cg = 0; cg < ngroups; ++cg) {
-        const float4 v = src[cg * (kGroupFloats / 4)];
-        const float x[4] = {v.x, v.y, v.z, v.w};
-        uint32_t packed = 0;
+    float amax[2] = {0.f, 0.f}, nrm[2], ratio = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float t = __builtin_rintf(x[i] * inv);
-            t = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, t));
-            packed |= ((uint32_t)(int)t & 0xffu) << (8 * i);
-            const double e = (double)x[i] - (double)sx * (double)t;
-            err2 += e * e;
-            n2 += (double)x[i] * (double)x[i];
+    for (int p = 0; p < 2; ++p) {
+        const int64_t panel = slab * 2 + p;
+        nrm[p] = __builtin_nanf("");
+        if (panel >= panel_end) continue;  // the capacity is a whole number of panels, not of slabs
+        const float4* src = reinterpret_cast<const float4*>(X + panel * (int64_t)(kPanelRows * ld) + lane_group_offset(lane));
+        float m = 0.f;
+        for (int cg = 0; cg < ngroups; ++cg) {
+            const float4 v = src[cg * (kGroupFloats / 4)];
+            m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y))),
+                                __builtin_fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
         }
-        dst[(cg >> 2) * 256 + (cg & 3) * 64] = packed;  // bytes: (cg>>2)*1024 + (cg&3)*256 + r*16 + 4g (layout_offset_i8)
+        m = __builtin_fmaxf(m, __shfl_xor(m, 16));
+        m = __builtin_fmaxf(m, __shfl_xor(m, 32));
+        amax[p] = m;
+        nrm[p] = rn[panel * kPanelRows + r];  // NaN: tombstoned / not a row
+        if (nrm[p] == nrm[p]) ratio = __builtin_fmaxf(ratio, m / (nrm[p] + 1e-30f));
     }
-    err2 += __shfl_xor(err2, 16);
-    err2 += __shfl_xor(err2, 32);
-    n2 += __shfl_xor(n2, 16);
-    n2 += __shfl_xor(n2, 32);
-    if (g == 0) {
-        const int64_t row = panel * kPanelRows + r;
-        const float nrm = rn[row];  // NaN: tombstoned / not a row
-        float rel = 0.f;
-        if (n2 > 0.0) {
-            rel = (float)(__builtin_sqrt(err2 / n2) * 1.000001);
-            rel = __uint_as_float(__float_as_uint(rel) + 1u);
-            atomicMax(row_err8, __float_as_uint(rel));  // non-negative floats order like their bits
+    // the group's ratio: rows r with the same r >> 2, both panels
+    ratio = __builtin_fmaxf(ratio, __shfl_xor(ratio, 1));
+    ratio = __builtin_fmaxf(ratio, __shfl_xor(ratio, 2));
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int64_t panel = slab * 2 + p;
+        if (panel >= panel_end) continue;
+        float sx = amax[p] > 0.f ? amax[p] / 127.0f : 1.0f;
+        if (space == kSpaceCosine && nrm[p] == nrm[p] && ratio > 0.f) {
+            const float shared = ratio * (nrm[p] + 1e-30f) * (1.0f / 127.0f) * 1.0000005f;
+            if (shared > sx) sx = shared;  // never finer than the row's own scale: nothing clips
         }
-        // per-row pair: cosine {sx/(|x|+1e-30), this row's error}, l2 / ip {sx, |x|}; NaN marks a tombstone
-        float2 pr;
-        if (space == kSpaceCosine) pr = make_float2(sx / (nrm + 1e-30f), nrm == nrm ? rel : nrm);
-        else pr = make_float2(nrm == nrm ? sx : nrm, nrm);
-        reinterpret_cast<float2*>(rp8)[row] = pr;
+        const float inv = 1.0f / sx;
+        double err2 = 0.0, n2 = 0.0;
+        const float4* src = reinterpret_cast<const float4*>(X + panel * (int64_t)(kPanelRows * ld) + lane_group_offset(lane));
+        uint32_t* dst = reinterpret_cast<uint32_t*>(X8 + panel * (int64_t)(kPanelRows * ld)) + r * 4 + g;
+        for (int cg = 0; cg < ngroups; ++cg) {
+            const float4 v = src[cg * (kGroupFloats / 4)];
+            const float x[4] = {v.x, v.y, v.z, v.w};
+            uint32_t packed = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = __builtin_rintf(x[i] * inv);
+                t = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, t));
+                packed |= ((uint32_t)(int)t & 0xffu) << (8 * i);
+                const double e = (double)x[i] - (double)sx * (double)t;
+                err2 += e * e;
+                n2 += (double)x[i] * (double)x[i];
+            }
+            dst[(cg >> 2) * 256 + (cg & 3) * 64] = packed;  // bytes: (cg>>2)*1024 + (cg&3)*256 + r*16 + 4g (layout_offset_i8)
+        }
+        err2 += __shfl_xor(err2, 16);
+        err2 += __shfl_xor(err2, 32);
+        n2 += __shfl_xor(n2, 16);
+        n2 += __shfl_xor(n2, 32);
+        if (g == 0) {
+            const int64_t row = panel * kPanelRows + r;
+            float rel = 0.f;
+            if (n2 > 0.0) {
+                rel = (float)(__builtin_sqrt(err2 / n2) * 1.000001);
+                rel = __uint_as_float(__float_as_uint(rel) + 1u);
+                atomicMax(row_err8, __float_as_uint(rel));  // non-negative floats order like their bits
+            }
+            // per-row pair: cosine {sx/(|x|+1e-30), this row's error}, l2 / ip {sx, |x|}; NaN marks a tombstone
+            float2 pr;
+            if (space == kSpaceCosine) pr = make_float2(sx / (nrm[p] + 1e-30f), nrm[p] == nrm[p] ? rel : nrm[p]);
+            else pr = make_float2(nrm[p] == nrm[p] ? sx : nrm[p], nrm[p]);
+            reinterpret_cast<float2*>(rp8)[row] = pr;
+        }
     }
 }
 
 hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t row_begin,
                                int64_t row_end, int32_t ld, int32_t space, hipStream_t s) {
-    const int64_t pb = row_begin / kPanelRows, pe = (row_end + kPanelRows - 1) / kPanelRows;
-    if (pe <= pb) return hipSuccess;
-    shadow8_rows_kernel<<<(unsigned)((pe - pb + 3) / 4), 256, 0, s>>>(X, rn, static_cast<int8_t*>(X8), rp8,
-                                                                       reinterpret_cast<unsigned int*>(row_err8), pb, pe, ld, space);
+    const int64_t pe = (row_end + kPanelRows - 1) / kPanelRows;
+    const int64_t sb = row_begin / (2 * kPanelRows), se = (pe + 1) / 2;
+    if (se <= sb) return hipSuccess;
+    shadow8_rows_kernel<<<(unsigned)((se - sb + 3) / 4), 256, 0, s>>>(X, rn, static_cast<int8_t*>(X8), rp8,
+                                                                       reinterpret_cast<unsigned int*>(row_err8), sb, se, pe, ld, space);
     return hipGetLastError();
 }
 
@@ -1574,7 +1605,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     info->scatter_grid = grid;  // the caller runs launch_filter_scatter next (outside its timing window)
     info->nw = NW;
     info->dbg = QD == 108 ? 1 : 0;
-    info->i8 = QD != 208 && QD != 209 && QD != 210 && QD != 211 ? 0 : (SPACE == kSpaceCosine ? 1 : (SPACE == kSpaceIp ? 2 : 0));  // how the scatter turns stored values into bounds
+    info->i8 = QD != 208 && QD != 209 && QD != 210 && QD != 211 && QD != 212 && QD != 213 ? 0 : (SPACE == kSpaceCosine ? 1 : (SPACE == kSpaceIp ? 2 : 0));  // how the scatter turns stored values into bounds
     return hipGetLastError();
 }
 
@@ -1603,6 +1634,10 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                     return launch_scan_asm<SPACE, 4, 8, true, 209, true, 2, true>(a, row_begin, row_end, s, info);
                 if (env_int("MLVDB_SCAN_DIAG", 0) == 210)
                     return launch_scan_asm<SPACE, 4, 8, true, 210, true, 2, true>(a, row_begin, row_end, s, info);
+                if (env_int("MLVDB_SCAN_DIAG", 0) == 212)
+                    return launch_scan_asm<SPACE, 4, 8, true, 212, true, 2, true>(a, row_begin, row_end, s, info);
+                if (env_int("MLVDB_SCAN_DIAG", 0) == 213)
+                    return launch_scan_asm<SPACE, 4, 8, true, 213, true, 2, true>(a, row_begin, row_end, s, info);
             }
 #endif
             if (env_int("MLVDB_SCAN_VA", 1))  // accumulators in ArchVGPRs: the admission test reads them directly

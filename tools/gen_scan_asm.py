@@ -52,6 +52,7 @@ I8 = False     # generate(): int8 shadow -- v_mfma_i32_16x16x64_i8, k-steps of 6
 STAG = False   # generate(): the later-dispatched half of the waves runs half a tile behind (see generate)
 VA = False     # generate(): accumulators in ArchVGPRs v[VA_BASE : VA_BASE + 64*MT), ring and B fragments in AccVGPRs (see generate)
 VA_BASE = 64   # v0..v63 stay with the compiler (the statement's "v" operands)
+FUSE = False   # generate(): the admission test is folded into the tile's last k-step (cosine, VA; see gen_pretest)
 DBG = set()   # timing diagnostics only (wrong results): 'nolds' drops the B-fragment reads, 'nox' the X refills
 
 
@@ -66,6 +67,7 @@ class Sched:
         self.lg_done = 0
         self.recording = True
         self.label = 0
+        self.copy = ""   # which copy of the tile's last body this is (FUSE: its hit stubs return into it)
 
     def emit(self, text):
         if "nobar" in DBG and text == "s_barrier":
@@ -135,8 +137,53 @@ PRIO_STEPS = {8: (0, 2), 12: (1, 2), 16: (0, 1), 20: (1, 1), 24: (0, 0), 28: (1,
 XCUR, XNEXT, RNS, RET = "s[80:83]", "s[84:87]", "s[88:91]", "s[92:93]"
 
 
-def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=False):
-    """One 64-column chunk = 2 k-steps = 32 fragments x MT MFMAs."""
+def gen_pretest(s, n, part):
+    """Admission pre-test of query tile n, folded into the tile's last k-step (int8 cosine, ArchVGPR accumulators).
+
+    Exact test per row j and query: float(I_j) r_j + p_j >= T (gen_admission).  With r_j >= 0 and
+    R = max_j r_j, P = max_j p_j over the lane's 8 rows (NaN = tombstoned rows drop out of v_max_f32),
+    float(max(0, max_j I_j)) R + P >= float(I_j) r_j + p_j for every j (rounding is monotone), so a lane whose
+    left-hand side stays below T holds no admissible row: 4 v_max3_i32 + cvt + fma + compare per query tile instead
+    of 8 reads + 8 cvt + 8 fma + 5 max + compare, issued between the MFMAs of the following query tiles.  A lane
+    that passes sends the wave to .Lhit<n>, which computes the 8 exact bounds and calls the append routine; on
+    N(0,1) rows the pre-test lets ~2 % of the (wave, query tile) pairs through, the exact test 0.3 %.
+    part 0 / 1: the halves issued after the first / second MFMA of the query tile two steps later."""
+    a = s.emit
+    regs = [acc_reg(m, n, i) for m in range(MT) for i in range(4)]
+    t0, t1 = (("%[e0]", "%[e1]") if n & 1 == 0 else ("%[e2]", "%[e3]"))
+    if part == 0:
+        a(f"v_max3_i32 {t0}, {regs[0]}, {regs[1]}, {regs[2]}")
+        a(f"v_max3_i32 {t1}, {regs[3]}, {regs[4]}, {regs[5]}")
+        a(f"v_max3_i32 {t0}, {t0}, {regs[6]}, {regs[7]}")
+        a(f"v_max3_i32 {t0}, {t0}, {t1}, 0")
+    else:
+        a(f"v_cvt_f32_i32 {t0}, {t0}")
+        a(f"v_fma_f32 {t0}, {t0}, %[e10], %[e12]")
+        a(f"v_cmp_ge_f32 vcc, {t0}, %[tq{n}]")
+        if "nohit" not in DBG:
+            a(f"s_cbranch_vccnz .Lhit{n}c{s.copy}_%=")
+        a(f".Lback{n}c{s.copy}_%=:")
+
+
+def gen_rowmax(s, part):
+    """Start of the last k-step: p_j *= K, then R = max r_j and P = max p_j over this lane's rows (e10, e12)."""
+    a = s.emit
+    NR = 4 * MT
+    if part == 0:
+        for j in range(NR):
+            a(f"v_mul_f32 %[p{j}], %[k1], %[p{j}]")
+    else:
+        for dst, src in (("%[e10]", "r"), ("%[e12]", "p")):
+            a(f"v_max3_f32 {dst}, %[{src}0], %[{src}1], %[{src}2]")
+            for j in range(3, NR - 1, 2):
+                a(f"v_max3_f32 {dst}, {dst}, %[{src}{j}], %[{src}{j + 1}]")
+            if (NR - 3) % 2:
+                a(f"v_max_f32 {dst}, {dst}, %[{src}{NR - 1}]")
+
+
+def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=False, final=False):
+    """One 64-column chunk = 2 k-steps = 32 fragments x MT MFMAs.  final: the tile's last chunk, whose second k-step
+    carries the admission pre-tests (FUSE)."""
     s.emit("v_xor_b32 %[ldr], 0x8000, %[ldr]")
     if dma:
         s.emit("s_xor_b32 %[sldw], %[sldw], 0x8000")
@@ -223,11 +270,20 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
             s.label += 1
         if n == 0:
             s.need_vm(*[("x", b, m) for m in range(MT)])
+            if final and h == 1:   # issued before this body's ring refills: landed with them (vmcnt completes in order)
+                s.need_vm(*[("rn", j) for j in range(4 * MT)])
         s.need_lg(("rd", f))
         for m in range(MT):
             c = "0" if (zero_first and h == 0) else acc(m, n)
             op = "v_mfma_i32_16x16x64_i8" if I8 else "v_mfma_f32_16x16x32_bf16"
             s.emit(f"{op} {acc(m, n)}, {ring(b, m)}, %[t{f % QD}], {c}")
+            if final and h == 1:
+                # the accumulators of query tile n - 2 are complete (their last MFMAs were issued four MFMAs ago)
+                if n < 2:
+                    if m == 1:
+                        gen_rowmax(s, n)
+                else:
+                    gen_pretest(s, n - 2, m)
         if f + QD < 32:
             read(f + QD)
         if f in plan:
@@ -246,6 +302,12 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
                 s.vmem(f"buffer_load_dwordx4 {reg}, %[qvoff], %[qsrd], %[st0] offen", (setname, i))
         if n == 15:
             refill(h)
+    if final:   # the last two query tiles: nothing left to hide behind
+        gen_pretest(s, 14, 0)
+        gen_pretest(s, 14, 1)
+        s.emit("s_nop 3")   # XDL write (query tile 15's MFMAs, 10 instructions back) -> VALU read
+        gen_pretest(s, 15, 0)
+        gen_pretest(s, 15, 1)
     # advance the Q cursor (chunk c+2 -> c+3, wrapping) and publish the chunk just staged
     s.emit("s_add_u32 %[qcur], %[qcur], 0x8000")
     s.emit("s_cmp_eq_u32 %[qcur], %[qbytes]")
@@ -295,7 +357,7 @@ def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False, dma=False):
             s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{off}" if off else ""),
                    ("rn", j))
     for ch in range(R // 2):
-        gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last, nt, prio, dma)
+        gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last, nt, prio, dma, FUSE and last and ch == R // 2 - 1)
     if last:
         s.need_vm(*[("rn", j) for j in range(4 * MT)])
 
@@ -307,6 +369,7 @@ def body_lines(R, QD, KQ, NW, first, last, nt, prio=False, label0=0, dma=False):
         gen_body(s, R, QD, KQ, NW, False, False, nt, prio, dma)
     s.recording = True
     s.label = label0
+    s.copy = str(label0)
     gen_body(s, R, QD, KQ, NW, first, last, nt, prio, dma)
     return s.lines
 
@@ -324,6 +387,8 @@ def gen_admission(space):
     # cosine p0 = 1/(|x|+1e-30), u = a*p0 + ke; ip p0 = |x|, u = a + ke*p0; l2 p0 = |x|, p1 = -|x|^2 (1-slack),
     # u = sq*(a + ke*p0) + p1
     NR = 4 * MT
+    if FUSE:
+        return s.lines   # the pre-tests ran inside the last k-step (gen_pretest); .Lback<n> live there
     if I8 and space == "cosine":
         # int8 shadow, cosine: r_j = sx/(|x|+1e-30) of the row (NaN: tombstoned), p_j = the row's own rounding error,
         # accumulators = exact integer dot products I; the test is float(I)*r_j + p_j*K >= T[q] with T = (thr - ke8)/sq8
@@ -427,17 +492,22 @@ def gen_admission(space):
     return s.lines
 
 
-def gen_hit_stubs():
+def gen_hit_stubs(copy=""):
     out = []
     for n in range(16):
-        out += [f".Lhit{n}_%=:",
-                f"v_mov_b32 %[e6], %[e{n & 1}]",          # the threshold of this query tile
+        out.append(f".Lhit{n}{copy}_%=:")
+        if FUSE:   # the pre-test let a lane through: the 8 exact bounds of this query tile (gen_admission's arithmetic)
+            for j in range(4 * MT):
+                out.append(f"v_cvt_f32_i32 %[u{j}], {acc_reg(j >> 2, n, j & 3)}")
+            for j in range(4 * MT):
+                out.append(f"v_fma_f32 %[u{j}], %[u{j}], %[r{j}], %[p{j}]")
+        out += [f"v_mov_b32 %[e6], %[tq{n}]" if FUSE else f"v_mov_b32 %[e6], %[e{n & 1}]",          # the threshold of this query tile
                 f"s_movk_i32 %[sn64], 0x{n * 16:x}",      # first query of this tile
                 f"s_getpc_b64 {RET}",
                 "s_add_u32 s92, s92, 12",                 # return to the instruction after the branch below
                 "s_addc_u32 s93, s93, 0",
                 "s_branch .Lslow_%=",
-                f"s_branch .Lback{n}_%="]
+                f"s_branch .Lback{n}{copy}_%="]
     return out
 
 
@@ -494,6 +564,8 @@ def gen_slow(NW):
                   "v_lshlrev_b32 %[e7], 2, %[e9]",
                   "v_mov_b32 %[e5], 1",
                   "global_store_dword %[e7], %[e5], %[ovfb]",           # overflow[q] = 1: the query is re-run exactly
+                  "s_mov_b64 exec, -1",
+                  "s_waitcnt vmcnt(0)",   # stores may complete before older loads: no counted vmcnt wait may see them
                   f".Lnext{j}_%=:",
                   "s_add_u32 %[wcnt], %[wcnt], %[st0]",
                   f".Lskip{j}_%=:",
@@ -553,6 +625,8 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     # descriptor becomes 192 ArchVGPRs + 48 AccVGPRs (accum_offset 192) instead of hipcc's 128 / 128 split.
     VA = va
     assert not va or (i8 and mt == 2 and dma and not stag)
+    global FUSE
+    FUSE = va and space == "cosine" and "noadm" not in DBG
     assert R in (2, 4, 6) and 2 <= QD <= 8 and mt in (2, 4)
     assert not stag or (dma and mt == 2 and R * 1024 <= 4096)
     KQ = 1024 // (NW * 64)
@@ -615,6 +689,10 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
             a(f"buffer_load_dwordx4 %[{setname}{i}], %[qvoff], %[qsrd], %[st0] offen")
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")   # counted waits below assume the steady-state issue pattern
     a("s_barrier")
+    if FUSE:   # the thresholds of this lane's query column in the 16 query tiles: constant for the whole launch
+        for n in range(16):
+            a(f"ds_read_b32 %[tq{n}], %[thra]" + (f" offset:{n * 64}" if n else ""))
+        a("s_waitcnt lgkmcnt(0)")
     if stag:
         a("s_mov_b32 %[qcur], %[qc1]")   # the Q cursor follows the shared chunk stream from here on, never reset
         a("s_cmp_eq_u32 %[wtype], 1")
@@ -693,7 +771,10 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
         a("global_store_dword %[e1], %[e3], %[wgbq] offset:4")
         a("s_waitcnt vmcnt(0)")
     a("s_branch .Ldone_%=")
-    out += gen_hit_stubs()
+    if FUSE:   # one set per copy of the tile's last body (.Llast / .Lsingle): a stub returns into its copy
+        out += gen_hit_stubs("c200") + gen_hit_stubs("c300")
+    else:
+        out += gen_hit_stubs()
     out += gen_slow(NW)
     a(".Ldone_%=:")
 
@@ -721,6 +802,9 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
         ops_out.append(f'[u{j}] "=&v"(vu[{j}])')
     for j in range(13):
         ops_out.append(f'[e{j}] "=&v"(ve[{j}])')
+    if FUSE:
+        for n in range(16):
+            ops_out.append(f'[tq{n}] "=&v"(vt[{n}])')
     ops_out += ['[ldr] "=&v"(ldr)'] + (['[sldw] "=&s"(s_sldw)'] if dma else ['[ldw] "=&v"(ldw)'])
     for name in [f"xso{m}" for m in range(MT)] + ["qcur", "cnt", "st0", "tl", "trow", "sn64", "wcnt", "sacc0", "sacc1"]:
         ops_out.append(f'[{name}] "=&s"(s_{name})')
@@ -780,7 +864,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -801,6 +885,12 @@ def main():
     DBG.clear()
     DBG.update({"noread", "nohit"})   # 210: ... with the test's arithmetic but without the accumulator reads (and no hits)
     (Path(args.outdir) / "scan_asm_diag210.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True))
+    DBG.clear()
+    DBG.update({"nohit"})   # 212: the folded pre-test computed, no hit ever taken
+    (Path(args.outdir) / "scan_asm_diag212.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
+    DBG.clear()
+    DBG.update({"noadm"})   # 213: ArchVGPR accumulators, no admission test at all
+    (Path(args.outdir) / "scan_asm_diag213.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
     DBG.clear()
     disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT, DMA, STAG>."]
     for i, (space, nw, r, nt, qd, prio, mt, dma, stag) in enumerate(CONFIGS):
@@ -824,6 +914,9 @@ def main():
     disp.append('#include "scan_asm_diag209.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 210 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_diag210.inc"')
+    for code in (212, 213):
+        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
+        disp.append(f'#include "scan_asm_diag{code}.inc"')
     disp.append("#endif")
     disp.append("} else {")
     disp.append('    static_assert(SPACE < 0, "configuration not generated: add it to CONFIGS in tools/gen_scan_asm.py");')
