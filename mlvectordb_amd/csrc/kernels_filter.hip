@@ -644,6 +644,13 @@ typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
 #include "scan_asm_consts.inc"
 static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagree");
 
+// The QD template slot doubles as a variant code: 2..8 = B-fragment read-ahead of a bf16 body; 1xx = timing diagnostics of
+// the bf16 body; 208..219 = int8 bodies (208 AccVGPR accumulators; 211 ArchVGPR accumulators, cosine: admission folded into the
+// last k-step; 214 / 215 / 216 tuning variants of 211: ring of 6, read-ahead 8, no wave priorities; 209 / 210 / 212 / 213
+// timing diagnostics).
+constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 219; }
+constexpr int scan_code_qd(int qd) { return qd == 215 ? 8 : (qd > 8 ? 4 : qd); }
+
 template <int SPACE, int R, int NW, bool NT, int QD, bool PRIO, int MT, bool DMA, bool STAG>
 __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kernel(const FilterArgs a, const int64_t tile_begin,
                                                                                   const int64_t tile_end) {
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     constexpr int kTileRowsV = NW * kWaveRows;
     constexpr int kQBufs = 2;
     constexpr int kStageCap = MT == 4 ? kAsmStageCapNw4Mt4 : (NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4);  // entries a wave stages in LDS
-    constexpr bool I8 = QD == 208 || QD == 209 || QD == 210 || QD == 211 || QD == 212 || QD == 213;  // int8 shadow (211: accumulators in ArchVGPRs): k-steps of 64 int8 columns, same bytes per step (209: timing diagnostic)
+    constexpr bool I8 = scan_code_i8(QD);  // int8 shadow: k-steps of 64 int8 columns, same bytes per step
     // LDS: [2][32 KiB] Q chunks at offset 0, thr[256], qscale[256], ke[256], [NW waves] staging {u[], row[], q[]}
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* thr_l = reinterpret_cast<float*>(smem + kQBufs * kChunkVec * sizeof(uint4));
@@ -756,7 +763,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     const uint32_t crow = (uint32_t)wave * (uint32_t)kWaveRows + g * 4;
     static_assert(kWgCap == 16384 && sizeof(WgEntry) == 16, "the assembly hard-codes the append buffer geometry");
 
-    u32x4s xring[R * MT], qsa[kQPer], qsb[kQPer], qt[QD > 8 ? 4 : QD];
+    u32x4s xring[R * MT], qsa[kQPer], qsb[kQPer], qt[scan_code_qd(QD)];
     float vr[4 * MT], vp[4 * MT], vu[4 * MT], vs[4 * MT], vt[16];
     (void)vs;
     (void)vt;
@@ -1605,7 +1612,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     info->scatter_grid = grid;  // the caller runs launch_filter_scatter next (outside its timing window)
     info->nw = NW;
     info->dbg = QD == 108 ? 1 : 0;
-    info->i8 = QD != 208 && QD != 209 && QD != 210 && QD != 211 && QD != 212 && QD != 213 ? 0 : (SPACE == kSpaceCosine ? 1 : (SPACE == kSpaceIp ? 2 : 0));  // how the scatter turns stored values into bounds
+    info->i8 = !scan_code_i8(QD) ? 0 : (SPACE == kSpaceCosine ? 1 : (SPACE == kSpaceIp ? 2 : 0));  // how the scatter turns stored values into bounds
     return hipGetLastError();
 }
 
@@ -1640,8 +1647,18 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                     return launch_scan_asm<SPACE, 4, 8, true, 213, true, 2, true>(a, row_begin, row_end, s, info);
             }
 #endif
-            if (env_int("MLVDB_SCAN_VA", 1))  // accumulators in ArchVGPRs: the admission test reads them directly
+            if (env_int("MLVDB_SCAN_VA", 1)) {  // accumulators in ArchVGPRs: the admission test reads them directly
+                if constexpr (SPACE == kSpaceCosine) {  // tuning variants of the folded body
+                    const int var = env_int("MLVDB_SCAN_VAR", 0);
+                    if (var == 214 && (a.ld / 64) % 6 == 0)
+                        return launch_scan_asm<SPACE, 6, 8, true, 214, true, 2, true>(a, row_begin, row_end, s, info);
+                    if (var == 215) return launch_scan_asm<SPACE, 4, 8, true, 215, true, 2, true>(a, row_begin, row_end, s, info);
+                    if (var == 216) return launch_scan_asm<SPACE, 4, 8, true, 216, false, 2, true>(a, row_begin, row_end, s, info);
+                    if (var == 217) return launch_scan_asm<SPACE, 4, 4, true, 217, false, 2, true>(a, row_begin, row_end, s, info);
+                    if (var == 218) return launch_scan_asm<SPACE, 4, 4, true, 218, true, 2, true>(a, row_begin, row_end, s, info);
+                }
                 return launch_scan_asm<SPACE, 4, 8, true, 211, true, 2, true>(a, row_begin, row_end, s, info);
+            }
             if (env_int("MLVDB_SCAN_PRIO", 1))
                 return launch_scan_asm<SPACE, 4, 8, true, 208, true, 2, true>(a, row_begin, row_end, s, info);
             return launch_scan_asm<SPACE, 4, 8, true, 208, false, 2, true>(a, row_begin, row_end, s, info);

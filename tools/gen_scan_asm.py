@@ -864,7 +864,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -886,6 +886,13 @@ def main():
     DBG.update({"noread", "nohit"})   # 210: ... with the test's arithmetic but without the accumulator reads (and no hits)
     (Path(args.outdir) / "scan_asm_diag210.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True))
     DBG.clear()
+    # tuning variants of the folded cosine body (QD slot: 214 ring of 6 k-steps, 215 B fragments read 8 ahead, 216 no wave priorities)
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_r6.inc").write_text(generate("cosine", 6, 4, 8, True, True, 2, True, False, True, True))
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_qd8.inc").write_text(generate("cosine", 4, 8, 8, True, True, 2, True, False, True, True))
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_nopr.inc").write_text(generate("cosine", 4, 4, 8, True, False, 2, True, False, True, True))
+    # 217 / 218: two 4-wave workgroups per CU (independent barriers: one's chunk-boundary bubble under the other's MFMAs)
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_nw4.inc").write_text(generate("cosine", 4, 4, 4, True, False, 2, True, False, True, True))
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_nw4_pr.inc").write_text(generate("cosine", 4, 4, 4, True, True, 2, True, False, True, True))
     DBG.update({"nohit"})   # 212: the folded pre-test computed, no hit ever taken
     (Path(args.outdir) / "scan_asm_diag212.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
     DBG.clear()
@@ -906,6 +913,16 @@ def main():
     for sp, code in SPACES.items():
         disp.append(f"}} else if constexpr (SPACE == {code} && NW == 8 && R == 4 && NT == true && QD == 211 && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
         disp.append(f'#include "scan_asm_{sp}_i8_va.inc"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 6 && NT == true && QD == 214 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
+    disp.append('#include "scan_asm_cosine_i8_va_r6.inc"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 215 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
+    disp.append('#include "scan_asm_cosine_i8_va_qd8.inc"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 216 && PRIO == false && MT == 2 && DMA == true && STAG == false) {")
+    disp.append('#include "scan_asm_cosine_i8_va_nopr.inc"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 4 && R == 4 && NT == true && QD == 217 && PRIO == false && MT == 2 && DMA == true && STAG == false) {")
+    disp.append('#include "scan_asm_cosine_i8_va_nw4.inc"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 4 && R == 4 && NT == true && QD == 218 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
+    disp.append('#include "scan_asm_cosine_i8_va_nw4_pr.inc"')
     disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
     for code in DIAG:
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2 && DMA == false && STAG == false) {{")
