@@ -60,6 +60,7 @@ struct mlvdb_index {
     DevBuf gather_out, gather_lab;     // its private buffers (a search may be running on `stream` from another host thread)
     // workspaces (grow only)
     DevBuf stage, qpad, qaux, partial, qsel, seed_lab, seed_dist, seed_cnt, seed_d64;
+    DevBuf cand_range, rhits, rhit_cnt;  // range passes: larger candidate lists, exact hits, hit counts
     DevBuf row_mask, rn_masked;  // filtered search
     DevBuf qerr, rowerr;         // rounding errors of the bf16 images: per query / maximum over the rows (device scalar)
     // experimental int8 shadow (MLVDB_I8=1, cosine, ld % 256 == 0): built lazily at search time, rebuilt after any mutation
@@ -283,6 +284,7 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     fa.ke8 = h->fmisc.as<float>() + 6 * kFilterQueries;  // 257 floats
     fa.sqmin = h->fmisc.as<uint32_t>() + 7 * kFilterQueries + 128;
     fa.cand = h->cand.as<CandEntry>();
+    fa.cand_cap = kCandCap;
     fa.wgbuf = h->wgbuf.as<WgEntry>();
     fa.wgcnt = h->wgcnt.as<uint32_t>();
     return MLVDB_OK;
@@ -509,9 +511,9 @@ __global__ void range_pack_kernel(const int64_t* lab, const float* dist, const i
 }
 
 __global__ void range_reset_kernel(uint32_t* cnt, const int32_t* qsel) { cnt[qsel[threadIdx.x]] = 0; }
-__global__ void range_resolve_kernel(uint32_t* overflow, const uint32_t* cnt, const int32_t* qsel) {
+__global__ void range_resolve_kernel(uint32_t* overflow, const uint32_t* cnt, const int32_t* qsel, uint32_t cap) {
     const int q = qsel[threadIdx.x];
-    overflow[q] = cnt[q] > (uint32_t)kCandCap ? 1u : 0u;
+    overflow[q] = cnt[q] > cap ? 1u : 0u;
 }
 
 bool use_filter(const mlvdb_index* h, int64_t nq) {
@@ -610,7 +612,7 @@ int mlvdb_index_destroy(mlvdb_index* h) {
     if (h->rn) (void)hipFree(h->rn);
     if (h->Xb) (void)hipFree(h->Xb);
     for (DevBuf* b : {&h->stage, &h->qpad, &h->qaux, &h->partial, &h->qsel, &h->seed_lab, &h->seed_dist, &h->seed_cnt,
-                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->qerr, &h->rowerr, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt, &h->io_d64, &h->gather_out, &h->gather_lab, &h->x8, &h->rp8, &h->rowerr8, &h->qimg8, &h->sq8,
+                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->qerr, &h->rowerr, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt, &h->io_d64, &h->gather_out, &h->gather_lab, &h->cand_range, &h->rhits, &h->rhit_cnt, &h->x8, &h->rp8, &h->rowerr8, &h->qimg8, &h->sq8,
                       &h->counters, &h->labels_in, &h->page_lab, &h->page_dist, &h->page_cnt, &h->page_d64, &h->cur_d,
                       &h->cur_l})
         b->release();
@@ -953,7 +955,27 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
         rc = setup_filter_ws(h, fa, h->qpad.as<float>() + (size_t)q0 * h->ld, h->qaux.as<double>() + q0,
                              h->qerr.as<float>() + q0, n);
         if (rc) return rc;
+        // a range pass keeps its own, larger candidate lists: true hits + the band of the bound, per query anything
+        // from none to tens of thousands
+        HIP_TRY(h, h->cand_range.ensure((size_t)kFilterQueries * kRangeCandCap * sizeof(CandEntry)));
+        HIP_TRY(h, h->rhits.ensure((size_t)kFilterQueries * kCandCap * sizeof(RangeHit)));
+        HIP_TRY(h, h->rhit_cnt.ensure(kFilterQueries * sizeof(uint32_t)));
+        fa.cand = h->cand_range.as<CandEntry>();
+        fa.cand_cap = kRangeCandCap;
+        fa.rhits = h->rhits.as<RangeHit>();
+        fa.rhit_cnt = h->rhit_cnt.as<uint32_t>();
+        // int8 bounds (half the scan time of the bf16 body; MLVDB_RANGE_I8=0 keeps the bf16 one): their band admits
+        // ~8x more candidates than there are hits, which the chunked rescoring below absorbs
+        {
+            const char* env = getenv("MLVDB_RANGE_I8");
+            if (filt && !(env && env[0] == '0')) {
+                rc = attach_i8(h, s, fa);
+                if (rc) return rc;
+            }
+        }
         HIP_TRY(h, launch_filter_prep(fa, s));  // also clears the candidate counters
+        if (fa.X8) HIP_TRY(h, launch_filter_prep8(fa, s));
+        h->stats.bound_dtype = fa.X8 ? 2 : (filt ? 1 : 0);
         rc = scan_event(h, s, true);
         if (rc) return rc;
         if (filt) {
@@ -972,48 +994,44 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
         rc = collect_overflow(h, s, fa, &n_flagged);
         if (rc) return rc;
         if (n_flagged) {
-            // more candidates than list slots: exact hit counts from the exact range scan restricted to those
-            // queries, then their nearest min(count, capacity) hits from the paged exact kNN
+            // more candidates than list slots (or a wave buffer overflowed): the exact range scan restricted to those
+            // queries stores exactly their hits; a list that now fits is complete, larger ones stay flagged
             h->stats.fallback_queries += n_flagged;
             const int32_t* qsel = h->qsel.as<int32_t>();
             range_reset_kernel<<<1, n_flagged, 0, s>>>(fa.cnt, qsel);
             HIP_TRY(h, hipGetLastError());
             HIP_TRY(h, launch_exact_range_scan(fa, radius, qsel, n_flagged, s));
-            HIP_TRY(h, hipMemcpyAsync(h->host_flags, fa.cnt, kFilterQueries * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(h, hipStreamSynchronize(s));
-            // a query whose exact hits fit its list is complete now (the list holds exactly its hits): clear its
-            // flag so that the normal rescoring/sort handles it; only larger result sets are paged
-            int32_t still[kFilterQueries];
-            int32_t n_still = 0;
-            int64_t kmax = 1;
-            for (int q = 0; q < n; ++q) {
-                if (!h->host_overflow[q]) continue;
-                if (h->host_flags[q] > (uint32_t)kCandCap) {
-                    still[n_still++] = q;
-                    kmax = std::max<int64_t>(kmax, std::min<int64_t>(h->host_flags[q], cap_eff));
-                }
-            }
-            range_resolve_kernel<<<1, n_flagged, 0, s>>>(fa.overflow, fa.cnt, qsel);
+            range_resolve_kernel<<<1, n_flagged, 0, s>>>(fa.overflow, fa.cnt, qsel, (uint32_t)fa.cand_cap);
             HIP_TRY(h, hipGetLastError());
-            if (n_still) {
-                HIP_TRY(h, hipMemcpyAsync(h->qsel.p, still, n_still * sizeof(int32_t), hipMemcpyHostToDevice, s));
-                HIP_TRY(h, hipStreamSynchronize(s));  // `still` is on this stack frame
-                HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * kmax * sizeof(int64_t)));
-                HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * kmax * sizeof(float)));
-                HIP_TRY(h, h->seed_cnt.ensure(kFilterQueries * sizeof(int32_t)));
-                rc = run_paged_exact(h, s, fa.Qpad, fa.qaux, kFilterQueries, qsel, n_still, (int32_t)kmax,
-                                     h->seed_lab.as<int64_t>(), h->seed_dist.as<float>(), h->seed_cnt.as<int32_t>(),
-                                     nullptr);
-                if (rc) return rc;
-                range_fallback_commit_kernel<<<n_still, 256, 0, s>>>(qsel, fa.cnt, h->seed_lab.as<int64_t>(),
-                                                                     h->seed_dist.as<float>(), (int32_t)kmax, (int32_t)q0,
-                                                                     cap_eff, h->io_lab.as<int64_t>(),
-                                                                     h->io_dist.as<float>(), h->io_cnt.as<int64_t>());
-                HIP_TRY(h, hipGetLastError());
-            }
         }
+        // exact fp64 distance of every candidate (blocks over query x candidate chunk), then sort + emit per query
         HIP_TRY(h, launch_range_rescore(fa, radius, (int32_t)q0, cap_eff, h->io_lab.as<int64_t>(),
                                         h->io_dist.as<float>(), h->io_cnt.as<int64_t>(), s));
+        // queries with more hits than one block sorts (> kCandCap), or more than a list holds: their nearest
+        // min(count, capacity) hits come from the paged exact kNN; cnt[q] holds the exact count in both cases
+        int32_t n_still = 0;
+        rc = collect_overflow(h, s, fa, &n_still);
+        if (rc) return rc;
+        if (n_still) {
+            const int32_t* qsel = h->qsel.as<int32_t>();
+            HIP_TRY(h, hipMemcpyAsync(h->host_flags, fa.cnt, kFilterQueries * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+            int64_t kmax = 1;
+            for (int q = 0; q < n; ++q)
+                if (h->host_overflow[q]) kmax = std::max<int64_t>(kmax, std::min<int64_t>(h->host_flags[q], cap_eff));
+            if (n_flagged == 0) h->stats.fallback_queries += n_still;
+            HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * kmax * sizeof(int64_t)));
+            HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * kmax * sizeof(float)));
+            HIP_TRY(h, h->seed_cnt.ensure(kFilterQueries * sizeof(int32_t)));
+            rc = run_paged_exact(h, s, fa.Qpad, fa.qaux, kFilterQueries, qsel, n_still, (int32_t)kmax,
+                                 h->seed_lab.as<int64_t>(), h->seed_dist.as<float>(), h->seed_cnt.as<int32_t>(), nullptr);
+            if (rc) return rc;
+            range_fallback_commit_kernel<<<n_still, 256, 0, s>>>(qsel, fa.cnt, h->seed_lab.as<int64_t>(),
+                                                                 h->seed_dist.as<float>(), (int32_t)kmax, (int32_t)q0, cap_eff,
+                                                                 h->io_lab.as<int64_t>(), h->io_dist.as<float>(),
+                                                                 h->io_cnt.as<int64_t>());
+            HIP_TRY(h, hipGetLastError());
+        }
     }
     // copy back.  Hit counts vary by orders of magnitude between queries, so the dense [nq, cap_eff] device
     // arrays are mostly padding: when the hits are a small part of them, pack the rows' valid prefixes on the

@@ -97,7 +97,10 @@ hipError_t launch_exact_merge(const TopEntry* partial, int32_t nq_sel, const int
 // ---------------------------------------------------------------- filter path (kernels_filter.hip)
 constexpr int kFilterQueries = 256;   // queries per filter pass
 constexpr int kFilterChunkK = 64;     // columns per Q chunk staged in LDS
-constexpr int kCandCap = 8192;        // candidate slots per query
+constexpr int kCandCap = 8192;        // candidate slots per query (kNN passes; also the most range hits sorted in LDS)
+constexpr int kRangeCandCap = 65536;  // candidate slots per query of a range pass: true hits + the bound's band
+constexpr int kRangeChunk = 256;      // candidates one block of the range rescoring scores (4 gather steps: the gathers are
+                                      // latency-bound, so a long list is spread over many resident blocks rather than looped over)
 constexpr int kFilterTile = 768;      // scan ranges start on multiples of it (common multiple of the kernels' 192/128/256-row tiles)
 constexpr int kScanMaxGrid = 512;     // most workgroups any scan launch uses
 constexpr int kWgCap = 16384;         // append slots per workgroup and launch (assembly scan: split evenly over its waves)
@@ -105,6 +108,12 @@ constexpr int kWgCap = 16384;         // append slots per workgroup and launch (
 struct CandEntry {
     float u;      // upper bound of the row's score (higher = nearer)
     int32_t row;
+};
+
+struct RangeHit {
+    double d;
+    int32_t l;
+    int32_t pad;
 };
 
 // What a workgroup of the assembly scan appends to its private buffer; the scatter kernel then moves
@@ -138,7 +147,10 @@ struct FilterArgs {
     float* ke;              // [256] per-query error term of the bound: cosine E1q + 2 slack, ip / l2 E1q + slack (x |x|)
     uint32_t* cnt;          // [256] candidates appended
     uint32_t* overflow;     // [256] nonzero = list overflowed, query must be re-run exactly
-    CandEntry* cand;        // [256][kCandCap]
+    CandEntry* cand;        // [256][cand_cap]
+    int32_t cand_cap;       // kCandCap (kNN passes) or kRangeCandCap (range passes: their own, larger lists)
+    struct RangeHit* rhits; // range passes: [256][kCandCap] exact hits (fp64 distance, row) found by range_score_kernel
+    uint32_t* rhit_cnt;     // [256] exact hit count per query (may exceed kCandCap: the excess is counted, not stored)
     // int8 shadow (cosine, ld % 256 == 0; MLVDB_I8=0 disables): all null / unused otherwise
     const void* X8;         // int8 rows, per-row scale: panels of 16 rows, 64-column groups of 1 KiB (layout_offset_i8)
     const float* rp8;       // [rows][2] cosine {scale/(|x|+1e-30), row error}, l2 / ip {scale, |x|}; NaN = tombstoned

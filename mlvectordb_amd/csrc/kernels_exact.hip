@@ -211,11 +211,11 @@ __global__ __launch_bounds__(512) void exact_range_kernel(const FilterArgs a, co
                 const double dist = finish_distance<SPACE>(acc[p][t], nx[p], qinv[t]);
                 if (live && qid[t] >= 0 && dist <= radius) {
                     const uint32_t slot = atomicAdd(&a.cnt[qid[t]], 1u);
-                    if (slot < (uint32_t)kCandCap) {
+                    if (slot < (uint32_t)a.cand_cap) {
                         CandEntry e;
                         e.u = 0.f;
                         e.row = (int32_t)row;
-                        a.cand[(int64_t)qid[t] * kCandCap + slot] = e;
+                        a.cand[(int64_t)qid[t] * a.cand_cap + slot] = e;
                     } else {
                         a.overflow[qid[t]] = 1u;
                     }

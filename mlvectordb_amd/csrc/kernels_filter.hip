@@ -101,6 +101,10 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const FilterArgs a) {
         a.thr[q] = q < a.nq ? -3.0e38f : 3.4e38f;  // padded queries never admit anything
         a.cnt[q] = 0;
         a.overflow[q] = 0;
+        if (q == 0 && a.sqmin) {  // what filter_prep8_kernel's atomicMin / atomicMax start from (it runs after this kernel)
+            a.sqmin[0] = 0x7f7f7f7fu;  // 3.39e38: above every query scale
+            a.sqmin[1] = 0u;           // largest query error so far
+        }
     }
 }
 
@@ -235,7 +239,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
                 for (int i = 0; i < 4; ++i) mask |= bound(m, i, n, sq, ke) >= thr ? 1u << (4 * m + i) : 0u;
             if (mask) slot = atomicAdd(&a.cnt[16 * n + c16], (uint32_t)__popc(mask));
         }
-        packed[n] = mask | (min(slot, (uint32_t)kCandCap) << 12);
+        packed[n] = mask | (min(slot, (uint32_t)a.cand_cap) << 12);
     }
     // pass 2 (rare): write the admitted (bound, row) pairs into the reserved slots
 #pragma unroll
@@ -253,11 +257,11 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
             while (mask) {
                 const int j = __builtin_ctz(mask);
                 mask &= mask - 1;
-                if (slot < (uint32_t)kCandCap) {
+                if (slot < (uint32_t)a.cand_cap) {
                     CandEntry e;
                     e.u = dump[j * 64];
                     e.row = row0 + 16 * (j >> 2) + (j & 3);
-                    a.cand[(int64_t)q * kCandCap + slot] = e;
+                    a.cand[(int64_t)q * a.cand_cap + slot] = e;
                 } else {
                     a.overflow[q] = 1u;
                 }
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(256) void filter_scatter_kernel(const FilterArgs a,
     {
         const uint32_t c = hist[threadIdx.x];
         base[threadIdx.x] = c ? atomicAdd(&a.cnt[threadIdx.x], c) : 0u;
-        if (c && base[threadIdx.x] + c > (uint32_t)kCandCap) a.overflow[threadIdx.x] = 1u;
+        if (c && base[threadIdx.x] + c > (uint32_t)a.cand_cap) a.overflow[threadIdx.x] = 1u;
         hist[threadIdx.x] = 0;
     }
     __syncthreads();
@@ -622,12 +626,12 @@ __global__ __launch_bounds__(256) void filter_scatter_kernel(const FilterArgs a,
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
             const uint32_t q = bq[i];
             const uint32_t slot = base[q] + atomicAdd(&hist[q], 1u);
-            if (slot < (uint32_t)kCandCap) {
+            if (slot < (uint32_t)a.cand_cap) {
                 CandEntry e;
                 // int8 scan: the stored value is in units of the query's scale (cosine: w, ip: w + ke' |x|)
                 e.u = i8 == 1 ? __builtin_fmaf(bu[i], a.sq8[q], a.ke8[q]) : (i8 == 2 ? bu[i] * a.sq8[q] : bu[i]);
                 e.row = br[i];
-                a.cand[(size_t)q * kCandCap + slot] = e;
+                a.cand[(size_t)q * a.cand_cap + slot] = e;
             }
         }
     }
@@ -650,6 +654,10 @@ static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagre
 // timing diagnostics).
 constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 219; }
 constexpr int scan_code_qd(int qd) { return qd == 215 ? 8 : (qd > 8 ? 4 : qd); }
+constexpr int scan_code_qbufs(int qd) { return qd == 219 ? 4 : 2; }  // 219: four Q chunk buffers, one barrier per two chunks
+constexpr int scan_code_stage_cap(int qd, int nw, int mt) {
+    return qd == 219 ? kAsmStageCapNw8Q4 : (mt == 4 ? kAsmStageCapNw4Mt4 : (nw == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4));
+}
 
 template <int SPACE, int R, int NW, bool NT, int QD, bool PRIO, int MT, bool DMA, bool STAG>
 __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kernel(const FilterArgs a, const int64_t tile_begin,
@@ -658,8 +666,8 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     constexpr int kQPer = 1024 / kThreads;  // uint4 of a Q half-chunk moved per thread
     constexpr int kWaveRows = 16 * MT;  // MT = 2: two waves per SIMD; MT = 4: one, 64 rows each
     constexpr int kTileRowsV = NW * kWaveRows;
-    constexpr int kQBufs = 2;
-    constexpr int kStageCap = MT == 4 ? kAsmStageCapNw4Mt4 : (NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4);  // entries a wave stages in LDS
+    constexpr int kQBufs = scan_code_qbufs(QD);
+    constexpr int kStageCap = scan_code_stage_cap(QD, NW, MT);  // entries a wave stages in LDS
     constexpr bool I8 = scan_code_i8(QD);  // int8 shadow: k-steps of 64 int8 columns, same bytes per step
     // LDS: [2][32 KiB] Q chunks at offset 0, thr[256], qscale[256], ke[256], [NW waves] staging {u[], row[], q[]}
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -943,7 +951,7 @@ __global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const Filter
 // ------------------------------------------------------------------ exact rescoring
 // One block per query: the surviving rows are scored by the exact-scan arithmetic
 // (accumulate_rows, 16 gathered rows per wave step) and ranked (distance, label).
-constexpr int kRescoreWaves = 8;
+constexpr int kRescoreWaves = 16;  // 256 candidates per gather step: the usual list (~130 on int8 bounds) is one step
 constexpr int kRescoreRankMax = 2048;  // lists up to this length are ranked by counting in LDS
 template <int SPACE>
 __global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_kernel(const FilterArgs a, const int32_t k, const int32_t q0,
@@ -1047,25 +1055,28 @@ __global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_kernel(cons
     }
 }
 
-// Range variant: exact distance of every candidate, keep dist <= radius, bitonic sort by
-// (distance, label) in LDS, emit the nearest `capacity`.
-struct RangeHit {
-    double d;
-    int32_t l;
-    int32_t pad;
-};
-
+// Range variant, two kernels.  A range pass can hold tens of thousands of candidates for one query and a handful for
+// the next (hit counts vary ~1000x with |q| on unnormalised data), so the exact rescoring is spread over
+// (query, chunk of kRangeChunk candidates) blocks instead of one block per query:
+//   range_score_kernel  exact fp64 distance of every candidate of its chunk; the hits (dist <= radius, live) are
+//                       collected in LDS and copied to the query's hit array behind one atomic reservation;
+//   range_sort_kernel   one block per query: bitonic sort of its hits by (distance, label) in LDS, emit the nearest
+//                       `capacity`, publish the exact count.  More than kCandCap hits: flagged, served by the paged
+//                       exact kNN (api.hip).
 template <int SPACE>
-__global__ __launch_bounds__(256) void range_rescore_kernel(const FilterArgs a, const float radius, const int32_t q0,
-                                                            const int64_t capacity, int64_t* out_labels,
-                                                            float* out_dist, int64_t* out_counts) {
+__global__ __launch_bounds__(256) void range_score_kernel(const FilterArgs a, const float radius) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    RangeHit* hits = reinterpret_cast<RangeHit*>(smem);                               // [kCandCap]
-    double* qs = reinterpret_cast<double*>(smem + (size_t)kCandCap * sizeof(RangeHit));  // [ld]
-    const int ld = a.ld;
-    uint32_t& s_n = *reinterpret_cast<uint32_t*>(qs + ld);
+    double* qs = reinterpret_cast<double*>(smem);                                  // [ld]
+    RangeHit* found = reinterpret_cast<RangeHit*>(qs + a.ld);                      // [kRangeChunk]
+    uint32_t& s_n = *reinterpret_cast<uint32_t*>(found + kRangeChunk);
+    uint32_t& s_base = *(&s_n + 1);
     const int q = blockIdx.x;
     if (q >= a.nq || a.overflow[q]) return;
+    const uint32_t cnt = min(a.cnt[q], (uint32_t)a.cand_cap);
+    const uint32_t begin = blockIdx.y * (uint32_t)kRangeChunk;
+    if (begin >= cnt) return;
+    const uint32_t end = min(cnt, begin + (uint32_t)kRangeChunk);
+    const int ld = a.ld;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, r = lane & 15;
     for (int c = threadIdx.x; c < ld; c += 256) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
@@ -1073,15 +1084,14 @@ __global__ __launch_bounds__(256) void range_rescore_kernel(const FilterArgs a, 
     __syncthreads();
     const double qinv = a.qaux[q];
     const double rad = (double)radius;
-    const uint32_t cnt = min(a.cnt[q], (uint32_t)kCandCap);
-    const CandEntry* list = a.cand + (int64_t)q * kCandCap;
-    for (uint32_t i0 = wave * 16; i0 < cnt; i0 += 64) {
+    const CandEntry* list = a.cand + (int64_t)q * a.cand_cap;
+    for (uint32_t i0 = begin + wave * 16; i0 < end; i0 += 64) {
         const uint32_t idx = i0 + r;
-        const bool have = idx < cnt;
+        const bool have = idx < end;
         const int32_t row = have ? list[idx].row : 0;
         const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 16 + g * 4};
         double acc[1][1], nx[1];
-        accumulate_rows<SPACE, 1, 1, 4>(base, qs, ld, g, acc, nx);
+        accumulate_rows<SPACE, 1, 1, 8>(base, qs, ld, g, acc, nx);
         const double dist = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
         bool hit = have && lane < 16 && dist <= rad;
         if (hit) {
@@ -1090,17 +1100,46 @@ __global__ __launch_bounds__(256) void range_rescore_kernel(const FilterArgs a, 
         }
         if (hit) {
             const uint32_t slot = atomicAdd(&s_n, 1u);
-            hits[slot].d = dist;
-            hits[slot].l = row;
+            found[slot].d = dist;
+            found[slot].l = row;
         }
     }
     __syncthreads();
     const uint32_t n = s_n;
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&a.rhit_cnt[q], n);
+    __syncthreads();
+    const uint32_t base = s_base;
+    RangeHit* out = a.rhits + (int64_t)q * kCandCap;
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
+        if (base + i < (uint32_t)kCandCap) out[base + i] = found[i];  // beyond: counted only (the query is paged exactly)
+}
+
+__global__ __launch_bounds__(256) void range_sort_kernel(const FilterArgs a, const int32_t q0, const int64_t capacity,
+                                                         int64_t* out_labels, float* out_dist, int64_t* out_counts) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    RangeHit* hits = reinterpret_cast<RangeHit*>(smem);  // [np2 <= kCandCap]
+    const int q = blockIdx.x;
+    if (q >= a.nq || a.overflow[q]) return;
+    const uint32_t total = a.rhit_cnt[q];
+    if (total > (uint32_t)kCandCap) {  // more hits than one block sorts: the exact count is known, the hits come from the
+        if (threadIdx.x == 0) {        // paged exact kNN (api.hip reads the flag after the kernel; cnt = the exact count)
+            a.overflow[q] = 2u;
+            a.cnt[q] = total;
+            out_counts[q0 + q] = total;
+        }
+        return;
+    }
+    const uint32_t n = total;
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
-    for (uint32_t i = n + threadIdx.x; i < np2; i += 256) {
-        hits[i].d = __builtin_inf();
-        hits[i].l = kNoLabel;
+    const RangeHit* src = a.rhits + (int64_t)q * kCandCap;
+    for (uint32_t i = threadIdx.x; i < np2; i += 256) {
+        RangeHit h;
+        h.d = __builtin_inf();
+        h.l = kNoLabel;
+        h.pad = 0;
+        hits[i] = i < n ? src[i] : h;
     }
     __syncthreads();
     for (uint32_t size = 2; size <= np2; size <<= 1) {
@@ -1356,9 +1395,7 @@ __global__ __launch_bounds__(256) void filter_prep8_fin_kernel(const FilterArgs 
 }
 
 hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(a.sqmin, 0x7f, sizeof(unsigned int), s);  // 3.39e38: above every scale
-    if (e == hipSuccess) e = hipMemsetAsync(a.sqmin + 1, 0, sizeof(unsigned int), s);  // largest query error so far
-    if (e != hipSuccess) return e;
+    // a.sqmin[0..1] were initialised by filter_prep_kernel (always launched first: launch_filter_prep)
     filter_prep8_kernel<<<kFilterQueries, 256, 0, s>>>(a);
     filter_prep8_fin_kernel<<<1, kFilterQueries, 0, s>>>(a);
     return hipGetLastError();
@@ -1599,8 +1636,8 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     const int64_t tile_begin = row_begin / tile_rows;
     const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
     if (tile_end <= tile_begin) return hipSuccess;
-    const size_t lds = 2 * kChunkVec * sizeof(uint4) + 3 * kFilterQueries * sizeof(float) +
-                       (size_t)NW * 12 * (MT == 4 ? kAsmStageCapNw4Mt4 : (NW == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4));
+    const size_t lds = scan_code_qbufs(QD) * kChunkVec * sizeof(uint4) + 3 * kFilterQueries * sizeof(float) +
+                       (size_t)NW * 12 * scan_code_stage_cap(QD, NW, MT);
     const int64_t ntiles = tile_end - tile_begin;
     const int max_grid = 256 * ((16 / MT) / NW);  // two waves per SIMD on every CU (<= kScanMaxGrid)  // two waves per SIMD on every CU
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
@@ -1654,6 +1691,7 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                         return launch_scan_asm<SPACE, 6, 8, true, 214, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 215) return launch_scan_asm<SPACE, 4, 8, true, 215, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 216) return launch_scan_asm<SPACE, 4, 8, true, 216, false, 2, true>(a, row_begin, row_end, s, info);
+                    if (var == 219) return launch_scan_asm<SPACE, 4, 8, true, 219, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 217) return launch_scan_asm<SPACE, 4, 4, true, 217, false, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 218) return launch_scan_asm<SPACE, 4, 4, true, 218, true, 2, true>(a, row_begin, row_end, s, info);
                 }
@@ -1798,14 +1836,18 @@ hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int
 
 hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, int64_t capacity, int64_t* out_labels,
                                 float* out_dist, int64_t* out_counts, hipStream_t s) {
-    const size_t lds = (size_t)kCandCap * sizeof(RangeHit) + (size_t)a.ld * sizeof(double) + 16;
-    hipError_t e = hipSuccess;
+    const size_t lds_score = (size_t)a.ld * sizeof(double) + (size_t)kRangeChunk * sizeof(RangeHit) + 16;
+    const size_t lds_sort = (size_t)kCandCap * sizeof(RangeHit);
+    const dim3 grid((unsigned)a.nq, (unsigned)((a.cand_cap + kRangeChunk - 1) / kRangeChunk));
+    hipError_t e = hipMemsetAsync(a.rhit_cnt, 0, kFilterQueries * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
 #define MLVDB_LAUNCH_RANGE(SP)                                                                                        \
     do {                                                                                                              \
-        auto kern = range_rescore_kernel<SP>;                                                                         \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                                (int)lds);                                                                            \
-        if (e == hipSuccess) kern<<<a.nq, 256, lds, s>>>(a, radius, q0, capacity, out_labels, out_dist, out_counts);  \
+        auto kern = range_score_kernel<SP>;                                                                           \
+        if (lds_score > 48 * 1024)                                                                                    \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                    (int)lds_score);                                                                  \
+        if (e == hipSuccess) kern<<<grid, 256, lds_score, s>>>(a, radius);                                            \
     } while (0)
     switch (a.space) {
         case kSpaceL2: MLVDB_LAUNCH_RANGE(kSpaceL2); break;
@@ -1814,6 +1856,11 @@ hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, i
     }
 #undef MLVDB_LAUNCH_RANGE
     if (e != hipSuccess) return e;
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(range_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_sort);
+    if (e != hipSuccess) return e;
+    range_sort_kernel<<<a.nq, 256, lds_sort, s>>>(a, q0, capacity, out_labels, out_dist, out_counts);
     return hipGetLastError();
 }
 

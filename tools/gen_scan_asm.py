@@ -52,6 +52,7 @@ I8 = False     # generate(): int8 shadow -- v_mfma_i32_16x16x64_i8, k-steps of 6
 STAG = False   # generate(): the later-dispatched half of the waves runs half a tile behind (see generate)
 VA = False     # generate(): accumulators in ArchVGPRs v[VA_BASE : VA_BASE + 64*MT), ring and B fragments in AccVGPRs (see generate)
 VA_BASE = 64   # v0..v63 stay with the compiler (the statement's "v" operands)
+Q4 = False     # generate(): four Q chunk buffers in LDS, chunk c+2 staged during chunk c, ONE barrier per two chunks
 FUSE = False   # generate(): the admission test is folded into the tile's last k-step (cosine, VA; see gen_pretest)
 DBG = set()   # timing diagnostics only (wrong results): 'nolds' drops the B-fragment reads, 'nox' the X refills
 
@@ -181,14 +182,20 @@ def gen_rowmax(s, part):
                 a(f"v_max_f32 {dst}, {dst}, %[{src}{NR - 1}]")
 
 
-def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=False, final=False):
+def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=False, final=False, sync=True):
     """One 64-column chunk = 2 k-steps = 32 fragments x MT MFMAs.  final: the tile's last chunk, whose second k-step
     carries the admission pre-tests (FUSE)."""
-    s.emit("v_xor_b32 %[ldr], 0x8000, %[ldr]")
-    if dma:
-        s.emit("s_xor_b32 %[sldw], %[sldw], 0x8000")
+    if Q4:   # buffers 0..3 in rotation: this chunk reads the next one, its DMAs fill the one after the next
+        s.emit("v_add_u32 %[ldr], 0x8000, %[ldr]")
+        s.emit("v_and_b32 %[ldr], 0x1ffff, %[ldr]")
+        s.emit("s_add_u32 %[sldw], %[sldw], 0x8000")
+        s.emit("s_and_b32 %[sldw], %[sldw], 0x1ffff")
     else:
-        s.emit("v_xor_b32 %[ldw], 0x8000, %[ldw]")
+        s.emit("v_xor_b32 %[ldr], 0x8000, %[ldr]")
+        if dma:
+            s.emit("s_xor_b32 %[sldw], %[sldw], 0x8000")
+        else:
+            s.emit("v_xor_b32 %[ldw], 0x8000, %[ldw]")
 
     def read(f):
         h, n = f >> 4, f & 15
@@ -312,7 +319,12 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
     s.emit("s_add_u32 %[qcur], %[qcur], 0x8000")
     s.emit("s_cmp_eq_u32 %[qcur], %[qbytes]")
     s.emit("s_cselect_b32 %[qcur], 0, %[qcur]")
-    if dma:   # this wave's share of the next chunk has landed in LDS
+    if not sync:
+        # Q4: no barrier after the first chunk of a pair.  The chunk read next was published by the previous barrier
+        # (every wave waited for its share of it there), and the buffer this wave's DMAs are filling was last read two
+        # chunks ago, before that same barrier.
+        return
+    if dma:   # this wave's share of the chunk(s) staged since the last barrier has landed in LDS
         s.need_vm(*[(sn, i) for sn in ("qb", "qa") for i in range(KQ)])
     s.drain_lg()
     if "stamp" in DBG:   # cycles parked at the barrier, summed in an SGPR (timing diagnostic)
@@ -357,7 +369,8 @@ def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False, dma=False):
             s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{off}" if off else ""),
                    ("rn", j))
     for ch in range(R // 2):
-        gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last, nt, prio, dma, FUSE and last and ch == R // 2 - 1)
+        gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last, nt, prio, dma, FUSE and last and ch == R // 2 - 1,
+                  sync=not Q4 or ch % 2 == 1)
     if last:
         s.need_vm(*[("rn", j) for j in range(4 * MT)])
 
@@ -511,10 +524,11 @@ def gen_hit_stubs(copy=""):
     return out
 
 
-def lds_stage_cap(NW, mt=2):
+def lds_stage_cap(NW, mt=2, qbufs=None):
     """Entries of a wave's staging area in LDS (12 B each, SoA): what is left of the 160 KiB per CU."""
+    qbufs = qbufs or (4 if Q4 else 2)
     wgs_per_cu = (16 // mt) // NW      # mt = 2: two waves per SIMD, mt = 4: one
-    per_wg = (160 * 1024) // wgs_per_cu - (2 * CHUNK_BYTES + 3072)   # Q buffers + thr[256], qscale[256], ke[256]
+    per_wg = (160 * 1024) // wgs_per_cu - (qbufs * CHUNK_BYTES + 3072)   # Q buffers + thr[256], qscale[256], ke[256]
     return min(WG_CAP // NW, (per_wg // NW) // 12 // 8 * 8)
 
 
@@ -605,7 +619,7 @@ def gen_flush(NW):
             "s_waitcnt vmcnt(0)"]
 
 
-def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False):
+def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False, q4=False):
     """stag: both waves of a SIMD reach the admission test (VALU only) together and leave the MFMA pipe idle for it.
     With the stagger the later-dispatched half of a workgroup's waves (wtype 1) runs half a tile behind: it sits out
     the first nkc/2 chunk periods (staging only), starts every row tile at column ld/2 (k origin rotated by xrot,
@@ -625,8 +639,13 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     # descriptor becomes 192 ArchVGPRs + 48 AccVGPRs (accum_offset 192) instead of hipcc's 128 / 128 split.
     VA = va
     assert not va or (i8 and mt == 2 and dma and not stag)
-    global FUSE
+    global FUSE, Q4
     FUSE = va and space == "cosine" and "noadm" not in DBG
+    # q4: four 32 KiB Q buffers (128 KiB), chunk c + 2 is staged while chunk c is consumed, and the workgroup meets at
+    # ONE barrier per two chunks (after the odd ones) instead of one per chunk: half the parking, half the refills of
+    # the software pipeline.  Needs the DMA staging and a ring of 4 k-steps (one loop body = one pair of chunks).
+    Q4 = q4
+    assert not q4 or (dma and R == 4 and not stag)
     assert R in (2, 4, 6) and 2 <= QD <= 8 and mt in (2, 4)
     assert not stag or (dma and mt == 2 and R * 1024 <= 4096)
     KQ = 1024 // (NW * 64)
@@ -651,7 +670,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
         a("s_memtime s[78:79]")
         a("s_waitcnt lgkmcnt(0)")
         a("s_mov_b32 %[sacc1], s78")
-    a("v_add_u32 %[ldr], 0x8000, %[lane16]")   # the first chunk toggles it to buffer 0
+    a("v_add_u32 %[ldr], 0x18000, %[lane16]" if q4 else "v_add_u32 %[ldr], 0x8000, %[lane16]")   # the first chunk moves it to buffer 0
     if not dma:
         a("v_mov_b32 %[ldw], %[qvoff]")        # ... and this one to buffer 1
     # ---- prologue: Q chunk 0 -> LDS buffer 0, chunk 1 -> the sets (register staging only), k-steps 0..R-1 -> the ring
@@ -662,6 +681,12 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
             a(f"s_add_u32 m0, %[sldw], 0x{const:x}")
             a(f"s_movk_i32 %[st0], 0x{const:x}")
             a("buffer_load_dwordx4 %[qvoff], %[qsrd], %[st0] offen lds")
+        if q4:   # chunk 1 -> buffer 1 as well; the first chunk then moves the write base to buffer 2
+            a("s_add_u32 %[sldw], %[sldw], 0x8000")
+            for const, setname, i in pieces:
+                a(f"s_add_u32 m0, %[sldw], 0x{const:x}")
+                a(f"s_add_u32 %[st0], %[qc1], 0x{const:x}")
+                a("buffer_load_dwordx4 %[qvoff], %[qsrd], %[st0] offen lds")
     else:
         for const, setname, i in pieces:
             a(f"s_movk_i32 %[st0], 0x{const:x}")
@@ -714,7 +739,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     a("s_add_u32 s84, s80, %[st0]")
     a("s_addc_u32 s85, s81, %[cnt]")
     if not stag:
-        a("s_mov_b32 %[qcur], %[qc1]" if dma else "s_mov_b32 %[qcur], %[qcur0]")   # first chunk staged inside this tile's loop
+        a("s_mov_b32 %[qcur], %[qc1]" if dma and not q4 else "s_mov_b32 %[qcur], %[qcur0]")   # first chunk staged inside this tile's loop
     a(f"s_add_u32 %[xso0], %[xrot], 0x{R * 1024:x}" if stag else f"s_movk_i32 %[xso0], 0x{R * 1024:x}")
     a("s_add_u32 %[xso1], %[pb], %[xso0]")
     for m in range(2, MT):
@@ -864,7 +889,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -893,6 +918,8 @@ def main():
     # 217 / 218: two 4-wave workgroups per CU (independent barriers: one's chunk-boundary bubble under the other's MFMAs)
     (Path(args.outdir) / "scan_asm_cosine_i8_va_nw4.inc").write_text(generate("cosine", 4, 4, 4, True, False, 2, True, False, True, True))
     (Path(args.outdir) / "scan_asm_cosine_i8_va_nw4_pr.inc").write_text(generate("cosine", 4, 4, 4, True, True, 2, True, False, True, True))
+    # 219: four Q buffers, one barrier per two chunks
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_q4.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, True))
     DBG.update({"nohit"})   # 212: the folded pre-test computed, no hit ever taken
     (Path(args.outdir) / "scan_asm_diag212.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
     DBG.clear()
@@ -923,6 +950,8 @@ def main():
     disp.append('#include "scan_asm_cosine_i8_va_nw4.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 4 && R == 4 && NT == true && QD == 218 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_cosine_i8_va_nw4_pr.inc"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 219 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
+    disp.append('#include "scan_asm_cosine_i8_va_q4.inc"')
     disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
     for code in DIAG:
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2 && DMA == false && STAG == false) {{")
@@ -942,9 +971,10 @@ def main():
     (Path(args.outdir) / "scan_asm_consts.inc").write_text(
         "// GENERATED by tools/gen_scan_asm.py -- do not edit.\n"
         f"constexpr int kAsmWgCap = {WG_CAP};\n"
-        f"constexpr int kAsmStageCapNw4 = {lds_stage_cap(4)};  // entries per wave staged in LDS\n"
-        f"constexpr int kAsmStageCapNw8 = {lds_stage_cap(8)};\n"
-        f"constexpr int kAsmStageCapNw4Mt4 = {lds_stage_cap(4, 4)};  // one wave per SIMD, 64 rows per wave\n")
+        f"constexpr int kAsmStageCapNw4 = {lds_stage_cap(4, 2, 2)};  // entries per wave staged in LDS\n"
+        f"constexpr int kAsmStageCapNw8 = {lds_stage_cap(8, 2, 2)};\n"
+        f"constexpr int kAsmStageCapNw4Mt4 = {lds_stage_cap(4, 4, 2)};  // one wave per SIMD, 64 rows per wave\n"
+        f"constexpr int kAsmStageCapNw8Q4 = {lds_stage_cap(8, 2, 4)};  // four Q buffers (QD slot 219)\n")
     print("wrote", len(names), "files to", args.outdir)
 
 

@@ -3,7 +3,19 @@
 HBM bytes per launch of the filter scan kernel, with the gfx950 FETCH_SIZE x2 correction
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section).  Takes the three largest-grid launches' pattern of one wave:
 the counters of the LAST complete wave (three consecutive launches of filter_scan_asm_kernel) are reported."""
-import csv, json, sys
+import csv, hashlib, json, sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def kernel_source_sha16():
+    """Same hash as bench.py: ties the measurement to the kernel sources it was taken on (a stale file is ignored)."""
+    h = hashlib.sha256()
+    for rel in ("mlvectordb_amd/csrc/kernels_filter.hip", "mlvectordb_amd/csrc/scan_common.h", "tools/gen_scan_asm.py"):
+        h.update((ROOT / rel).read_bytes())
+    return h.hexdigest()[:16]
+
 
 def launches(path, counter):
     out = []
@@ -21,6 +33,7 @@ f3, w3 = [v for _, v, _ in fetch[-per_wave:]], [v for _, v, _ in write[-per_wave
 fetch_bytes = 2.0 * 1024.0 * sum(f3)   # counter unit KB; x2: gfx950 reports half of a wide coalesced stream
 write_bytes = 1024.0 * sum(w3)
 print(json.dumps({
+    "kernel_source_sha16": kernel_source_sha16(),
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras, MI355X (tools/pmc_traffic.py)",
     "kernel": fetch[-1][2] + ": the launches of one 256-query wave over 10M x 768",
     "FETCH_SIZE_KB_per_launch": f3, "WRITE_SIZE_KB_per_launch": w3,
