@@ -509,11 +509,19 @@ def main() -> None:
                         lat.append(time.perf_counter() - ts)
                         scan2 += e2.last_stats()["scan_ms"]
                 ids[strat] = lab[:1].cpu().numpy().copy()
+                lat_io = []  # SURVEY 8d's latency: host-pointer entry, H2D of the query and D2H of the result included
+                for i in range(60):
+                    ts = time.perf_counter()
+                    e2.search(q_host[:1], k)
+                    if i >= 10:
+                        lat_io.append(time.perf_counter() - ts)
+                e2.last_stats()
                 p50 = float(np.median(lat))
                 alg = 1_000_000 * (d * 4 + 4)
                 side[strat] = {
                     "strategy_used": {1: "exact", 2: "filter"}.get(e2.last_stats()["strategy_used"], "?"),
                     "qps": round(1.0 / p50, 1), "p50_ms": round(p50 * 1e3, 4),
+                    "p50_ms_host_io": round(float(np.median(lat_io)) * 1e3, 4),
                     "scan_kernels_ms": round(scan2 / len(lat), 4),
                     "hbm_frac_p50_alg_bytes": round(alg / p50 / 1e9 / HBM_PEAK_GBS, 4),
                     "hbm_frac_scan_kernels_alg_bytes": round(alg / (scan2 / len(lat) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
