@@ -589,7 +589,16 @@ def gen_slow(NW):
 
 
 def gen_flush(NW):
-    """Kernel end: the wave's staged entries go to its global buffer, its count to wgcnt."""
+    """Kernel end.  The entries a wave staged in LDS are moved into the per-query candidate lists by the C++ tail of
+    filter_scan_asm_kernel (the workgroup's own scatter: LDS histogram, one device atomic per query it has entries
+    for) -- no separate scatter launch, no round trip of the entries through global memory.  The assembly only has to
+    make sure everything it issued has landed; the wave's entry count leaves through the wcnt operand."""
+    return ["s_waitcnt vmcnt(0) lgkmcnt(0)"]   # ring / Q sets still in flight that nobody consumes; staged entries landed
+
+
+def gen_flush_to_global(NW):
+    """(Superseded by the in-kernel scatter; kept for reference.)  The wave's staged entries go to its global buffer,
+    its count to wgcnt."""
     lcw = lds_stage_cap(NW, MT)
     return ["s_waitcnt vmcnt(0) lgkmcnt(0)",   # ring / Q sets still in flight that nobody consumes; staged entries landed
             f"s_min_u32 %[st0], %[wcnt], 0x{lcw:x}",
