@@ -404,6 +404,14 @@ class Index:
         ns = self._ns[namespace]
         return ns.engine.get_rows_at(np.asarray(labels, dtype=np.int64))
 
+    def fetch_values_by_id(self, namespace: str, ids: Sequence[UUID]) -> np.ndarray:
+        """``fetch_values`` addressed by id (every id must be live in the namespace)."""
+        ns = self._ns[namespace]
+        labels = ns.ids.lookup(ids)
+        if (labels < 0).any():
+            raise RuntimeError("fetch_values_by_id: unknown or removed id")
+        return ns.engine.get_rows_at(labels)
+
     # ------------------------------------------------------------------ additive: persistence
     # Directory layout ("mlvdb-index-v1"): index.json + per namespace i
     #   ns<i>.rows.f32     raw row-major float32 [total, dim], every label incl. tombstoned ones (labels stay stable)

@@ -144,7 +144,13 @@ class QueryProcessor:
                        metric: str = "cosine", max_results: int = 1024) -> List[dict]:
         """Range query (no reference counterpart; README.md:30-41 intent only)."""
         hits = self._index.range_search(query, radius, namespace=namespace, metric=metric, max_results=max_results)
-        return self._enrich(hits, namespace)
+        out = self._enrich(hits, namespace)
+        missing = [i for i, h in enumerate(out) if h["values"] is None]  # array storage that keeps the rows in HBM only
+        if missing and hasattr(self._index, "fetch_values_by_id"):
+            rows = self._index.fetch_values_by_id(namespace, [out[i]["id"] for i in missing])
+            for i, r in zip(missing, rows):
+                out[i]["values"] = r
+        return out
 
     # ---- delete -> lazy rebuild (query_processor.py:51-62)
     def delete(self, ids: Sequence[UUID], namespace: str = "default") -> Sequence[UUID]:

@@ -177,6 +177,10 @@ def test_batched_enrichment_equals_the_hit_by_hit_path(keep_host_copy):
     _same(fast.find_similar_many(qs, top_k=200, namespace="ns"), slow.find_similar_many(qs, top_k=200, namespace="ns"))
     _same(fast.find_similar_many(qs, 4, "ns", where=lambda m: m["even"]), slow.find_similar_many(qs, 4, "ns", where=lambda m: m["even"]))
     assert fast.find_similar_many(qs[:2], 3, "nowhere") == [[], []]
+    near_f = fast.find_in_radius(VectorDTO(values=qs[0], metadata={}), 0.9, "ns", "cosine", max_results=6)
+    near_s = slow.find_in_radius(VectorDTO(values=qs[0], metadata={}), 0.9, "ns", "cosine", max_results=6)
+    _same([near_f], [near_s])
+    assert 4 <= len(near_f) <= 6   # max_results caps the index hits; ids missing from the storage are dropped after that
     info = fast.get_storage_info()
     assert info["vectors_per_namespace"] == {"ns": rows.shape[0] - 3} == slow.get_storage_info()["vectors_per_namespace"]
     assert info["namespace_count"] == 1 and info["total_vectors"] == rows.shape[0] - 3
