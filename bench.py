@@ -63,7 +63,65 @@ def parse_args():
     ap.add_argument("--gen-threads", type=int, default=0)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (gloo for single-device rehearsals)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--in-process", action="store_true",
+                    help="ONE process, Index(devices=[...]): the row-sharded path behind the Protocol surface (not the "
+                         "driver's mode: that is one process per GPU under torch.distributed.run)")
+    ap.add_argument("--devices", default="", help="--in-process: comma-separated device list (a device may repeat: "
+                                                  "logical shards); default 0..gpus-1")
     return ap.parse_args()
+
+
+def in_process_main(args, json_fd) -> None:
+    """`--in-process`: every namespace shard is an mlvdb_index of THIS process (mlvectordb_amd/multi_device.py): one host
+    thread per shard issues the scans, the per-shard top-k (fp64 distances) are merged on the host.  A step = one wave of
+    `batch` queries through Index.search_many (host-pointer entries: PCIe of queries and results included).  Same
+    synthetic rows and fatal parity gate as the default mode; weak scaling (rows_per_gpu rows per shard)."""
+    from mlvectordb_amd import Index, synth
+
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    g = len(devices)
+    n_local, d, k = args.rows_per_gpu, args.dim, args.k
+    batch = args.batch or (256 if g == 1 else 1024)
+    t0 = time.perf_counter()
+    index = Index(space=args.space, devices=devices, strategy=args.strategy, capacity_hint=g * n_local)
+    for off, rows in synth.iter_corpus(0, g * n_local, d, threads=args.gen_threads or 16):
+        index.add_arrays(rows, "bench")
+    load_s = time.perf_counter() - t0
+    eng = index._ns["bench"].engine
+    shards = getattr(eng, "shards", [eng])
+    log(f"{g} shards on devices {devices}: {[s.counts()[0] for s in shards]} rows after {load_s:.1f} s")
+    q_host = synth.queries(batch, d)
+    hits = index.search_many(q_host, k, "bench", args.space)
+    for s in shards:
+        s.set_strategy("exact")
+    exact = index.search_many(q_host, k, "bench", args.space)
+    for s in shards:
+        s.set_strategy(args.strategy)
+    verify = {"queries_compared": int(batch), "merged_ids_equal_merged_exact_scans": bool(np.array_equal(hits.labels, exact.labels)),
+              "max_abs_score_err": float(np.abs(hits.scores - exact.scores).max())}
+    out = {"metric": "queries/sec, exact cosine kNN k=10 over a row-sharded Nx768 fp32 corpus (10M rows per GPU)",
+           "unit": "queries/s (each query scanned against one shard; whole-corpus QPS = value / n_gpus)",
+           "n_gpus": g, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "data": "synthetic", "mode": "in-process: Index(devices=...) behind the Protocol surface",
+           "config": {"workload": f"{g * n_local} x {d} fp32 N(0,1) rows ({n_local}/shard), {args.space} kNN k={k}, batch={batch}",
+                      "devices": devices, "rows_per_gpu": n_local, "dim": d, "k": k, "batch": batch},
+           "parity_gate": verify, "load_s": round(load_s, 1)}
+    if not verify["merged_ids_equal_merged_exact_scans"] or verify["max_abs_score_err"] > 1e-5:
+        log(f"PARITY GATE FAILED: {verify}")
+        out.update({"value": None, "error": "parity gate failed"})
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        sys.exit(1)
+    for _ in range(args.warmup):
+        index.search_many(q_host, k, "bench", args.space)
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        index.search_many(q_host, k, "bench", args.space)
+    elapsed = time.perf_counter() - t_start
+    out.update({"value": round(g * batch * args.steps / elapsed, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                "whole_corpus_qps": round(batch * args.steps / elapsed, 1),
+                "dtype": "i8 / bf16 (MFMA bounds) + f64 (exact rescoring of the f32 rows)"})
+    index.close()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 def config1_side(device: int) -> dict:
@@ -145,6 +203,8 @@ def main() -> None:
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.in_process:
+        return in_process_main(args, json_fd)
     import torch
     import torch.distributed as dist
 

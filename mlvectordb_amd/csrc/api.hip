@@ -52,7 +52,10 @@ struct mlvdb_index {
     bool profiling = false;
     float* X = nullptr;   // panels, capacity * ld floats
     void* Xb = nullptr;   // bf16 shadow of X for the filter scan (capacity * ld bf16), or nullptr
-    bool shadow = false;  // keep the shadow (decided at creation: dim % 64 == 0 and not disabled)
+    bool shadow = false;  // keep the bf16 shadow (decided at creation: dim % 64 == 0 and not disabled)
+    bool i8_only = false; // MLVDB_SHADOW=int8 at creation (dim % 256 == 0): no bf16 shadow, the int8 one serves kNN and range
+                          // scans (1.25x instead of 1.75x the corpus in HBM); row-mask searches, the seeding pass and
+                          // indexes whose rows quantise too badly for int8 bounds convert the fp32 rows in registers
     float* rn = nullptr;  // row norms, NaN = tombstoned / not a row
     int64_t capacity = 0, total = 0, deleted = 0;
     hipStream_t stream = nullptr;
@@ -260,7 +263,7 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     HIP_TRY(h, h->qimg.ensure(filter_qimg_bytes(h->ld)));
     HIP_TRY(h, h->fmisc.ensure(8 * kFilterQueries * sizeof(uint32_t)));
     HIP_TRY(h, h->cand.ensure((size_t)kFilterQueries * kCandCap * sizeof(CandEntry)));
-    if (h->Xb) {  // the assembly scan appends through workgroup-private buffers
+    if (h->Xb || h->i8_only) {  // the assembly scan appends through workgroup-private buffers
         HIP_TRY(h, h->wgbuf.ensure((size_t)kScanMaxGrid * kWgCap * sizeof(WgEntry)));
         HIP_TRY(h, h->wgcnt.ensure((size_t)kScanMaxGrid * 8 * sizeof(uint32_t)));
     }
@@ -321,7 +324,7 @@ __global__ void tombstone_rp8_kernel(const int64_t* labels, int64_t n, float* rp
 
 int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
     const char* env = getenv("MLVDB_I8");  // read per pass: tools/scan_ab.py switches it inside one process
-    if ((env && env[0] == '0') || !h->Xb || h->ld % 256 != 0 || h->mask_active) return MLVDB_OK;
+    if ((env && env[0] == '0') || !(h->Xb || h->i8_only) || h->ld % 256 != 0 || h->mask_active) return MLVDB_OK;
     const size_t need_x8 = (size_t)h->capacity * h->ld, need_rp = (size_t)h->capacity * 2 * sizeof(float);
     if (h->x8.bytes < need_x8 || h->rp8.bytes < need_rp || !h->rowerr8.p) {
         HIP_TRY(h, h->x8.ensure(need_x8));
@@ -532,10 +535,11 @@ __global__ void range_resolve_kernel(uint32_t* overflow, const uint32_t* cnt, co
 bool use_filter(const mlvdb_index* h, int64_t nq) {
     if (h->strategy == MLVDB_STRATEGY_EXACT || !filter_supported(h->ld)) return false;
     if (h->strategy == MLVDB_STRATEGY_FILTER) return true;
-    if (nq >= 12 || (nq >= 8 && h->Xb != nullptr)) return h->total >= 32768;
+    const bool shadowed = h->Xb != nullptr || h->i8_only;
+    if (nq >= 12 || (nq >= 8 && shadowed)) return h->total >= 32768;
     // small batches: the narrow filter kernel streams the bf16 shadow, half the bytes of the exact fp32 scan; below
     // ~125k rows of 768 columns the exact scan's two launches win (profiles/r01/small_batch_ab_crossover.txt)
-    return h->Xb != nullptr && h->total * (int64_t)h->ld >= (int64_t)96 << 20;
+    return shadowed && h->total * (int64_t)h->ld >= (int64_t)96 << 20;
 }
 
 int check_handle(mlvdb_index* h) {
@@ -591,7 +595,9 @@ int mlvdb_index_create(int device, int32_t dim, int32_t space, int64_t capacity_
     h->space = space;
     {
         const char* ns = getenv("MLVDB_NO_SHADOW");
-        h->shadow = filter_supported(h->ld) && !(ns && ns[0] == '1');
+        const char* sm = getenv("MLVDB_SHADOW");
+        h->i8_only = sm && !strcmp(sm, "int8") && h->ld % 256 == 0 && !(ns && ns[0] == '1');
+        h->shadow = filter_supported(h->ld) && !(ns && ns[0] == '1') && !h->i8_only;
     }
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {

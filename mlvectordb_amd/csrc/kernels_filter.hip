@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
         const int32_t row = have ? pick[idx] : 0;
         const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 16 + g * 4};
         double acc[1][1], nx[1];
-        accumulate_rows<SPACE, 1, 1, 8>(base, qs, ld, g, acc, nx);
+        accumulate_rows<SPACE, 1, 1, 16>(base, qs, ld, g, acc, nx);
         const double dk = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
         double sc;
         if (SPACE == kSpaceCosine) sc = 1.0 - dk;
@@ -1720,13 +1720,13 @@ template <int SPACE>
 static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info) {
     const int nkc = a.ld / kFilterChunkK;
     if (filter_narrow_ok(a)) return launch_scan_narrow<SPACE, false>(a, row_begin, row_end, s);  // appends to the lists itself
-    if (a.Xb && env_int("MLVDB_SCAN_ASM", 1)) {
+    if ((a.Xb || a.X8) && env_int("MLVDB_SCAN_ASM", 1)) {
         // hand-written body (tools/gen_scan_asm.py).  Default: one 8-wave workgroup per CU (256-row tiles:
         // the query image is staged once per CU, by LDS-DMA), non-temporal X loads, ring of 4 k-steps -- measured
         // fastest (profiles/r01/scan_ab_*.txt); a ring of R k-steps needs the tile's 2*nkc k-steps to be a
         // multiple of R.  MLVDB_SCAN_NW / _NT / _R / _QD select the other generated variants (tuning).
         const int nw = env_int("MLVDB_SCAN_NW", 8);
-        if (env_int("MLVDB_SCAN_MT", 2) == 4) {  // one wave per SIMD, 64 rows per wave
+        if (a.Xb && env_int("MLVDB_SCAN_MT", 2) == 4) {  // one wave per SIMD, 64 rows per wave
             if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true, 4, false, 4>(a, row_begin, row_end, s, info);
             return launch_scan_asm<SPACE, 2, 4, true, 4, false, 4>(a, row_begin, row_end, s, info);
         }
@@ -1762,6 +1762,9 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                 return launch_scan_asm<SPACE, 4, 8, true, 208, true, 2, true>(a, row_begin, row_end, s, info);
             return launch_scan_asm<SPACE, 4, 8, true, 208, false, 2, true>(a, row_begin, row_end, s, info);
         }
+        // everything below streams the bf16 shadow (an int8-only index without usable int8 bounds has none: its
+        // fp32 rows are converted in registers by the compiler-scheduled kernel)
+        if (!a.Xb) return launch_scan_one<SPACE, false>(a, row_begin, row_end, s, info);
         if constexpr (SPACE == kSpaceCosine) {
             if (nw == 8 && nkc % 2 == 0 && env_int("MLVDB_SCAN_PRIO", 0) != 0)
                 return launch_scan_asm<SPACE, 4, 8, true, 4, true>(a, row_begin, row_end, s, info);

@@ -148,6 +148,37 @@ def test_filter_without_bf16_shadow_matches_oracle(space, monkeypatch):
         assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"noshadow/{space}/n{n}d{d}")
 
 
+@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+def test_int8_only_shadow_matches_oracle(space, monkeypatch):
+    """MLVDB_SHADOW=int8 (dim % 256 == 0): no bf16 shadow in HBM (1.25x instead of 1.75x the corpus); kNN and range scans run
+    on the int8 shadow, the seeding pass / row masks / narrow batches convert the fp32 rows in registers.  Same answers."""
+    monkeypatch.setenv("MLVDB_SHADOW", "int8")
+    for seed, n, d, nq, k in [(64, 40000, 256, 40, 10), (65, 9000, 768, 300, 5), (66, 36000, 512, 3, 10)]:
+        rows, qs = make_case(seed, n, d, nq, dup=True)
+        deleted = deleted_mask(seed, n, 0.1)
+        eng = HipScanEngine(d, space, device=0, strategy="filter")
+        try:
+            eng.append(rows[: n // 2])
+            eng.append(rows[n // 2:])
+            eng.tombstone(np.nonzero(deleted)[0])
+            got = eng.search(qs, k)
+            st = eng.last_stats()
+            assert st["strategy_used"] == 2 and st["bound_dtype"] == 2, st
+            assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"int8only/{space}/n{n}d{d}")
+            mask = (np.arange(n) % 3 != 0).astype(np.uint8)     # row-mask search: no shadow serves it, still exact
+            gm = eng.search(qs[:8], k, mask)
+            assert_knn_matches(gm, oracle_knn(qs[:8], rows, k, space, deleted | (mask == 0)), f"int8only-mask/{space}/n{n}")
+            radius = float(got[1][:, min(k, 5) - 1].mean())
+            hits = eng.range(qs[:6], radius, 64)
+            want = exact_scan.range_query(qs[:6], rows, radius, space, deleted=deleted)
+            assert all(np.array_equal(h[0], w[0]) for h, w in zip(hits, want))
+            old = eng.compact()
+            assert old.size == n - int(deleted.sum())
+            assert_knn_matches(eng.search(qs[:16], k), oracle_knn(qs[:16], rows[old], k, space), f"int8only-compact/{space}")
+        finally:
+            eng.close()
+
+
 def test_k_larger_than_live_rows_pads():
     rows, qs = make_case(51, 6, 64, 2)
     got, _ = run_hip(rows, qs, 10, "l2", "exact", deleted_mask(51, 6, 0.4))
