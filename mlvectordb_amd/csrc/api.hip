@@ -374,8 +374,28 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
     // the update kernel turns them into thresholds; the remaining rows follow in rounds of growing
     // size so that thresholds tighten early
     const int64_t n_seed = std::min<int64_t>(h->total, kSeedRows);
-    HIP_TRY(h, launch_filter_seed_scan(fa, n_seed, k, s));  // includes the first threshold update
-    const int64_t bounds[] = {kSeedRows, (int64_t)kFilterTile * 64, (int64_t)kFilterTile * 2048, h->total};
+    int64_t first_row = kSeedRows;
+    {
+        // Round 2: thresholds are seeded from the EXACT k-th best score among the first kSeedRows rows (exact fp64
+        // scan of that prefix for the pass's queries + merge + one tiny kernel: ~25 us) instead of a dense bf16 pass
+        // that puts all 3840 bounds of every query into the lists + an exact-threshold refine over them (~65 us);
+        // the prefix rows then simply belong to the first scan round.  MLVDB_SEED_EXACT=0: the dense pass.
+        const char* env = getenv("MLVDB_SEED_EXACT");
+        if (!(env && env[0] == '0')) {
+            HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * k * sizeof(int64_t)));
+            HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * k * sizeof(float)));
+            HIP_TRY(h, h->seed_cnt.ensure(kFilterQueries * sizeof(int32_t)));
+            HIP_TRY(h, h->seed_d64.ensure((size_t)kFilterQueries * k * sizeof(double)));
+            rc = run_exact(h, s, fa.Qpad, fa.qaux, nq, nullptr, 0, n_seed, k, h->seed_lab.as<int64_t>(),
+                           h->seed_dist.as<float>(), h->seed_cnt.as<int32_t>(), h->seed_d64.as<double>(), false);
+            if (rc) return rc;
+            HIP_TRY(h, launch_filter_seed_thr(fa, h->seed_d64.as<double>(), k, s));
+            first_row = 0;
+        } else {
+            HIP_TRY(h, launch_filter_seed_scan(fa, n_seed, k, s));  // includes the first threshold update
+        }
+    }
+    const int64_t bounds[] = {first_row, (int64_t)kFilterTile * 64, (int64_t)kFilterTile * 2048, h->total};
     for (int r = 0; r < 3; ++r) {
         const int64_t b = std::min(bounds[r], h->total), e = std::min(bounds[r + 1], h->total);
         if (e <= b) continue;
@@ -390,7 +410,8 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
             HIP_TRY(h, hipMemcpyAsync(wc.data(), fa.wgcnt, wc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
             uint64_t sum = 0, mx = 0;
-            for (int i = 0; i < info.scatter_grid * info.nw; ++i) {
+            const int waves = (int)std::min<int64_t>(256, (e - b + 255) / 256) * 8;  // 8-wave workgroups of 256-row tiles
+            for (int i = 0; i < waves; ++i) {
                 sum += wc[(size_t)i];
                 mx = std::max<uint64_t>(mx, wc[(size_t)i]);
             }
