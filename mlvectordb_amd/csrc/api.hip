@@ -376,12 +376,13 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
     const int64_t n_seed = std::min<int64_t>(h->total, kSeedRows);
     int64_t first_row = kSeedRows;
     {
-        // Round 2: thresholds are seeded from the EXACT k-th best score among the first kSeedRows rows (exact fp64
-        // scan of that prefix for the pass's queries + merge + one tiny kernel: ~25 us) instead of a dense bf16 pass
-        // that puts all 3840 bounds of every query into the lists + an exact-threshold refine over them (~65 us);
-        // the prefix rows then simply belong to the first scan round.  MLVDB_SEED_EXACT=0: the dense pass.
+        // Tried in round 2 (MLVDB_SEED_EXACT=1): thresholds seeded from the EXACT k-th best score among the first
+        // kSeedRows rows (exact fp64 scan of that prefix + merge + one tiny kernel) instead of the dense bf16 pass that
+        // puts all 3840 bounds of every query into the lists + the exact-threshold refine over them; the prefix rows
+        // then belong to the first scan round.  Slower: 2.16 vs 2.04 ms per 256-query wave, 0.303 vs 0.288 ms at batch 1
+        // (3840 x 768 x 256 fp64 multiply-adds are not free); the dense pass stays the default.
         const char* env = getenv("MLVDB_SEED_EXACT");
-        if (!(env && env[0] == '0')) {
+        if (env && env[0] == '1') {
             HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * k * sizeof(int64_t)));
             HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * k * sizeof(float)));
             HIP_TRY(h, h->seed_cnt.ensure(kFilterQueries * sizeof(int32_t)));
