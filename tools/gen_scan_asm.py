@@ -628,7 +628,7 @@ def gen_flush_to_global(NW):
             "s_waitcnt vmcnt(0)"]
 
 
-def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False, q4=False):
+def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False, q4=False, place=None):
     """stag: both waves of a SIMD reach the admission test (VALU only) together and leave the MFMA pipe idle for it.
     With the stagger the later-dispatched half of a workgroup's waves (wtype 1) runs half a tile behind: it sits out
     the first nkc/2 chunk periods (staging only), starts every row tile at column ld/2 (k origin rotated by xrot,
@@ -647,7 +647,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     # admission test then reads it with no v_accvgpr_read and no XDL drain.  With two waves per SIMD the kernel
     # descriptor becomes 192 ArchVGPRs + 48 AccVGPRs (accum_offset 192) instead of hipcc's 128 / 128 split.
     VA = va
-    assert not va or (i8 and mt == 2 and dma and not stag)
+    assert not va or (i8 and mt == 2 and dma)
     global FUSE, Q4
     FUSE = va and space == "cosine" and "noadm" not in DBG
     # q4: four 32 KiB Q buffers (128 KiB), chunk c + 2 is staged while chunk c is consumed, and the workgroup meets at
@@ -660,6 +660,12 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     KQ = 1024 // (NW * 64)
     out = []
     a = out.append
+    if place is not None:
+        # code placement (MI355X_MICROARCH.md, "Two waves per SIMD" item 8: a hand-written stream can lose 13 % when its
+        # 8-byte instructions sit at addresses = 4 mod 8): pin the phase of the statement, optionally shifted by 4 bytes
+        a(".p2align 6")
+        for _ in range(place):
+            a("s_nop 0")
     # ---- descriptors and per-workgroup state
     a("s_mov_b32 s80, %[xlo]")
     a("s_mov_b32 s81, %[xhi]")
@@ -898,7 +904,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -927,6 +933,11 @@ def main():
     # 217 / 218: two 4-wave workgroups per CU (independent barriers: one's chunk-boundary bubble under the other's MFMAs)
     (Path(args.outdir) / "scan_asm_cosine_i8_va_nw4.inc").write_text(generate("cosine", 4, 4, 4, True, False, 2, True, False, True, True))
     (Path(args.outdir) / "scan_asm_cosine_i8_va_nw4_pr.inc").write_text(generate("cosine", 4, 4, 4, True, True, 2, True, False, True, True))
+    # 220 / 221: the default body with its code placement pinned to a 64-byte boundary / that + 4 bytes
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_p0.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, False, 0))
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_p4.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, False, 1))
+    # 222: the later half of the waves half a tile behind (round 1's stagger, now that no serial admission phase is left)
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_stag.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, True, True, True))
     # 219: four Q buffers, one barrier per two chunks
     (Path(args.outdir) / "scan_asm_cosine_i8_va_q4.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, True))
     DBG.update({"nohit"})   # 212: the folded pre-test computed, no hit ever taken
@@ -959,6 +970,11 @@ def main():
     disp.append('#include "scan_asm_cosine_i8_va_nw4.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 4 && R == 4 && NT == true && QD == 218 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_cosine_i8_va_nw4_pr.inc"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 222 && PRIO == true && MT == 2 && DMA == true && STAG == true) {")
+    disp.append('#include "scan_asm_cosine_i8_va_stag.inc"')
+    for code, nm in ((220, "p0"), (221, "p4")):
+        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
+        disp.append(f'#include "scan_asm_cosine_i8_va_{nm}.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 219 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_cosine_i8_va_q4.inc"')
     disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
