@@ -652,7 +652,7 @@ static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagre
 // the bf16 body; 208..219 = int8 bodies (208 AccVGPR accumulators; 211 ArchVGPR accumulators, cosine: admission folded into the
 // last k-step; 214 / 215 / 216 tuning variants of 211: ring of 6, read-ahead 8, no wave priorities; 209 / 210 / 212 / 213
 // timing diagnostics).
-constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 223; }
+constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 229; }
 constexpr int scan_code_qd(int qd) { return qd == 215 ? 8 : (qd > 8 ? 4 : qd); }
 constexpr int scan_code_qbufs(int qd) { return qd == 219 ? 4 : 2; }  // 219: four Q chunk buffers, one barrier per two chunks
 constexpr int scan_code_stage_cap(int qd, int nw, int mt) {
@@ -1743,11 +1743,20 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                     return launch_scan_asm<SPACE, 4, 8, true, 212, true, 2, true>(a, row_begin, row_end, s, info);
                 if (env_int("MLVDB_SCAN_DIAG", 0) == 213)
                     return launch_scan_asm<SPACE, 4, 8, true, 213, true, 2, true>(a, row_begin, row_end, s, info);
+                switch (env_int("MLVDB_SCAN_DIAG", 0)) {
+                    case 224: return launch_scan_asm<SPACE, 4, 8, true, 224, true, 2, true>(a, row_begin, row_end, s, info);
+                    case 225: return launch_scan_asm<SPACE, 4, 8, true, 225, true, 2, true>(a, row_begin, row_end, s, info);
+                    case 226: return launch_scan_asm<SPACE, 4, 8, true, 226, true, 2, true>(a, row_begin, row_end, s, info);
+                    case 227: return launch_scan_asm<SPACE, 4, 8, true, 227, true, 2, true>(a, row_begin, row_end, s, info);
+                    default: break;
+                }
             }
 #endif
             if (env_int("MLVDB_SCAN_VA", 1)) {  // accumulators in ArchVGPRs: the admission test reads them directly
                 if constexpr (SPACE == kSpaceCosine) {  // tuning variants of the folded body
                     const int var = env_int("MLVDB_SCAN_VAR", 0);
+                    if (var == 228 && (a.ld / 64) % 6 == 0)
+                        return launch_scan_asm<SPACE, 6, 8, true, 228, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 214 && (a.ld / 64) % 6 == 0)
                         return launch_scan_asm<SPACE, 6, 8, true, 214, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 215) return launch_scan_asm<SPACE, 4, 8, true, 215, true, 2, true>(a, row_begin, row_end, s, info);

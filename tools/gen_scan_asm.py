@@ -52,6 +52,7 @@ I8 = False     # generate(): int8 shadow -- v_mfma_i32_16x16x64_i8, k-steps of 6
 STAG = False   # generate(): the later-dispatched half of the waves runs half a tile behind (see generate)
 VA = False     # generate(): accumulators in ArchVGPRs v[VA_BASE : VA_BASE + 64*MT), ring and B fragments in AccVGPRs (see generate)
 VA_BASE = 64   # v0..v63 stay with the compiler (the statement's "v" operands)
+BURST = 0      # generate(): ring refills issued in bursts of BURST consecutive k-steps of a panel (contiguous KiBs) instead of one per k-step
 Q4 = False     # generate(): four Q chunk buffers in LDS, chunk c+2 staged during chunk c, ONE barrier per two chunks
 FUSE = False   # generate(): the admission test is folded into the tile's last k-step (cosine, VA; see gen_pretest)
 DBG = set()   # timing diagnostics only (wrong results): 'nolds' drops the B-fragment reads, 'nox' the X refills
@@ -202,31 +203,41 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
         s.lds(f"ds_read_b128 %[t{f % QD}], %[ldr] offset:{n * 2048 + h * 1024}", ("rd", f))
 
     def refill(h):
-        step = step0 + h
-        b = step % R
+        last_step = step0 + h
+        if BURST:
+            # burst mode: nothing until the last k-step of a group of BURST is done, then the whole group of the next
+            # body at once -- BURST consecutive KiBs of each panel, issued back to back (DRAM page locality)
+            if last_step % BURST != BURST - 1:
+                return
+            steps = list(range(last_step - BURST + 1, last_step + 1))
+        else:
+            steps = [last_step]
         pol = " nt" if nt else ""   # streamed once: non-temporal
-        for m in range(MT):
-            if last and step * 1024 < 4096:
-                if m >= 2:
-                    s.emit(f"s_mul_i32 %[st0], %[pb], {m}")
-                so = "0" if m == 0 else ("%[pb]" if m == 1 else "%[st0]")
-                if STAG:
-                    so = "%[xrot]" if m == 0 else "%[pbrot]"
-                off = f" offset:{step * 1024}" if step else ""
-                s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XNEXT}, {so} offen{off}{pol}", ("x", b, m))
-            elif last:
-                if m == 0:
-                    s.emit(f"s_movk_i32 %[st0], 0x{step * 1024:x}")
-                else:
+        for idx, step in enumerate(steps):
+            b = step % R
+            for m in range(MT):
+                if last and step * 1024 < 4096:
                     if m >= 2:
                         s.emit(f"s_mul_i32 %[st0], %[pb], {m}")
-                    s.emit(f"s_add_u32 %[st0], {'%[pb]' if m == 1 else '%[st0]'}, 0x{step * 1024:x}")
-                s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XNEXT}, %[st0] offen{pol}", ("x", b, m))
-            else:
-                s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, %[xso{m}] offen{pol}", ("x", b, m))
+                    so = "0" if m == 0 else ("%[pb]" if m == 1 else "%[st0]")
+                    if STAG:
+                        so = "%[xrot]" if m == 0 else "%[pbrot]"
+                    off = f" offset:{step * 1024}" if step else ""
+                    s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XNEXT}, {so} offen{off}{pol}", ("x", b, m))
+                elif last:
+                    if m == 0:
+                        s.emit(f"s_movk_i32 %[st0], 0x{step * 1024:x}")
+                    else:
+                        if m >= 2:
+                            s.emit(f"s_mul_i32 %[st0], %[pb], {m}")
+                        s.emit(f"s_add_u32 %[st0], {'%[pb]' if m == 1 else '%[st0]'}, 0x{step * 1024:x}")
+                    s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XNEXT}, %[st0] offen{pol}", ("x", b, m))
+                else:
+                    off = f" offset:{idx * 1024}" if idx else ""
+                    s.vmem(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, %[xso{m}] offen{off}{pol}", ("x", b, m))
         if not last:
             for m in range(MT):
-                s.emit(f"s_add_u32 %[xso{m}], %[xso{m}], 0x400")
+                s.emit(f"s_add_u32 %[xso{m}], %[xso{m}], 0x{0x400 * len(steps):x}")
             if STAG:   # a rotated k origin passes the end of the panel in mid-tile
                 s.emit("s_cmp_eq_u32 %[xso0], %[pb]")
                 s.emit("s_cselect_b32 %[xso0], 0, %[xso0]")
@@ -628,7 +639,7 @@ def gen_flush_to_global(NW):
             "s_waitcnt vmcnt(0)"]
 
 
-def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False, q4=False, place=None):
+def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False, q4=False, place=None, burst=0):
     """stag: both waves of a SIMD reach the admission test (VALU only) together and leave the MFMA pipe idle for it.
     With the stagger the later-dispatched half of a workgroup's waves (wtype 1) runs half a tile behind: it sits out
     the first nkc/2 chunk periods (staging only), starts every row tile at column ld/2 (k origin rotated by xrot,
@@ -655,6 +666,9 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     # the software pipeline.  Needs the DMA staging and a ring of 4 k-steps (one loop body = one pair of chunks).
     Q4 = q4
     assert not q4 or (dma and R == 4 and not stag)
+    global BURST
+    BURST = burst
+    assert not burst or (R % burst == 0 and not stag)
     assert R in (2, 4, 6) and 2 <= QD <= 8 and mt in (2, 4)
     assert not stag or (dma and mt == 2 and R * 1024 <= 4096)
     KQ = 1024 // (NW * 64)
@@ -904,7 +918,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_diag224.inc", "scan_asm_diag225.inc", "scan_asm_diag226.inc", "scan_asm_diag227.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc", "scan_asm_cosine_i8_va_r6b3.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -938,11 +952,18 @@ def main():
     (Path(args.outdir) / "scan_asm_cosine_i8_va_p4.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, False, 1))
     # 222: the later half of the waves half a tile behind (round 1's stagger, now that no serial admission phase is left)
     (Path(args.outdir) / "scan_asm_cosine_i8_va_stag.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, True, True, True))
+    # 228: ring of 6 k-steps refilled in bursts of 3 (3 contiguous KiB per panel at once)
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_r6b3.inc").write_text(generate("cosine", 6, 4, 8, True, True, 2, True, False, True, True, False, None, 3))
     # 219: four Q buffers, one barrier per two chunks
     (Path(args.outdir) / "scan_asm_cosine_i8_va_q4.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, True))
     DBG.update({"nohit"})   # 212: the folded pre-test computed, no hit ever taken
     (Path(args.outdir) / "scan_asm_diag212.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
     DBG.clear()
+    # the folded body without its X loads / B reads / Q staging (and never taking a hit: the bounds are garbage then)
+    for code, knobs in ((224, {"nox", "nohit"}), (225, {"nolds", "nohit"}), (226, {"nox", "nolds", "nohit"}), (227, {"noq", "nohit"})):
+        DBG.update(knobs)
+        (Path(args.outdir) / f"scan_asm_diag{code}.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
+        DBG.clear()
     DBG.update({"noadm"})   # 213: ArchVGPR accumulators, no admission test at all
     (Path(args.outdir) / "scan_asm_diag213.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
     DBG.clear()
@@ -970,6 +991,8 @@ def main():
     disp.append('#include "scan_asm_cosine_i8_va_nw4.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 4 && R == 4 && NT == true && QD == 218 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_cosine_i8_va_nw4_pr.inc"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 6 && NT == true && QD == 228 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
+    disp.append('#include "scan_asm_cosine_i8_va_r6b3.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 222 && PRIO == true && MT == 2 && DMA == true && STAG == true) {")
     disp.append('#include "scan_asm_cosine_i8_va_stag.inc"')
     for code, nm in ((220, "p0"), (221, "p4")):
@@ -985,7 +1008,7 @@ def main():
     disp.append('#include "scan_asm_diag209.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 210 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_diag210.inc"')
-    for code in (212, 213):
+    for code in (212, 213, 224, 225, 226, 227):
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
         disp.append(f'#include "scan_asm_diag{code}.inc"')
     disp.append("#endif")
