@@ -654,9 +654,9 @@ static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagre
 // timing diagnostics).
 constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 229; }
 constexpr int scan_code_qd(int qd) { return qd == 215 ? 8 : (qd > 8 ? 4 : qd); }
-constexpr int scan_code_qbufs(int qd) { return qd == 219 ? 4 : 2; }  // 219: four Q chunk buffers, one barrier per two chunks
+constexpr int scan_code_qbufs(int qd) { return qd == 219 || qd == 229 ? 4 : 2; }  // 219 / 229: four Q chunk buffers
 constexpr int scan_code_stage_cap(int qd, int nw, int mt) {
-    return qd == 219 ? kAsmStageCapNw8Q4 : (mt == 4 ? kAsmStageCapNw4Mt4 : (nw == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4));
+    return qd == 219 || qd == 229 ? kAsmStageCapNw8Q4 : (mt == 4 ? kAsmStageCapNw4Mt4 : (nw == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4));
 }
 
 template <int SPACE, int R, int NW, bool NT, int QD, bool PRIO, int MT, bool DMA, bool STAG>
@@ -1755,6 +1755,8 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
             if (env_int("MLVDB_SCAN_VA", 1)) {  // accumulators in ArchVGPRs: the admission test reads them directly
                 if constexpr (SPACE == kSpaceCosine) {  // tuning variants of the folded body
                     const int var = env_int("MLVDB_SCAN_VAR", 0);
+                    if (var == 229 && (a.ld / 64) % 6 == 0)
+                        return launch_scan_asm<SPACE, 6, 8, true, 229, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 228 && (a.ld / 64) % 6 == 0)
                         return launch_scan_asm<SPACE, 6, 8, true, 228, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 214 && (a.ld / 64) % 6 == 0)

@@ -53,6 +53,7 @@ STAG = False   # generate(): the later-dispatched half of the waves runs half a 
 VA = False     # generate(): accumulators in ArchVGPRs v[VA_BASE : VA_BASE + 64*MT), ring and B fragments in AccVGPRs (see generate)
 VA_BASE = 64   # v0..v63 stay with the compiler (the statement's "v" operands)
 BURST = 0      # generate(): ring refills issued in bursts of BURST consecutive k-steps of a panel (contiguous KiBs) instead of one per k-step
+Q3D = False    # generate(): four Q buffers, chunk c+3 staged during chunk c, its landing awaited TWO chunks later (see generate)
 Q4 = False     # generate(): four Q chunk buffers in LDS, chunk c+2 staged during chunk c, ONE barrier per two chunks
 FUSE = False   # generate(): the admission test is folded into the tile's last k-step (cosine, VA; see gen_pretest)
 DBG = set()   # timing diagnostics only (wrong results): 'nolds' drops the B-fragment reads, 'nox' the X refills
@@ -183,10 +184,10 @@ def gen_rowmax(s, part):
                 a(f"v_max_f32 {dst}, {dst}, %[{src}{NR - 1}]")
 
 
-def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=False, final=False, sync=True):
+def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=False, final=False, sync=True, ch=0):
     """One 64-column chunk = 2 k-steps = 32 fragments x MT MFMAs.  final: the tile's last chunk, whose second k-step
     carries the admission pre-tests (FUSE)."""
-    if Q4:   # buffers 0..3 in rotation: this chunk reads the next one, its DMAs fill the one after the next
+    if Q4 or Q3D:   # buffers 0..3 in rotation: this chunk reads the next one, its DMAs fill the one after the next (Q3D: one further)
         s.emit("v_add_u32 %[ldr], 0x8000, %[ldr]")
         s.emit("v_and_b32 %[ldr], 0x1ffff, %[ldr]")
         s.emit("s_add_u32 %[sldw], %[sldw], 0x8000")
@@ -311,7 +312,7 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
             if kind == "d":
                 s.emit(f"s_add_u32 m0, %[sldw], 0x{const:x}")
                 s.emit(f"s_add_u32 %[st0], %[qcur], 0x{const:x}")
-                s.vmem(f"buffer_load_dwordx4 %[qvoff], %[qsrd], %[st0] offen lds", (setname, i))
+                s.vmem(f"buffer_load_dwordx4 %[qvoff], %[qsrd], %[st0] offen lds", (setname, i, ch) if Q3D else (setname, i))
             elif kind == "w":
                 s.need_vm((setname, i))
                 s.lds(f"ds_write_b128 %[ldw], {reg} offset:{const}", ("wr", setname, i))
@@ -335,7 +336,13 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
         # (every wave waited for its share of it there), and the buffer this wave's DMAs are filling was last read two
         # chunks ago, before that same barrier.
         return
-    if dma:   # this wave's share of the chunk(s) staged since the last barrier has landed in LDS
+    if dma and Q3D:
+        # the chunk read NEXT was staged two chunks ago: waiting for those transfers (vmcnt completes in order) only
+        # forces the X refills issued before them, i.e. more than two chunks ago -- the ring of 6 k-steps gets its
+        # full three chunks of latency cover instead of the one a wait for this chunk's own transfers leaves
+        nch = R // 2
+        s.need_vm(*[(sn, i, (ch + 1) % nch) for sn in ("qb", "qa") for i in range(KQ)])
+    elif dma:   # this wave's share of the chunk(s) staged since the last barrier has landed in LDS
         s.need_vm(*[(sn, i) for sn in ("qb", "qa") for i in range(KQ)])
     s.drain_lg()
     if "stamp" in DBG:   # cycles parked at the barrier, summed in an SGPR (timing diagnostic)
@@ -381,7 +388,7 @@ def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False, dma=False):
                    ("rn", j))
     for ch in range(R // 2):
         gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last, nt, prio, dma, FUSE and last and ch == R // 2 - 1,
-                  sync=not Q4 or ch % 2 == 1)
+                  sync=not Q4 or ch % 2 == 1, ch=ch)
     if last:
         s.need_vm(*[("rn", j) for j in range(4 * MT)])
 
@@ -537,7 +544,7 @@ def gen_hit_stubs(copy=""):
 
 def lds_stage_cap(NW, mt=2, qbufs=None):
     """Entries of a wave's staging area in LDS (12 B each, SoA): what is left of the 160 KiB per CU."""
-    qbufs = qbufs or (4 if Q4 else 2)
+    qbufs = qbufs or (4 if (Q4 or Q3D) else 2)
     wgs_per_cu = (16 // mt) // NW      # mt = 2: two waves per SIMD, mt = 4: one
     per_wg = (160 * 1024) // wgs_per_cu - (qbufs * CHUNK_BYTES + 3072)   # Q buffers + thr[256], qscale[256], ke[256]
     return min(WG_CAP // NW, (per_wg // NW) // 12 // 8 * 8)
@@ -639,7 +646,7 @@ def gen_flush_to_global(NW):
             "s_waitcnt vmcnt(0)"]
 
 
-def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False, q4=False, place=None, burst=0):
+def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False, q4=False, place=None, burst=0, q3d=False):
     """stag: both waves of a SIMD reach the admission test (VALU only) together and leave the MFMA pipe idle for it.
     With the stagger the later-dispatched half of a workgroup's waves (wtype 1) runs half a tile behind: it sits out
     the first nkc/2 chunk periods (staging only), starts every row tile at column ld/2 (k origin rotated by xrot,
@@ -666,6 +673,13 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     # the software pipeline.  Needs the DMA staging and a ring of 4 k-steps (one loop body = one pair of chunks).
     Q4 = q4
     assert not q4 or (dma and R == 4 and not stag)
+    # q3d: four Q buffers, chunk c + 3 is staged while chunk c is consumed, one barrier per chunk, and the wait before
+    # that barrier is for the transfers issued TWO chunks ago (the chunk read next).  Why: vmcnt completes in order, so
+    # waiting for this chunk's own transfers (the two-buffer scheme) also waits for every X refill issued before them --
+    # whatever the ring depth, an X load then has about one chunk period to arrive (a ring of 6 brought 0.9 %).
+    global Q3D
+    Q3D = q3d
+    assert not q3d or (dma and R == 6 and not stag and not q4)
     global BURST
     BURST = burst
     assert not burst or (R % burst == 0 and not stag)
@@ -699,7 +713,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
         a("s_memtime s[78:79]")
         a("s_waitcnt lgkmcnt(0)")
         a("s_mov_b32 %[sacc1], s78")
-    a("v_add_u32 %[ldr], 0x18000, %[lane16]" if q4 else "v_add_u32 %[ldr], 0x8000, %[lane16]")   # the first chunk moves it to buffer 0
+    a("v_add_u32 %[ldr], 0x18000, %[lane16]" if (q4 or q3d) else "v_add_u32 %[ldr], 0x8000, %[lane16]")   # the first chunk moves it to buffer 0
     if not dma:
         a("v_mov_b32 %[ldw], %[qvoff]")        # ... and this one to buffer 1
     # ---- prologue: Q chunk 0 -> LDS buffer 0, chunk 1 -> the sets (register staging only), k-steps 0..R-1 -> the ring
@@ -710,12 +724,22 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
             a(f"s_add_u32 m0, %[sldw], 0x{const:x}")
             a(f"s_movk_i32 %[st0], 0x{const:x}")
             a("buffer_load_dwordx4 %[qvoff], %[qsrd], %[st0] offen lds")
-        if q4:   # chunk 1 -> buffer 1 as well; the first chunk then moves the write base to buffer 2
+        if q4 or q3d:   # chunk 1 -> buffer 1 as well; the first chunk then moves the write base to buffer 2
             a("s_add_u32 %[sldw], %[sldw], 0x8000")
             for const, setname, i in pieces:
                 a(f"s_add_u32 m0, %[sldw], 0x{const:x}")
                 a(f"s_add_u32 %[st0], %[qc1], 0x{const:x}")
                 a("buffer_load_dwordx4 %[qvoff], %[qsrd], %[st0] offen lds")
+        if q3d:  # ... and chunk 2 -> buffer 2; the first chunk moves the write base to buffer 3.  The Q cursor (the chunk
+            #     staged next: 3, 4, ... mod the image's chunks) lives in sacc1 between tiles
+            a("s_add_u32 %[sldw], %[sldw], 0x8000")
+            for const, setname, i in pieces:
+                a(f"s_add_u32 m0, %[sldw], 0x{const:x}")
+                a(f"s_add_u32 %[st0], %[qcur0], 0x{const:x}")
+                a("buffer_load_dwordx4 %[qvoff], %[qsrd], %[st0] offen lds")
+            a("s_add_u32 %[qcur], %[qcur0], 0x8000")
+            a("s_cmp_eq_u32 %[qcur], %[qbytes]")
+            a("s_cselect_b32 %[qcur], 0, %[qcur]")
     else:
         for const, setname, i in pieces:
             a(f"s_movk_i32 %[st0], 0x{const:x}")
@@ -767,7 +791,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     a("s_cselect_b32 %[cnt], %[xshi], 0")
     a("s_add_u32 s84, s80, %[st0]")
     a("s_addc_u32 s85, s81, %[cnt]")
-    if not stag:
+    if not stag and not q3d:   # (q3d: the cursor simply keeps running: a tile is a whole number of image periods)
         a("s_mov_b32 %[qcur], %[qc1]" if dma and not q4 else "s_mov_b32 %[qcur], %[qcur0]")   # first chunk staged inside this tile's loop
     a(f"s_add_u32 %[xso0], %[xrot], 0x{R * 1024:x}" if stag else f"s_movk_i32 %[xso0], 0x{R * 1024:x}")
     a("s_add_u32 %[xso1], %[pb], %[xso0]")
@@ -918,7 +942,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_diag224.inc", "scan_asm_diag225.inc", "scan_asm_diag226.inc", "scan_asm_diag227.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc", "scan_asm_cosine_i8_va_r6b3.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_diag224.inc", "scan_asm_diag225.inc", "scan_asm_diag226.inc", "scan_asm_diag227.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc", "scan_asm_cosine_i8_va_r6b3.inc", "scan_asm_cosine_i8_va_q3d.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -954,6 +978,8 @@ def main():
     (Path(args.outdir) / "scan_asm_cosine_i8_va_stag.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, True, True, True))
     # 228: ring of 6 k-steps refilled in bursts of 3 (3 contiguous KiB per panel at once)
     (Path(args.outdir) / "scan_asm_cosine_i8_va_r6b3.inc").write_text(generate("cosine", 6, 4, 8, True, True, 2, True, False, True, True, False, None, 3))
+    # 229: ring of 6 + Q staged three chunks ahead, awaited two chunks later
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_q3d.inc").write_text(generate("cosine", 6, 4, 8, True, True, 2, True, False, True, True, False, None, 0, True))
     # 219: four Q buffers, one barrier per two chunks
     (Path(args.outdir) / "scan_asm_cosine_i8_va_q4.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, True))
     DBG.update({"nohit"})   # 212: the folded pre-test computed, no hit ever taken
@@ -991,6 +1017,8 @@ def main():
     disp.append('#include "scan_asm_cosine_i8_va_nw4.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 4 && R == 4 && NT == true && QD == 218 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_cosine_i8_va_nw4_pr.inc"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 6 && NT == true && QD == 229 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
+    disp.append('#include "scan_asm_cosine_i8_va_q3d.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 6 && NT == true && QD == 228 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_cosine_i8_va_r6b3.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 222 && PRIO == true && MT == 2 && DMA == true && STAG == true) {")
