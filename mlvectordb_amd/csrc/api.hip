@@ -70,7 +70,9 @@ struct mlvdb_index {
     DevBuf x8, rp8, rowerr8, qimg8, sq8;
     int64_t i8_rows = 0;      // rows [0, i8_rows) of the int8 shadow are current (0 after compact / reset / regrowth)
     float i8_err = 0.f;       // host copy of rowerr8 (read back whenever rows were converted)
-    bool mask_active = false;  // h->rn is a masked copy (mlvdb_search_batch_filtered): the int8 rp8 knows no masks
+    bool mask_active = false;  // h->rn is a masked copy (mlvdb_search_batch_filtered)
+    bool mask_pairs_ready = false;  // ... and rp8_masked holds the masked copy of the int8 shadow's row pairs
+    DevBuf rp8_masked;
     DevBuf qimg, fmisc, cand, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, io_d64, counters, labels_in;
     DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
     uint32_t* host_flags = nullptr;  // pinned, kFilterQueries words
@@ -322,9 +324,14 @@ __global__ void tombstone_rp8_kernel(const int64_t* labels, int64_t n, float* rp
     if (i < n && labels[i] >= 0 && labels[i] < rows) rp8[2 * labels[i]] = rp8[2 * labels[i] + 1] = __builtin_nanf("");
 }
 
-int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
+bool i8_eligible(const mlvdb_index* h) {
     const char* env = getenv("MLVDB_I8");  // read per pass: tools/scan_ab.py switches it inside one process
-    if ((env && env[0] == '0') || !(h->Xb || h->i8_only) || h->ld % 256 != 0 || h->mask_active) return MLVDB_OK;
+    return !(env && env[0] == '0') && (h->Xb || h->i8_only) && h->ld % 256 == 0;
+}
+
+// Bring the int8 shadow up to date (rows appended since the last pass).  Must run with the index's own norms in h->rn
+// (a row-mask search swaps them for a masked copy afterwards).
+int update_i8_shadow(mlvdb_index* h, hipStream_t s) {
     const size_t need_x8 = (size_t)h->capacity * h->ld, need_rp = (size_t)h->capacity * 2 * sizeof(float);
     if (h->x8.bytes < need_x8 || h->rp8.bytes < need_rp || !h->rowerr8.p) {
         HIP_TRY(h, h->x8.ensure(need_x8));
@@ -344,6 +351,17 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
         HIP_TRY(h, hipMemcpyAsync(&h->i8_err, h->rowerr8.p, sizeof(float), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
     }
+    return MLVDB_OK;
+}
+
+int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
+    if (!i8_eligible(h)) return MLVDB_OK;
+    if (h->mask_active) {
+        if (!h->mask_pairs_ready) return MLVDB_OK;  // the masked copy of the row pairs was not built: bf16 / fp32 bodies
+    } else {
+        int rc = update_i8_shadow(h, s);
+        if (rc) return rc;
+    }
     // One scale per row: a row with an outlier component quantises badly.  Cosine bounds carry every row's own error;
     // l2 / ip still use the index-wide maximum, which would then admit everything: beyond 0.03 (typical data sits at
     // 0.008-0.015) they keep to the bf16 shadow, whose error is relative per component.
@@ -351,7 +369,7 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
     HIP_TRY(h, h->qimg8.ensure((size_t)kFilterQueries * h->ld));
     HIP_TRY(h, h->sq8.ensure(kFilterQueries * sizeof(float)));
     fa.X8 = h->x8.p;
-    fa.rp8 = h->rp8.as<float>();
+    fa.rp8 = h->mask_active ? h->rp8_masked.as<float>() : h->rp8.as<float>();  // a masked-out row is a NaN pair: "not a row"
     fa.row_err8 = h->rowerr8.as<float>();
     fa.qimg8 = h->qimg8.p;
     fa.sq8 = h->sq8.as<float>();
@@ -653,7 +671,7 @@ int mlvdb_index_destroy(mlvdb_index* h) {
     if (h->rn) (void)hipFree(h->rn);
     if (h->Xb) (void)hipFree(h->Xb);
     for (DevBuf* b : {&h->stage, &h->qpad, &h->qaux, &h->partial, &h->qsel, &h->seed_lab, &h->seed_dist, &h->seed_cnt,
-                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->qerr, &h->rowerr, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt, &h->io_d64, &h->gather_out, &h->gather_lab, &h->cand_range, &h->rhits, &h->rhit_cnt, &h->x8, &h->rp8, &h->rowerr8, &h->qimg8, &h->sq8,
+                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->qerr, &h->rowerr, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt, &h->io_d64, &h->gather_out, &h->gather_lab, &h->cand_range, &h->rhits, &h->rhit_cnt, &h->rp8_masked, &h->x8, &h->rp8, &h->rowerr8, &h->qimg8, &h->sq8,
                       &h->counters, &h->labels_in, &h->page_lab, &h->page_dist, &h->page_cnt, &h->page_d64, &h->cur_d,
                       &h->cur_l})
         b->release();
@@ -973,12 +991,24 @@ int mlvdb_search_batch_ex(mlvdb_index* h, const float* queries, int64_t nq, int3
     HIP_TRY(h, h->rn_masked.ensure((size_t)h->capacity * sizeof(float)));
     HIP_TRY(h, hipMemcpyAsync(h->row_mask.p, row_mask, (size_t)h->total, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, launch_mask_norms(h->rn, h->row_mask.as<uint8_t>(), h->rn_masked.as<float>(), h->total, h->capacity, h->stream));
+    // the int8 shadow serves masked searches too: bring it up to date with the index's own norms, then mask a copy of its
+    // row pairs (8 bytes per row) exactly like the norms
+    h->mask_pairs_ready = false;
+    if (i8_eligible(h)) {
+        rc = update_i8_shadow(h, h->stream);
+        if (rc) return rc;
+        HIP_TRY(h, h->rp8_masked.ensure((size_t)h->capacity * 2 * sizeof(float)));
+        HIP_TRY(h, launch_mask_pairs(h->rp8.as<float>(), h->row_mask.as<uint8_t>(), h->rp8_masked.as<float>(), h->total,
+                                     h->capacity, h->stream));
+        h->mask_pairs_ready = true;
+    }
     float* const all_rows = h->rn;  // every kernel of the call reads the masked norms instead
     h->rn = h->rn_masked.as<float>();
     h->mask_active = true;
     rc = search_host(h, queries, nq, k, out_labels, out_dist, out_counts, out_dist64);
     h->rn = all_rows;
     h->mask_active = false;
+    h->mask_pairs_ready = false;
     return rc;
 }
 

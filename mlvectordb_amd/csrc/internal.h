@@ -55,6 +55,8 @@ hipError_t launch_compact_rows(const float* X, float* nX, const void* Xb, void* 
                                const int32_t* old_of_new, int64_t live, int32_t ld, hipStream_t s);
 // out[i] = mask[i] ? rn[i] : NaN (i < total), NaN up to capacity: a masked-out row looks tombstoned to every scan
 hipError_t launch_mask_norms(const float* rn, const uint8_t* mask, float* out, int64_t total, int64_t capacity, hipStream_t s);
+// the same for the int8 shadow's row pairs [rows][2]
+hipError_t launch_mask_pairs(const float* rp8, const uint8_t* mask, float* out, int64_t total, int64_t capacity, hipStream_t s);
 // Qpad[q][0..ld) = queries[q][0..dim) zero padded; qaux[q] = 1/(|q|+1e-30) (cosine) or |q| (l2, ip)
 // qerr (optional): |q^ - bf16 image of q^| per query, rounded up
 hipError_t launch_query_prep(const float* queries, int32_t nq, int32_t dim, int32_t ld, int32_t space, float* Qpad,

@@ -425,7 +425,7 @@ def test_save_index_load_index_round_trip_on_device(tmp_path, monkeypatch):
                                           ("l2", 768, 40, 10), ("ip", 512, 300, 5), ("l2", 256, 3, 10)])
 def test_int8_shadow_follows_appends_tombstones_compaction_and_masks(space, d, nq, k):
     """The int8 shadow is maintained lazily: rows appended, tombstoned or compacted away after a
-    search must be reflected in the next one (ids == oracle each time); a row-mask search falls back to bf16."""
+    search must be reflected in the next one (ids == oracle each time); a row-mask search masks a copy of its row pairs."""
     n = 30_000
     rows, qs = make_case(900 + d, n, d, nq, dup=True)
     eng = HipScanEngine(d, space, device=0, strategy="filter")
@@ -448,8 +448,10 @@ def test_int8_shadow_follows_appends_tombstones_compaction_and_masks(space, d, n
         assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), "i8/tombstoned best")
         mask = (np.arange(n) % 3 != 0).astype(np.uint8)
         got = eng.search(qs, k, mask=mask)
-        assert eng.last_stats()["bound_dtype"] == 1
+        assert eng.last_stats()["bound_dtype"] == 2  # round 2: the mask is applied to a copy of the int8 row pairs too
         assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted | (mask == 0)), "i8/mask")
+        got = eng.search(qs, k)  # ... and the unmasked shadow is untouched by it
+        assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), "i8/after mask")
         old = eng.compact()
         live = rows[old]
         got = eng.search(qs, k)
