@@ -4,7 +4,7 @@ tombstone) draws, the filter strategy must return exactly the ids (and float32 d
 Distributions are chosen to stress the error bounds: Gaussian, clustered (near-ties), heavy-tailed, sparse, rows and
 queries with dominant components, wide dynamic range of norms.  Prints one line per case and a summary; exits non-zero
 on any mismatch.  Not part of the test suite (minutes of GPU time)."""
-import argparse, sys, time
+import argparse, os, sys, time
 from pathlib import Path
 import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -54,18 +54,25 @@ for case in range(args.cases):
     if rng.random() < 0.3:  # queries that are (noisy) copies of rows: exact and near matches
         src = rng.integers(0, n, nq)
         qs = (rows[src] * (1 + 0.001 * rng.standard_normal((nq, d)))).astype(np.float32)
+    i8only = d % 256 == 0 and rng.random() < 0.25     # no bf16 shadow (MLVDB_SHADOW=int8)
+    if i8only:
+        os.environ["MLVDB_SHADOW"] = "int8"
     eng = HipScanEngine(d, space, device=0, strategy="filter")
-    eng.append(rows)
+    os.environ.pop("MLVDB_SHADOW", None)
+    eng.append(rows[: n // 2])
+    eng.append(rows[n // 2:])                          # the int8 shadow is extended lazily
     if rng.random() < 0.5:
         eng.tombstone(np.nonzero(rng.random(n) < 0.1)[0])
-    fl, fd, fc = eng.search(qs, k)
+    mask = (rng.random(n) < rng.uniform(0.05, 0.95)).astype(np.uint8) if rng.random() < 0.3 else None  # row-mask search
+    fl, fd, fc = eng.search(qs, k, mask)
     st = eng.last_stats()
     eng.set_strategy("exact")
-    el, ed, ec = eng.search(qs, k)
+    el, ed, ec = eng.search(qs, k, mask)
     eng.close()
+    kind = kind + ("*" if i8only else "") + ("+m" if mask is not None else "")
     ok = np.array_equal(fl, el) and np.array_equal(fc, ec) and np.array_equal(fd, ed)
     bad += not ok
-    print(f"case {case:3d} {'ok ' if ok else 'BAD'} rows {kind:9s} queries {qkind:9s} {space:6s} n {n:6d} d {d:4d} nq {nq:3d} k {k:2d} "
+    print(f"case {case:3d} {'ok ' if ok else 'BAD'} rows {kind:12s} queries {qkind:9s} {space:6s} n {n:6d} d {d:4d} nq {nq:3d} k {k:2d} "
           f"dtype {st['bound_dtype']} fallback {st['fallback_queries']:3d} rescored/q {st['candidates_rescored'] / max(1, nq):8.1f}", flush=True)
 print(f"{args.cases - bad} of {args.cases} cases identical to the exact scan in {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
