@@ -1744,6 +1744,7 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                 if (env_int("MLVDB_SCAN_DIAG", 0) == 213)
                     return launch_scan_asm<SPACE, 4, 8, true, 213, true, 2, true>(a, row_begin, row_end, s, info);
                 switch (env_int("MLVDB_SCAN_DIAG", 0)) {
+                    case 223: return launch_scan_asm<SPACE, 4, 8, true, 223, true, 2, true>(a, row_begin, row_end, s, info);
                     case 224: return launch_scan_asm<SPACE, 4, 8, true, 224, true, 2, true>(a, row_begin, row_end, s, info);
                     case 225: return launch_scan_asm<SPACE, 4, 8, true, 225, true, 2, true>(a, row_begin, row_end, s, info);
                     case 226: return launch_scan_asm<SPACE, 4, 8, true, 226, true, 2, true>(a, row_begin, row_end, s, info);

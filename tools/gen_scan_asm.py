@@ -295,7 +295,8 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
         for m in range(MT):
             c = "0" if (zero_first and h == 0) else acc(m, n)
             op = "v_mfma_i32_16x16x64_i8" if I8 else "v_mfma_f32_16x16x32_bf16"
-            s.emit(f"{op} {acc(m, n)}, {ring(b, m)}, %[t{f % QD}], {c}")
+            if "nomfma" not in DBG:
+                s.emit(f"{op} {acc(m, n)}, {ring(b, m)}, %[t{f % QD}], {c}")
             if final and h == 1:
                 # the accumulators of query tile n - 2 are complete (their last MFMAs were issued four MFMAs ago)
                 if n < 2:
@@ -942,7 +943,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_diag224.inc", "scan_asm_diag225.inc", "scan_asm_diag226.inc", "scan_asm_diag227.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc", "scan_asm_cosine_i8_va_r6b3.inc", "scan_asm_cosine_i8_va_q3d.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_diag223.inc", "scan_asm_diag224.inc", "scan_asm_diag225.inc", "scan_asm_diag226.inc", "scan_asm_diag227.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc", "scan_asm_cosine_i8_va_r6b3.inc", "scan_asm_cosine_i8_va_q3d.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -986,7 +987,8 @@ def main():
     (Path(args.outdir) / "scan_asm_diag212.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
     DBG.clear()
     # the folded body without its X loads / B reads / Q staging (and never taking a hit: the bounds are garbage then)
-    for code, knobs in ((224, {"nox", "nohit"}), (225, {"nolds", "nohit"}), (226, {"nox", "nolds", "nohit"}), (227, {"noq", "nohit"})):
+    for code, knobs in ((224, {"nox", "nohit"}), (225, {"nolds", "nohit"}), (226, {"nox", "nolds", "nohit"}), (227, {"noq", "nohit"}),
+                        (223, {"nomfma", "nohit"})):   # 223: no MFMAs at all: the kernel's streams (X, Q, B reads, barriers) alone
         DBG.update(knobs)
         (Path(args.outdir) / f"scan_asm_diag{code}.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
         DBG.clear()
@@ -1036,7 +1038,7 @@ def main():
     disp.append('#include "scan_asm_diag209.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 210 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_diag210.inc"')
-    for code in (212, 213, 224, 225, 226, 227):
+    for code in (212, 213, 223, 224, 225, 226, 227):
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
         disp.append(f'#include "scan_asm_diag{code}.inc"')
     disp.append("#endif")
