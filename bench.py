@@ -31,12 +31,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.
 
 
 def kernel_source_sha16() -> str:
-    """Hash of the sources the scan kernels are built from: ties a committed PMC measurement to a kernel version."""
+    """Hash of what the default scan kernels are built from -- the generated int8 bodies, the shared device helpers and
+    the C++ wrapper of the assembly (addresses, in-kernel scatter) -- so that a committed PMC measurement is tied to a
+    kernel version; variant / diagnostic plumbing elsewhere in the sources does not invalidate it."""
     import hashlib
 
     h = hashlib.sha256()
-    for rel in ("mlvectordb_amd/csrc/kernels_filter.hip", "mlvectordb_amd/csrc/scan_common.h", "tools/gen_scan_asm.py"):
-        h.update((ROOT / rel).read_bytes())
+    csrc = ROOT / "mlvectordb_amd" / "csrc"
+    for rel in ("scan_asm_cosine_i8_va.inc", "scan_asm_l2_i8_va.inc", "scan_asm_ip_i8_va.inc", "scan_common.h"):
+        h.update((csrc / rel).read_bytes())
+    src = (csrc / "kernels_filter.hip").read_text()
+    a = src.index("void filter_scan_asm_kernel(")
+    b = src.index("// ------------------------------------------------------------------ threshold update + compaction")
+    h.update(src[a:b].encode())
     return h.hexdigest()[:16]
 
 
