@@ -437,7 +437,6 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
             fprintf(stderr, "[mlvdb] scan rows [%lld, %lld): %llu entries appended (%.1f per query), max per wave %llu\n",
                     (long long)b, (long long)e, (unsigned long long)sum, (double)sum / fa.nq, (unsigned long long)mx);
         }
-        HIP_TRY(h, launch_filter_scatter(fa, info, s));
         h->stats.scan_launches += 1;
         h->stats.rows_scanned += e - b;
         // int8 bounds are loose: thresholds from exact scores of the k best bounds; the same kernel prunes the lists
@@ -1083,8 +1082,7 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
             HIP_TRY(h, launch_filter_range_thr(fa, radius, s));
             ScanInfo info;
             HIP_TRY(h, launch_filter_scan(fa, 0, h->total, s, &info));
-            HIP_TRY(h, launch_filter_scatter(fa, info, s));
-        } else {
+            } else {
             HIP_TRY(h, launch_exact_range_scan(fa, radius, nullptr, 0, s));
         }
         rc = scan_event(h, s, false);

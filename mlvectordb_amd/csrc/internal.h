@@ -168,10 +168,9 @@ struct FilterArgs {
 hipError_t launch_filter_prep(const FilterArgs& a, hipStream_t s);
 // seed thresholds from exact kNN distances of a prefix of the corpus: seed_d64[q][k]
 hipError_t launch_filter_seed_thr(const FilterArgs& a, const double* seed_d64, int32_t k, hipStream_t s);
-// The assembly scan leaves its hits in per-wave buffers: launch_filter_scatter (same stream, right after) moves
-// them into the per-query lists.  Two calls so that the caller can time the scan kernel alone.
+// What a scan launch reports back (tuning aids).  The assembly scan stages its hits per wave in LDS and its own tail
+// moves them into the per-query candidate lists (round 1 had a separate scatter launch for that).
 struct ScanInfo {
-    int scatter_grid = 0;  // 0: nothing to scatter
     int nw = 0;
     int dbg = 0;
     int i8 = 0;  // int8 scan, entries in units of the query's scale: 1 cosine (u = w sq8 + ke), 2 ip (u = w sq8)
@@ -184,7 +183,6 @@ hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s);
 bool filter_refine_can_fuse(const FilterArgs& a);
 hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, bool fuse, hipStream_t s);
 hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info);
-hipError_t launch_filter_scatter(const FilterArgs& a, const ScanInfo& info, hipStream_t s);
 // dense seeding pass over rows [0,row_end), row_end <= kSeedRows: all bounds -> candidate lists -> thresholds (update)
 constexpr int kSeedRows = 3840;  // a multiple of every scan tile (128, 192) and <= kCandCap
 hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t k, hipStream_t s);

@@ -582,61 +582,6 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
     }
 }
 
-// ------------------------------------------------------------------ append buffers -> candidate lists
-// One block per workgroup of the preceding assembly scan: the entries of its nw wave buffers
-// (u[cap], row[cap], q[cap] each) go to the per-query lists.  Entries are counted per query in LDS
-// first, so the block issues one device-scope atomic per query it has entries for (a per-entry
-// atomic on 256 hot counters cost ~90 us per launch).
-__global__ __launch_bounds__(256) void filter_scatter_kernel(const FilterArgs a, const int cap, const int nw, const int dbg,
-                                                             const int i8) {
-    __shared__ uint32_t hist[kFilterQueries], base[kFilterQueries];
-#ifdef MLVDB_SCAN_DIAGNOSTICS
-    if (dbg && threadIdx.x < (unsigned)nw && (blockIdx.x % 64) == 0) {  // MLVDB_SCAN_DIAG=108: in-kernel cycle stamps
-        const uint32_t* bq = reinterpret_cast<const uint32_t*>(
-            reinterpret_cast<const char*>(a.wgbuf + (size_t)(blockIdx.x * nw + threadIdx.x) * cap) + (size_t)cap * 8);
-        printf("stamp wg %d wave %d: barrier-parked %u of %u cycles, entries %u\n", (int)blockIdx.x, (int)threadIdx.x,
-               bq[cap - 2], bq[cap - 1], a.wgcnt[blockIdx.x * nw + threadIdx.x]);
-    }
-#else
-    (void)dbg;
-#endif
-    hist[threadIdx.x] = 0;
-    __syncthreads();
-    for (int w = 0; w < nw; ++w) {
-        const int wb = blockIdx.x * nw + w;
-        const uint32_t n = min(a.wgcnt[wb], (uint32_t)cap);  // entries past the buffer were flagged by the scan
-        const uint32_t* bq = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(a.wgbuf + (size_t)wb * cap) + (size_t)cap * 8);
-        for (uint32_t i = threadIdx.x; i < n; i += 256) atomicAdd(&hist[bq[i]], 1u);
-    }
-    __syncthreads();
-    {
-        const uint32_t c = hist[threadIdx.x];
-        base[threadIdx.x] = c ? atomicAdd(&a.cnt[threadIdx.x], c) : 0u;
-        if (c && base[threadIdx.x] + c > (uint32_t)a.cand_cap) a.overflow[threadIdx.x] = 1u;
-        hist[threadIdx.x] = 0;
-    }
-    __syncthreads();
-    for (int w = 0; w < nw; ++w) {
-        const int wb = blockIdx.x * nw + w;
-        const uint32_t n = min(a.wgcnt[wb], (uint32_t)cap);
-        const char* buf = reinterpret_cast<const char*>(a.wgbuf + (size_t)wb * cap);
-        const float* bu = reinterpret_cast<const float*>(buf);
-        const int32_t* br = reinterpret_cast<const int32_t*>(buf + (size_t)cap * 4);
-        const uint32_t* bq = reinterpret_cast<const uint32_t*>(buf + (size_t)cap * 8);
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            const uint32_t q = bq[i];
-            const uint32_t slot = base[q] + atomicAdd(&hist[q], 1u);
-            if (slot < (uint32_t)a.cand_cap) {
-                CandEntry e;
-                // int8 scan: the stored value is in units of the query's scale (cosine: w, ip: w + ke' |x|)
-                e.u = i8 == 1 ? __builtin_fmaf(bu[i], a.sq8[q], a.ke8[q]) : (i8 == 2 ? bu[i] * a.sq8[q] : bu[i]);
-                e.row = br[i];
-                a.cand[(size_t)q * a.cand_cap + slot] = e;
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------ the scan, hand-written for gfx950
 // Same geometry, data flow and bounds as filter_scan_kernel<.., kMT = 2, XB = true> above, but the
 // whole body -- prologue, persistent tile loop, k-loop, admission test, append path -- is the
@@ -1707,7 +1652,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     if (hipError_t e = ensure_dynamic_lds(configured, reinterpret_cast<const void*>(kern), (int)lds); e != hipSuccess)
         return e;
     kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end);
-    info->scatter_grid = 0;  // the kernel's own tail moves the entries into the candidate lists: no scatter launch
+    // (the kernel's own tail moves the entries into the candidate lists: there is no scatter launch)
     info->nw = NW;
     info->dbg = QD == 108 ? 1 : 0;
     info->i8 = !scan_code_i8(QD) ? 0 : (SPACE == kSpaceCosine ? 1 : (SPACE == kSpaceIp ? 2 : 0));  // how the scatter turns stored values into bounds
@@ -1873,11 +1818,6 @@ hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t ro
     }
 }
 
-hipError_t launch_filter_scatter(const FilterArgs& a, const ScanInfo& info, hipStream_t s) {
-    if (info.scatter_grid == 0) return hipSuccess;  // the compiler-scheduled kernel appends to the lists itself
-    filter_scatter_kernel<<<info.scatter_grid, 256, 0, s>>>(a, kWgCap / info.nw, info.nw, info.dbg, info.i8);
-    return hipGetLastError();
-}
 
 static hipError_t launch_update(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s) {
     const size_t lds = (size_t)kCandCap * (sizeof(CandEntry) + sizeof(uint32_t)) + 256 * 4 + 64;  // hist + s_scan[16]

@@ -36,7 +36,7 @@ energy per MFMA, which is what counts on a power-bound pipe (tools/probe).
     maximum against the threshold; only if some lane passes, an out-of-line routine appends
     (bound, row, query) entries to the WAVE's private buffer, staged in LDS until the kernel ends:
     the fill count lives in an SGPR, slots come from v_mbcnt -- no atomic, no wait, and no global
-    store in the loop (see gen_slow).  filter_scatter_kernel then moves the entries into the
+    store in the loop (see gen_slow).  The kernel's C++ tail then moves the entries into the
     per-query lists.  The routine's memory
     operations are younger than every prefetch, so the counted waits elsewhere stay sufficient.
 """
@@ -425,7 +425,7 @@ def gen_admission(space):
         # int8 shadow, cosine: r_j = sx/(|x|+1e-30) of the row (NaN: tombstoned), p_j = the row's own rounding error,
         # accumulators = exact integer dot products I; the test is float(I)*r_j + p_j*K >= T[q] with T = (thr - ke8)/sq8
         # rounded down and K = (1 + max eq8)/min sq8 (filter_prep8_fin_kernel); the append path stores the left-hand side,
-        # filter_scatter_kernel turns it into the bound u = w*sq8 + ke8
+        # the kernel's tail (the in-kernel scatter) turns it into the bound u = w*sq8 + ke8
         if "noadm" in DBG:   # timing diagnostic: no admission test at all (labels only: the hit stubs refer to them)
             for n in range(16):
                 a(f".Lback{n}_%=:")
@@ -494,7 +494,7 @@ def gen_admission(space):
         if I8:
             # int8 shadow, l2 / ip: w = float(I) * sx_j takes the place of the bf16 dot product; the per-query constants in
             # LDS are rescaled by the query's scale (filter_scan_asm_kernel): ip  w + ke' |x| >= thr/sq8 (the append path
-            # stores that, filter_scatter_kernel multiplies by sq8), l2  sq' (w + ke' |x|) + p1 >= thr
+            # stores that, the in-kernel scatter multiplies by sq8), l2  sq' (w + ke' |x|) + p1 >= thr
             for j in range(NR):
                 if not VA:
                     a(f"v_cvt_f32_i32 %[u{j}], %[u{j}]")
@@ -613,38 +613,6 @@ def gen_flush(NW):
     for) -- no separate scatter launch, no round trip of the entries through global memory.  The assembly only has to
     make sure everything it issued has landed; the wave's entry count leaves through the wcnt operand."""
     return ["s_waitcnt vmcnt(0) lgkmcnt(0)"]   # ring / Q sets still in flight that nobody consumes; staged entries landed
-
-
-def gen_flush_to_global(NW):
-    """(Superseded by the in-kernel scatter; kept for reference.)  The wave's staged entries go to its global buffer,
-    its count to wgcnt."""
-    lcw = lds_stage_cap(NW, MT)
-    return ["s_waitcnt vmcnt(0) lgkmcnt(0)",   # ring / Q sets still in flight that nobody consumes; staged entries landed
-            f"s_min_u32 %[st0], %[wcnt], 0x{lcw:x}",
-            "v_mbcnt_lo_u32_b32 %[e0], -1, 0",
-            "v_mbcnt_hi_u32_b32 %[e0], -1, %[e0]",          # e0 = lane
-            ".Lflush_%=:",
-            "v_cmp_gt_u32 vcc, %[st0], %[e0]",
-            "s_and_saveexec_b64 s[76:77], vcc",
-            "s_cbranch_execz .Lflushed_%=",
-            "v_lshl_add_u32 %[e1], %[e0], 2, %[stg]",
-            "ds_read_b32 %[e2], %[e1]",
-            f"ds_read_b32 %[e3], %[e1] offset:{lcw * 4}",
-            f"ds_read_b32 %[e4], %[e1] offset:{lcw * 8}",
-            "v_lshlrev_b32 %[e1], 2, %[e0]",
-            "s_waitcnt lgkmcnt(0)",
-            "global_store_dword %[e1], %[e2], %[wgbu]",
-            "global_store_dword %[e1], %[e3], %[wgbr]",
-            "global_store_dword %[e1], %[e4], %[wgbq]",
-            "v_add_u32 %[e0], 64, %[e0]",
-            "s_mov_b64 exec, s[76:77]",
-            "s_branch .Lflush_%=",
-            ".Lflushed_%=:",
-            "s_mov_b64 exec, -1",
-            "v_mov_b32 %[e0], %[wcnt]",
-            "v_mov_b32 %[e1], 0",
-            "global_store_dword %[e1], %[e0], %[wgcp]",     # all lanes store the same value: this wave's entry count
-            "s_waitcnt vmcnt(0)"]
 
 
 def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False, q4=False, place=None, burst=0, q3d=False):
