@@ -325,7 +325,8 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
     if final:   # the last two query tiles: nothing left to hide behind
         gen_pretest(s, 14, 0)
         gen_pretest(s, 14, 1)
-        s.emit("s_nop 3")   # XDL write (query tile 15's MFMAs, 10 instructions back) -> VALU read
+        s.emit("s_nop 7")   # XDL write (query tile 15's MFMAs, 8 instructions back) -> VALU read: 16 wait states with this
+        #                     (an 8-pass MFMA needs 11; once per tile, so the margin is free)
         gen_pretest(s, 15, 0)
         gen_pretest(s, 15, 1)
     # advance the Q cursor (chunk c+2 -> c+3, wrapping) and publish the chunk just staged
