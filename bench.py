@@ -239,7 +239,9 @@ def main() -> None:
     n_local, d, k = args.rows_per_gpu, args.dim, args.k
     batch = args.batch or (256 if world == 1 else 1024)
     row0 = rank * n_local
-    threads = args.gen_threads or max(2, min(16, (os.cpu_count() or 8) // max(1, min(world, 8))))
+    # generator threads = 1M-row chunks (3 GB each) in flight per rank: bounded so that 8 ranks on one host stay under
+    # ~75 GB of generation buffers in total (all 10 chunks of a shard at once would be 30 GB per rank)
+    threads = args.gen_threads or max(2, min(16, (os.cpu_count() or 8) // max(1, min(world, 8)), max(2, 24 // world)))
 
     # ---- shard: seeded N(0,1) rows, generated on the host in 1M-row chunks, appended to HBM
     t0 = time.perf_counter()
