@@ -73,7 +73,7 @@ struct mlvdb_index {
     bool mask_active = false;  // h->rn is a masked copy (mlvdb_search_batch_filtered)
     bool mask_pairs_ready = false;  // ... and rp8_masked holds the masked copy of the int8 shadow's row pairs
     DevBuf rp8_masked;
-    DevBuf qimg, fmisc, cand, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, io_d64, counters, labels_in;
+    DevBuf qimg, fmisc, cand, rescr, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, io_d64, counters, labels_in;
     DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
     uint32_t* host_flags = nullptr;  // pinned, kFilterQueries words
     bool deferred = false;           // search_host: the pass left its overflow flags in host_flags instead of launching the
@@ -265,6 +265,7 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     HIP_TRY(h, h->qimg.ensure(filter_qimg_bytes(h->ld)));
     HIP_TRY(h, h->fmisc.ensure(8 * kFilterQueries * sizeof(uint32_t)));
     HIP_TRY(h, h->cand.ensure((size_t)kFilterQueries * kCandCap * sizeof(CandEntry)));
+    HIP_TRY(h, h->rescr.ensure((size_t)kFilterQueries * kCandCap * sizeof(RangeHit)));  // exact scores of the rescored candidates
     if (h->Xb || h->i8_only) {  // the assembly scan appends through workgroup-private buffers
         HIP_TRY(h, h->wgbuf.ensure((size_t)kScanMaxGrid * kWgCap * sizeof(WgEntry)));
         HIP_TRY(h, h->wgcnt.ensure((size_t)kScanMaxGrid * 8 * sizeof(uint32_t)));
@@ -291,6 +292,7 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     fa.keb = h->fmisc.as<float>() + 5 * kFilterQueries;
     fa.ke8 = h->fmisc.as<float>() + 6 * kFilterQueries;  // 257 floats
     fa.sqmin = h->fmisc.as<uint32_t>() + 7 * kFilterQueries + 128;
+    fa.rs = h->rescr.as<RangeHit>();
     fa.cand = h->cand.as<CandEntry>();
     fa.cand_cap = kCandCap;
     fa.wgbuf = h->wgbuf.as<WgEntry>();
@@ -443,11 +445,69 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
         // (the update kernel's bound-derived threshold could only be lower) unless the query does not fit beside them
         const bool fuse = fa.X8 && filter_refine_can_fuse(fa);
         if (fa.X8) HIP_TRY(h, launch_filter_refine_thr(fa, k, -1, fuse, s));
+#ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: where the refine kernel's time goes (its blocks stamp their phases)
+        if (fa.X8 && fa.wgbuf && getenv("MLVDB_DEBUG_REFINE")) {
+            std::vector<unsigned long long> st((size_t)fa.nq * 8, 0ull);
+            HIP_TRY(h, hipMemcpyAsync(st.data(), fa.wgbuf, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+            unsigned long long t0 = ~0ull, t5 = 0;
+            double ph[5] = {0, 0, 0, 0, 0};
+            for (int q = 0; q < fa.nq; ++q) {
+                t0 = std::min(t0, st[(size_t)q * 8]);
+                t5 = std::max(t5, st[(size_t)q * 8 + 5]);
+                for (int i = 0; i < 5; ++i) ph[i] += (double)(st[(size_t)q * 8 + i + 1] - st[(size_t)q * 8 + i]) * 0.01 / fa.nq;
+            }
+            fprintf(stderr, "[mlvdb] refine rows [%lld, %lld): first start -> last end %.1f us; mean per block: load+keys %.1f, "
+                    "select+compact %.1f, gather %.1f, rank+thr %.1f, prune %.1f us\n", (long long)b, (long long)e,
+                    (double)(t5 - t0) * 0.01, ph[0], ph[1], ph[2], ph[3], ph[4]);
+        }
+#endif
         if (!fuse) HIP_TRY(h, launch_filter_update(fa, k, s));
     }
     // counters: [0] rescored pairs, [1] fallback queries (accumulated over the passes of a call), [2] flag count
     unsigned long long* stats = h->counters.as<unsigned long long>();
+#ifdef MLVDB_SCAN_DIAGNOSTICS
+    if (fa.wgbuf && getenv("MLVDB_DEBUG_REFINE")) HIP_TRY(h, hipMemsetAsync(fa.wgbuf, 0, (16384 + 1024) * 8, s));
+#endif
     HIP_TRY(h, launch_filter_rescore(fa, k, q0, out_labels, out_dist, out_counts, out_d64, stats, s));
+#ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: where the ranking kernel's time goes (its blocks stamp their phases)
+    if (fa.wgbuf && getenv("MLVDB_DEBUG_REFINE")) {
+        std::vector<unsigned long long> st(16384 + 1024, 0ull);
+        HIP_TRY(h, hipMemcpyAsync(st.data(), fa.wgbuf, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(h, hipStreamSynchronize(s));
+        {
+            unsigned long long t0 = ~0ull, tl = 0;
+            double ph[3] = {0, 0, 0};
+            int nw = 0, idle = 0;
+            for (int w = 0; w < 4096; ++w) {
+                const unsigned long long* p = &st[(size_t)w * 4];
+                if (!p[0]) continue;
+                t0 = std::min(t0, p[0]);
+                if (!p[3]) { ++idle; tl = std::max(tl, p[1]); continue; }
+                tl = std::max(tl, p[3]);
+                ++nw;
+                for (int i = 0; i < 3; ++i) ph[i] += (double)(p[i + 1] - p[i]) * 0.01;
+            }
+            fprintf(stderr, "[mlvdb] rescoring, score kernel: %d waves with rows, %d without; first start -> last end %.1f us; mean per "
+                    "working wave (its last 16-row group): prefix %.1f, query %.1f, gather + score %.1f us\n", nw, idle,
+                    (double)(tl - t0) * 0.01, ph[0] / std::max(nw, 1), ph[1] / std::max(nw, 1), ph[2] / std::max(nw, 1));
+        }
+        unsigned long long r0 = ~0ull, rl = 0, rs1 = 0, rmax = 0;
+        double rp[3] = {0, 0, 0};
+        for (int q = 0; q < fa.nq; ++q) {
+            const unsigned long long* p = &st[16384 + (size_t)q * 4];
+            if (!p[0] || !p[3]) continue;
+            r0 = std::min(r0, p[0]);
+            rl = std::max(rl, p[3]);
+            rs1 = std::max(rs1, p[0]);
+            rmax = std::max(rmax, p[3] - p[0]);
+            for (int i = 0; i < 3; ++i) rp[i] += (double)(p[i + 1] - p[i]) * 0.01 / fa.nq;
+        }
+        fprintf(stderr, "[mlvdb] rescoring, rank kernel: first start -> last end %.1f us (last start %.1f us after the first, longest "
+                "block %.1f); mean per block: load %.1f, rank %.1f, output %.1f us\n",
+                (double)(rl - r0) * 0.01, (double)(rs1 - r0) * 0.01, (double)rmax * 0.01, rp[0], rp[1], rp[2]);
+    }
+#endif
     // overflowed queries (adversarial near-ties) are re-run on the exact scan.  The decision stays on
     // the device: the list is compacted there and the scan's blocks exit at once when it is empty,
     // so the call never waits for the host.
@@ -670,7 +730,7 @@ int mlvdb_index_destroy(mlvdb_index* h) {
     if (h->rn) (void)hipFree(h->rn);
     if (h->Xb) (void)hipFree(h->Xb);
     for (DevBuf* b : {&h->stage, &h->qpad, &h->qaux, &h->partial, &h->qsel, &h->seed_lab, &h->seed_dist, &h->seed_cnt,
-                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->qerr, &h->rowerr, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt, &h->io_d64, &h->gather_out, &h->gather_lab, &h->cand_range, &h->rhits, &h->rhit_cnt, &h->rp8_masked, &h->x8, &h->rp8, &h->rowerr8, &h->qimg8, &h->sq8,
+                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->rescr, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->qerr, &h->rowerr, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt, &h->io_d64, &h->gather_out, &h->gather_lab, &h->cand_range, &h->rhits, &h->rhit_cnt, &h->rp8_masked, &h->x8, &h->rp8, &h->rowerr8, &h->qimg8, &h->sq8,
                       &h->counters, &h->labels_in, &h->page_lab, &h->page_dist, &h->page_cnt, &h->page_d64, &h->cur_d,
                       &h->cur_l})
         b->release();

@@ -162,6 +162,7 @@ struct FilterArgs {
     float* ke8;             // [257] cosine: the query's own int8 error term (row errors are per row); [256] = K = (1 + max eq8)/min sq8
     float* keb;             // [256] the bf16 error term: what the (bf16) seeding pass adds, while `ke` covers both kinds of entry
     unsigned int* sqmin;    // two device scalars: bits of the smallest sq8 / of the largest query error of the pass's queries
+    struct RangeHit* rs;    // kNN passes: [256][kCandCap] exact (distance, label) of every rescored candidate (filter_rescore_score_kernel -> _rank_kernel)
     WgEntry* wgbuf;         // [kScanMaxGrid][kWgCap] append buffers of one scan launch, one slice per wave
     uint32_t* wgcnt;        // [kScanMaxGrid * 8] entries appended per wave (may exceed the slice: the excess was flagged as overflow)
 };

@@ -955,80 +955,164 @@ __global__ __launch_bounds__(kUpdThreads) void filter_update_kernel(const Filter
 }
 
 // ------------------------------------------------------------------ exact rescoring
-// One block per query: the surviving rows are scored by the exact-scan arithmetic
-// (accumulate_rows, 16 gathered rows per wave step) and ranked (distance, label).
-constexpr int kRescoreWaves = 16;  // 256 candidates per gather step: the usual list (~130 on int8 bounds) is one step
+// Two kernels.  filter_rescore_score_kernel: the surviving rows of ALL queries are scored by the exact-scan arithmetic
+// (accumulate_rows) as one flat list of 16-row groups dealt out to the waves of the grid in turn, so that every CU gathers
+// the same number of rows; the exact (distance, label) pairs go to a.rs.  Why: a CU pulls ~24 GB/s from HBM
+// (MI355X_MICROARCH.md), a row is 48 pieces of 64 bytes in half-used 128-byte lines, so 100 rows cost a CU ~27 us however
+// the loads are issued -- one block per query made the kernel as slow as its longest list (70-78 us for the 10M x 768
+// wave, mean block 33 us), eight blocks per query left the CUs with 2..4 blocks each (46-56 us):
+// profiles/r02/refine_rescore_phase_stamps_10m.txt.
+// filter_rescore_rank_kernel: one block per query ranks the pairs by (distance, label) and writes the answer.  (One kernel
+// whose last-finishing block ranks was tried first: the agent-scope fences it needs write the XCD's L2 back per block --
+// 264 us instead of 87.  The kernel boundary does that once.)
+constexpr int kRescoreWaves = 16;      // waves per block (fewer when that many copies of the query do not fit in LDS)
+constexpr int kRescoreGrid = 256;      // one block per CU: each asks for more than half of a CU's LDS, so no two share a CU, and the
+                                       // 16-row groups are dealt to the blocks in turn -- every CU gathers the same number of rows
+                                       // (+-16), each group on a wave of its own while there are at most 4096 of them
+constexpr int kRescorePF = 8;          // column groups per prefetch bank (accumulate_rows; the summation order is fixed).  A whole
+                                       // 768-column row in flight per lane (24 groups, two banks, 8-wave blocks) was slower: the
+                                       // gather is bound by bytes per CU, not by round trips
 constexpr int kRescoreRankMax = 2048;  // lists up to this length are ranked by counting in LDS
+constexpr int kRankWaves = 16;         // waves of the ranking block
 template <int SPACE>
-__global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_kernel(const FilterArgs a, const int32_t k, const int32_t q0,
-                                                             int64_t* out_labels, float* out_dist,
-                                                             int32_t* out_counts, double* out_d64,
-                                                             unsigned long long* rescored) {
+__global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_score_kernel(const FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t pre[kFilterQueries + 1];  // 16-row groups of the queries before q (overflowed queries: none)
     const int ld = a.ld;
-    double* qs = reinterpret_cast<double*>(smem);                                        // [ld]
-    double* ed = qs + ld;                                                                // [kRescoreRankMax] exact distances
-    int32_t* el = reinterpret_cast<int32_t*>(ed + kRescoreRankMax);                      // [kRescoreRankMax] labels
-    double(*sd)[64] = reinterpret_cast<double(*)[64]>(el + kRescoreRankMax);             // [waves][64]
-    int32_t(*sl)[64] = reinterpret_cast<int32_t(*)[64]>(sd + kRescoreWaves);             // [waves][64]
-    int32_t* s_nvalid = reinterpret_cast<int32_t*>(sl + kRescoreWaves);
-    const int q = blockIdx.x;
-    if (q >= a.nq || a.overflow[q]) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, r = lane & 15;
-    for (int c = threadIdx.x; c < ld; c += kRescoreWaves * 64) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
-    if (threadIdx.x == 0) *s_nvalid = 0;
+    const int nwaves = blockDim.x >> 6;
+    double* qs = reinterpret_cast<double*>(smem) + (size_t)wave * ld;  // this wave's copy of its current query
+#ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: phase stamps (100 MHz) of every wave, read back by api.hip (MLVDB_DEBUG_REFINE)
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.wgbuf) + ((size_t)blockIdx.x * nwaves + wave) * 4;
+#define SCORE_STAMP(i) do { if (lane == 0 && a.wgbuf) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SCORE_STAMP(i) do { } while (0)
+#endif
+    SCORE_STAMP(0);
+    if (wave == 0) {  // lane l: queries 4l .. 4l+3; inclusive scan over the lanes (a serial loop over LDS here cost 12 us)
+        uint32_t n[4], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = 4 * lane + i;
+            n[i] = q < a.nq && !a.overflow[q] ? (min(a.cnt[q], (uint32_t)kCandCap) + 15u) >> 4 : 0u;
+            sum += n[i];
+        }
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        uint32_t run = incl - sum;
+        if (lane == 0) pre[0] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            run += n[i];
+            pre[4 * lane + i + 1] = run;
+        }
+    }
     __syncthreads();
-    const double qinv = a.qaux[q];
-    const uint32_t cnt = min(a.cnt[q], (uint32_t)kCandCap);
-    const CandEntry* list = a.cand + (int64_t)q * kCandCap;
-    const bool by_rank = cnt <= (uint32_t)kRescoreRankMax;
-    WaveTopK top;
-    top.init();
-    for (uint32_t i0 = wave * 16; i0 < cnt; i0 += kRescoreWaves * 16) {
-        const uint32_t idx = i0 + r;
+    const uint32_t total = pre[kFilterQueries];
+    SCORE_STAMP(1);
+    const int g = lane >> 4, r = lane & 15;
+    int cur = -1;
+    double qinv = 0.0;
+    for (uint32_t u = blockIdx.x + gridDim.x * wave; u < total; u += gridDim.x * nwaves) {
+        int lo = 0, hi = kFilterQueries;  // the query with pre[q] <= u < pre[q + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= u) lo = mid;
+            else hi = mid;
+        }
+        const int q = lo;
+        if (q != cur) {  // (wave-private LDS: no barrier; the wave's own earlier reads are done -- its loop is in order)
+            for (int c = lane; c < ld; c += 64) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
+            qinv = a.qaux[q];
+            cur = q;
+        }
+        SCORE_STAMP(2);
+        const uint32_t cnt = min(a.cnt[q], (uint32_t)kCandCap);
+        const CandEntry* list = a.cand + (int64_t)q * kCandCap;
+        RangeHit* rs = a.rs + (int64_t)q * kCandCap;
+        const uint32_t idx = (u - pre[q]) * 16 + r;
         const bool have = idx < cnt;
         const int32_t row = have ? list[idx].row : 0;
         const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 16 + g * 4};
         double acc[1][1], nx[1];
-        accumulate_rows<SPACE, 1, 1, 8>(base, qs, ld, g, acc, nx);
+        accumulate_rows<SPACE, 1, 1, kRescorePF>(base, qs, ld, g, acc, nx);
         const double dist = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
-        bool live = have && lane < 16;
-        if (live) {
+        if (have && lane < 16) {
             const float nrm = a.rn[row];
-            live = nrm == nrm;
+            const bool live = nrm == nrm;
+            RangeHit hit;
+            hit.d = live ? dist : __builtin_inf();
+            hit.l = live ? row : kNoLabel;
+            hit.pad = 0;
+            rs[idx] = hit;
         }
-        if (by_rank) {
-            if (have && lane < 16) {
-                ed[idx] = live ? dist : __builtin_inf();
-                el[idx] = live ? row : kNoLabel;
-            }
-        } else {
-            top.offer(live, dist, row, k, lane);
-        }
+        SCORE_STAMP(3);
     }
+#undef SCORE_STAMP
+}
+
+__global__ __launch_bounds__(kRankWaves * 64) void filter_rescore_rank_kernel(const FilterArgs a, const int32_t k, const int32_t q0,
+                                                                                  int64_t* out_labels, float* out_dist,
+                                                                                  int32_t* out_counts, double* out_d64,
+                                                                                  unsigned long long* rescored) {
+    __shared__ double ed[kRescoreRankMax];  // exact distances
+    __shared__ int32_t el[kRescoreRankMax];  // labels
+    __shared__ double sd[kRankWaves][64];
+    __shared__ int32_t sl[kRankWaves][64];
+    __shared__ int32_t s_nvalid;
+    const int q = blockIdx.x;
+#ifdef MLVDB_SCAN_DIAGNOSTICS
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.wgbuf) + 16384 + (size_t)blockIdx.x * 4;
+#define RANK_STAMP(i) do { if (threadIdx.x == 0 && a.wgbuf) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RANK_STAMP(i) do { } while (0)
+#endif
+    RANK_STAMP(0);
+    if (q >= a.nq || a.overflow[q]) return;
+    const uint32_t cnt = min(a.cnt[q], (uint32_t)kCandCap);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const RangeHit* rs = a.rs + (int64_t)q * kCandCap;
     const int64_t o = (int64_t)(q0 + q) * k;
-    if (by_rank) {
-        // every entry counts how many entries precede it in (distance, label) order: that is its rank
+    if (threadIdx.x == 0) s_nvalid = 0;
+    if (cnt <= (uint32_t)kRescoreRankMax) {
+        for (uint32_t i = threadIdx.x; i < cnt; i += kRankWaves * 64) {
+            const RangeHit h = rs[i];
+            ed[i] = h.d;
+            el[i] = h.l;
+        }
         __syncthreads();
+        RANK_STAMP(1);
+        // an entry's rank = how many entries precede it in (distance, label) order; one entry per wave at a time, 64
+        // comparisons per step by ballot, given up as soon as k entries precede it (wave-uniform).  (A thread per entry
+        // looping over the whole list took 13.5 us for ~100 entries; 4 waves without the early exit 16 us, and 70 us for
+        // the longest list of the wave -- a step is ~200 cycles of dependent LDS latency.)
         int mine = 0;
-        for (uint32_t i = threadIdx.x; i < cnt; i += kRescoreWaves * 64) {
+        for (uint32_t i = wave; i < cnt; i += kRankWaves) {
             const double di = ed[i];
             const int32_t li = el[i];
-            if (li == kNoLabel) continue;
+            if (li == kNoLabel) continue;  // wave-uniform
             ++mine;
             int rank = 0;
-            for (uint32_t j = 0; j < cnt; ++j) rank += entry_less(ed[j], el[j], di, li) ? 1 : 0;
-            if (rank < k) {
+            for (uint32_t j0 = 0; j0 < cnt && rank < k; j0 += 128) {
+                const uint32_t j = j0 + lane, j2 = j + 64;
+                const bool l0 = j < cnt && entry_less(ed[j], el[j], di, li);
+                const bool l1 = j2 < cnt && entry_less(ed[j2], el[j2], di, li);
+                rank += __popcll(__ballot(l0)) + __popcll(__ballot(l1));
+            }
+            if (lane == 0 && rank < k) {
                 out_labels[o + rank] = (int64_t)li;
                 out_dist[o + rank] = (float)di;
                 if (out_d64) out_d64[o + rank] = di;
             }
         }
-        if (mine) atomicAdd(s_nvalid, mine);
+        if (lane == 0 && mine) atomicAdd(&s_nvalid, mine);
         __syncthreads();
-        const int n_out = min(*s_nvalid, k);
-        for (int i = n_out + threadIdx.x; i < k; i += kRescoreWaves * 64) {
+        RANK_STAMP(2);
+        const int n_out = min(s_nvalid, k);
+        for (int i = n_out + threadIdx.x; i < k; i += kRankWaves * 64) {
             out_labels[o + i] = -1;
             out_dist[o + i] = __builtin_inff();
             if (out_d64) out_d64[o + i] = __builtin_inf();
@@ -1037,7 +1121,20 @@ __global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_kernel(cons
             out_counts[q0 + q] = n_out;
             if (rescored) atomicAdd(rescored, (unsigned long long)cnt);
         }
+        RANK_STAMP(3);
+#undef RANK_STAMP
         return;
+    }
+    // long lists (k <= 64 here): per-wave sorted top-k lists, merged by wave 0
+    WaveTopK top;
+    top.init();
+    for (uint32_t b = 0; b < cnt; b += kRankWaves * 64) {
+        const uint32_t i = b + wave * 64 + lane;
+        RangeHit h;
+        h.d = __builtin_inf();
+        h.l = kNoLabel;
+        if (i < cnt) h = rs[i];
+        top.offer(h.l != kNoLabel, h.d, h.l, k, lane);
     }
     sd[wave][lane] = top.d;
     sl[wave][lane] = top.l;
@@ -1046,7 +1143,7 @@ __global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_kernel(cons
     WaveTopK f;
     f.init();
 #pragma unroll
-    for (int w2 = 0; w2 < kRescoreWaves; ++w2)
+    for (int w2 = 0; w2 < kRankWaves; ++w2)
         f.offer(lane < k && sl[w2][lane] != kNoLabel, sd[w2][lane], sl[w2][lane], k, lane);
     const bool valid = lane < k && f.l != kNoLabel;
     if (lane < k) {
@@ -1407,21 +1504,104 @@ hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// Exact thresholds: the k entries with the largest bounds are scored exactly (fp64, the rescoring arithmetic); the
-// smallest of those k scores is a lower bound of the final k-th best score, however loose the bounds are.
-// Runs before filter_update_kernel, which keeps the larger of this and its own bound-derived threshold.
+// Radix select for the refine kernel (256 threads): a key T such that the non-zero keys[0..cnt) that are >= T number at
+// least `want` and at most `cap` -- the caller takes ALL of them, so no ties have to be split and one or two histogram
+// passes usually do (the digits start at the highest bit in which two keys differ: see filter_update_kernel).  Only when
+// more than cap - want + 1 keys are exactly equal at the boundary does the search run to the last bit; then *ties is how
+// many of the entries with key == T belong to the selection (the caller takes those with the lowest list indices), else
+// *ties = 0xffffffff (take every key >= T).  *total = size of the selection.  kmin / kmax: smallest / largest non-zero
+// key (block-uniform).  hist: [256], s_sel: [3].  Needs want <= #non-zero keys.
+__device__ __forceinline__ uint32_t radix_select_atleast256(const uint32_t* keys, uint32_t cnt, uint32_t want, uint32_t cap,
+                                                            uint32_t kmin, uint32_t kmax, uint32_t* hist, uint32_t* s_sel,
+                                                            uint32_t* ties, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t want0 = want;
+    const uint32_t diff = kmin ^ kmax;
+    uint32_t prefix = kmax, mask = 0xffffffffu;
+    if (diff != 0) {
+        const int hb = 31 - __builtin_clz(diff);
+        mask = hb == 31 ? 0u : ~((2u << hb) - 1u);
+        prefix = kmax & mask;
+        int shift = hb >= 7 ? hb - 7 : 0, width = hb - shift + 1;
+        for (;;) {
+            __syncthreads();
+            hist[threadIdx.x] = 0;
+            __syncthreads();
+            const uint32_t dmask = (1u << width) - 1u;
+            for (uint32_t idx = threadIdx.x; idx < cnt; idx += 256) {
+                const uint32_t key = keys[idx];
+                if (key != 0 && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & dmask], 1u);
+            }
+            __syncthreads();
+            if (wave == 0) {  // suffix sums over the 256 bins: lane owns bins 4*lane .. 4*lane+3
+                const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+                uint32_t above = h0 + h1 + h2 + h3;
+                uint32_t run = above;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t v = __shfl_down(run, off);
+                    if (lane + off < 64) run += v;
+                }
+                above = run - above;  // keys in bins > 4*lane+3
+                const uint32_t c3 = above + h3, c2 = c3 + h2, c1 = c2 + h1, c0 = c1 + h0;
+                if (above < want && c0 >= want) {  // the highest bin b with (count in bins >= b) >= want
+                    if (c3 >= want) { s_sel[0] = 4 * lane + 3; s_sel[1] = above; s_sel[2] = h3; }
+                    else if (c2 >= want) { s_sel[0] = 4 * lane + 2; s_sel[1] = c3; s_sel[2] = h2; }
+                    else if (c1 >= want) { s_sel[0] = 4 * lane + 1; s_sel[1] = c2; s_sel[2] = h1; }
+                    else { s_sel[0] = 4 * lane; s_sel[1] = c1; s_sel[2] = h0; }
+                }
+            }
+            __syncthreads();
+            prefix |= s_sel[0] << shift;
+            mask |= dmask << shift;
+            want -= s_sel[1];
+            // everything in the chosen bin and above: (want0 - want) strictly above the bin + the bin's own s_sel[2]
+            if (want0 - want + s_sel[2] <= cap) {
+                *ties = 0xffffffffu;
+                *total = want0 - want + s_sel[2];
+                return prefix;  // the bin's lowest possible key: its undecided low bits are zero
+            }
+            if (shift == 0) break;
+            const int next = shift >= 8 ? shift - 8 : 0;
+            width = shift - next;
+            shift = next;
+        }
+        *ties = want;  // more equal keys at the boundary than fit: `want` of them
+        *total = want0;
+        return prefix;
+    }
+    *ties = want;  // all keys equal (and more of them than cap: the caller takes short lists whole)
+    *total = want0;
+    return prefix;
+}
+
+// Exact thresholds: the entries with the largest bounds -- at least `picks` (>= k), at most max(picks, 32) of them -- are
+// scored exactly (fp64); the k-th largest of those exact scores is a lower bound of the final k-th best score, however
+// loose the bounds are (k rows are known to score at least that).  With int8 bounds (error ~ one sigma of the score
+// distribution) the k largest BOUNDS are not the k best rows; a few more picks than k put most of the true top k among
+// them, and the threshold moves up to (nearly) the exact k-th best of the rows seen so far.  Picks: one or two histogram
+// passes find a bound with 16..32 entries at or above it, all of which are taken (the set is deterministic, no ties are
+// split); gather: 8 lanes per row, all of a row's pieces in flight at once (a row is one page walk: latency, not bytes).
+// The sums here are only compared against bounds (1e-9 relative slack below), so their order is free.
 template <int SPACE>
 __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs a, const int32_t k, const int32_t forced_cnt,
-                                                                const bool fuse) {
+                                                                const bool fuse, const int32_t picks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* qs = reinterpret_cast<double*>(smem);                                   // [ld]
-    unsigned long long* red = reinterpret_cast<unsigned long long*>(qs + a.ld);     // [4]
-    int32_t* pick = reinterpret_cast<int32_t*>(red + 4);                            // [64] rows picked
-    double* smin = reinterpret_cast<double*>(pick + 64);                            // [4]
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smin + 4);     // [kCandCap]
+    double* sc = qs + a.ld;                                                         // [64] exact scores of the picks
+    double* smin = sc + 64;                                                         // [1]
+    int32_t* pick = reinterpret_cast<int32_t*>(smin + 1);                           // [64] rows picked
+    uint32_t* hist = reinterpret_cast<uint32_t*>(pick + 64);                        // [256]
+    uint32_t* s_scan = hist + 256;                                                  // [24]
+    uint32_t* keys = s_scan + 24;                                                   // [kCandCap]
     CandEntry* stage = reinterpret_cast<CandEntry*>(keys + kCandCap);               // [kCandCap] (fuse only)
-    uint32_t* s_scan = reinterpret_cast<uint32_t*>(stage + kCandCap);               // [8] (fuse only)
     const int q = blockIdx.x;
+#ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: phase stamps (100 MHz) of every block, read back by api.hip (MLVDB_DEBUG_REFINE)
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.wgbuf) + (size_t)blockIdx.x * 8;
+#define REFINE_STAMP(i) do { if (threadIdx.x == 0 && a.wgbuf) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define REFINE_STAMP(i) do { } while (0)
+#endif
+    REFINE_STAMP(0);
     if (q >= a.nq || a.overflow[q]) return;
     const uint32_t cnt = forced_cnt >= 0 ? (uint32_t)forced_cnt : a.cnt[q];
     if (cnt > (uint32_t)kCandCap) {  // cannot happen without the flag, but never index past the list
@@ -1434,101 +1614,185 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     CandEntry* list = a.cand + (int64_t)q * kCandCap;
     for (int c = threadIdx.x; c < ld; c += 256) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
-    // keys (order key of u, list index) once into LDS; 0 = not a candidate (NaN bound: tombstoned / padding row)
-    for (uint32_t idx = threadIdx.x; idx < cnt; idx += 256) {
-        const CandEntry e = list[idx];
-        if (fuse) stage[idx] = e;
-        keys[idx] = e.u == e.u ? ((unsigned long long)float_order_key(e.u) << 32) | (0xffffffffu - idx) : 0ull;
-    }
-    __syncthreads();
-    // k rounds of argmax, each strictly below the previous pick
-    unsigned long long prev = ~0ull;
-    for (int i = 0; ok && i < k; ++i) {
-        unsigned long long best = 0;
-        for (uint32_t idx = threadIdx.x; idx < cnt; idx += 256) {
-            const unsigned long long key = keys[idx];
-            if (key < prev && key > best) best = key;
+    // order keys of the bounds into LDS; 0 = not a candidate (NaN bound: tombstoned / padding row).  Eight entries per
+    // thread are in flight at once: one load per iteration made this loop 15 dependent round trips on a seed list.
+    uint32_t n_valid = 0, kmin = 0xffffffffu, kmax = 0;
+    for (uint32_t base = 0; base < cnt; base += 256 * 8) {
+        CandEntry e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t idx = base + j * 256 + threadIdx.x;
+            e[j] = list[idx < cnt ? idx : cnt - 1];
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(best, off);
-            best = o > best ? o : best;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t idx = base + j * 256 + threadIdx.x;
+            if (idx >= cnt) continue;
+            if (fuse) stage[idx] = e[j];
+            uint32_t key = 0;
+            if (e[j].u == e[j].u) {
+                key = float_order_key(e[j].u);
+                if (key == 0) key = 1;
+                ++n_valid;
+                kmin = min(kmin, key);
+                kmax = max(kmax, key);
+            }
+            keys[idx] = key;
         }
-        __syncthreads();
-        if (lane == 0) red[wave] = best;
-        __syncthreads();
-        best = red[0];
-        for (int w = 1; w < 4; ++w) best = red[w] > best ? red[w] : best;
-        if (best == 0) {  // fewer than k valid entries (uniform: every thread sees the same value)
-            ok = false;
-            break;
-        }
-        if (threadIdx.x == 0) pick[i] = list[0xffffffffu - (uint32_t)(best & 0xffffffffu)].row;
-        prev = best;
-    }
-    __syncthreads();
-    // exact scores of the picked rows: 16 rows per wave step (lane 16g + r: row r, column quarter g)
-    const int g = lane >> 4, r = lane & 15;
-    const double qinv = a.qaux[q];
-    double smallest = __builtin_inf();
-    for (int i0 = wave * 16; ok && i0 < k; i0 += 64) {
-        const int idx = i0 + r;
-        const bool have = idx < k;
-        const int32_t row = have ? pick[idx] : 0;
-        const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 16 + g * 4};
-        double acc[1][1], nx[1];
-        accumulate_rows<SPACE, 1, 1, 16>(base, qs, ld, g, acc, nx);
-        const double dk = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
-        double sc;
-        if (SPACE == kSpaceCosine) sc = 1.0 - dk;
-        else if (SPACE == kSpaceIp) sc = (1.0 - dk) / qinv;  // qaux = |q| for ip / l2
-        else sc = qinv * qinv - dk;
-        if (have && sc < smallest) smallest = sc;
-        if (have && !(sc == sc)) smallest = -__builtin_inf();
     }
     for (int off = 32; off > 0; off >>= 1) {
-        const double o = __shfl_xor(smallest, off);
-        smallest = o < smallest ? o : smallest;
+        n_valid += __shfl_xor(n_valid, off);
+        kmin = min(kmin, (uint32_t)__shfl_xor(kmin, off));
+        kmax = max(kmax, (uint32_t)__shfl_xor(kmax, off));
     }
-    if (lane == 0) smin[wave] = smallest;
+    if (lane == 0) {
+        s_scan[wave] = n_valid;
+        s_scan[4 + wave] = kmin;
+        s_scan[8 + wave] = kmax;
+    }
+    __syncthreads();
+    n_valid = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+    kmin = min(min(s_scan[4], s_scan[5]), min(s_scan[6], s_scan[7]));
+    kmax = max(max(s_scan[8], s_scan[9]), max(s_scan[10], s_scan[11]));
+    if (n_valid < (uint32_t)k) ok = false;  // fewer than k valid entries (block-uniform)
+    REFINE_STAMP(1);
+    uint32_t m = 0;  // rows picked
+    if (ok) {
+        // at least `want` and at most `cap` rows (32 = one gather step): every entry whose key is >= tkey
+        const uint32_t want = min((uint32_t)max(picks, k), 64u), cap = max(want, 32u);
+        uint32_t tkey = 1, ties = 0xffffffffu;
+        m = n_valid;  // short lists whole
+        if (n_valid > cap) tkey = radix_select_atleast256(keys, cnt, want, cap, kmin, kmax, hist, s_scan + 12, &ties, &m);
+        if (threadIdx.x == 0) s_scan[16] = 0;
+        __syncthreads();
+        const bool split = ties != 0xffffffffu;  // more equal keys at the boundary than fit (block-uniform)
+        for (uint32_t idx = threadIdx.x; idx < cnt; idx += 256) {
+            const uint32_t key = keys[idx];
+            if (key != 0 && (split ? key > tkey : key >= tkey)) pick[atomicAdd(&s_scan[16], 1u)] = fuse ? stage[idx].row : list[idx].row;
+        }
+        if (split && wave == 0) {  // ... the `ties` entries with that key and the lowest list indices (rare: duplicates)
+            uint32_t taken = 0;
+            const uint32_t above = m - ties;
+            for (uint32_t base = 0; base < cnt && taken < ties; base += 64) {
+                const uint32_t idx = base + lane;
+                const bool hit = idx < cnt && keys[idx] == tkey;
+                const unsigned long long bal = __ballot(hit);
+                const uint32_t pos = taken + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                if (hit && pos < ties) pick[above + pos] = fuse ? stage[idx].row : list[idx].row;
+                taken += (uint32_t)__popcll(bal);
+            }
+        }
+    }
+    __syncthreads();
+    REFINE_STAMP(2);
+    // exact scores of the picked rows: 32 rows per step, lane l8 of a row takes the 16-column groups l8, l8 + 8, ...
+    const int rslot = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    const double qinv = a.qaux[q];
+    const int ngroups = ld >> 4;
+    constexpr int G = 6;  // groups in flight per lane (d = 768: all of them)
+    for (uint32_t p0 = 0; p0 < m; p0 += 32) {
+        const uint32_t pidx = p0 + rslot;
+        const bool have = pidx < m;
+        const int32_t row = have ? pick[pidx] : pick[0];
+        const float* rb = a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 16;
+        double acc = 0.0, nx = 0.0;
+        for (int c0 = l8; c0 < ngroups; c0 += 8 * G) {
+            float4 v[G][4];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int cg = c0 + 8 * j < ngroups ? c0 + 8 * j : c0;  // clamped: the loads stay unconditional
+                const float4* src = reinterpret_cast<const float4*>(rb + (int64_t)cg * kGroupFloats);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[j][i] = src[i];
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                if (c0 + 8 * j >= ngroups) continue;
+                const double* qp = qs + (c0 + 8 * j) * 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double x[4] = {(double)v[j][i].x, (double)v[j][i].y, (double)v[j][i].z, (double)v[j][i].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (SPACE == kSpaceL2) {
+                            const double e = qp[4 * i + t] - x[t];
+                            acc = __builtin_fma(e, e, acc);
+                        } else {
+                            acc = __builtin_fma(qp[4 * i + t], x[t], acc);
+                        }
+                        if (SPACE == kSpaceCosine) nx = __builtin_fma(x[t], x[t], nx);
+                    }
+                }
+            }
+        }
+        for (int off = 1; off < 8; off <<= 1) {
+            acc += __shfl_xor(acc, off);
+            if (SPACE == kSpaceCosine) nx += __shfl_xor(nx, off);
+        }
+        const double dk = finish_distance<SPACE>(acc, nx, qinv);
+        double s;
+        if (SPACE == kSpaceCosine) s = 1.0 - dk;
+        else if (SPACE == kSpaceIp) s = (1.0 - dk) / qinv;  // qaux = |q| for ip / l2
+        else s = qinv * qinv - dk;
+        if (have && l8 == 0) sc[pidx] = s == s ? s : -__builtin_inf();
+    }
+    if (threadIdx.x == 0) *smin = -__builtin_inf();
+    __syncthreads();
+    REFINE_STAMP(3);
+    if (ok && threadIdx.x < m) {  // the k-th largest of the m exact scores (ranks are a permutation: one thread writes)
+        const double si = sc[threadIdx.x];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < m; ++j) {
+            const double sj = sc[j];
+            rank += (sj > si || (sj == si && j < threadIdx.x)) ? 1u : 0u;
+        }
+        if (rank == (uint32_t)k - 1u) *smin = si;
+    }
     __syncthreads();
     float thr = a.thr[q];
     if (ok) {
-        double sm = smin[0];
-        for (int w = 1; w < 4; ++w) sm = smin[w] < sm ? smin[w] : sm;
+        const double sm = *smin;
         if (sm > -1.0e300 && sm < 1.0e300) {
             const double mag = SPACE == kSpaceL2 ? qinv * qinv + __builtin_fabs(sm) : __builtin_fabs(sm) + 1.0;
             const float t = float_below(sm - 1e-9 * mag);
             if (t > thr) thr = t;
         }
     }
+    REFINE_STAMP(4);
     if (!fuse) {
         if (threadIdx.x == 0) a.thr[q] = thr;
         return;
     }
     // fused threshold update (what filter_update_kernel does after its own, bound-derived threshold): survivors
     // (u >= thr; NaN bounds drop out) are compacted through LDS in list order
+    // (wave w owns the contiguous quarter [w per, w per + per) of the list, 64 entries per step: conflict-free LDS reads)
+    const uint32_t per = ((cnt + 255u) / 256u) * 64u;
+    const uint32_t wb = min(cnt, (uint32_t)wave * per), we = min(cnt, wb + per);
     uint32_t keep = 0;
-    for (uint32_t idx = threadIdx.x * 32; idx < min(cnt, threadIdx.x * 32 + 32); ++idx) keep += stage[idx].u >= thr ? 1u : 0u;
-    uint32_t incl = keep;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t v = __shfl_up(incl, off);
-        if (lane >= off) incl += v;
+    for (uint32_t base = wb; base < we; base += 64) {
+        const uint32_t idx = base + lane;
+        keep += (uint32_t)__popcll(__ballot(idx < we && stage[idx].u >= thr));
     }
-    if (lane == 63) s_scan[wave] = incl;
+    if (lane == 0) s_scan[wave] = keep;
     __syncthreads();
-    uint32_t pos = incl - keep;
+    uint32_t pos = 0;
     for (int w = 0; w < wave; ++w) pos += s_scan[w];
     const uint32_t new_cnt = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
     if (new_cnt != cnt) {
-        for (uint32_t idx = threadIdx.x * 32; idx < min(cnt, threadIdx.x * 32 + 32); ++idx) {
-            const CandEntry e = stage[idx];
-            if (e.u >= thr) list[pos++] = e;
+        for (uint32_t base = wb; base < we; base += 64) {
+            const uint32_t idx = base + lane;
+            const bool kept = idx < we && stage[idx].u >= thr;
+            const unsigned long long bal = __ballot(kept);
+            if (kept) list[pos + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = stage[idx];
+            pos += (uint32_t)__popcll(bal);
         }
     }
     if (threadIdx.x == 0) {
         a.thr[q] = thr;
         a.cnt[q] = new_cnt;
     }
+    REFINE_STAMP(5);
+#undef REFINE_STAMP
 }
 
 // fuse: also do the threshold update's pruning (then filter_update_kernel is not needed for the round); possible while
@@ -1536,14 +1800,21 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
 bool filter_refine_can_fuse(const FilterArgs& a) { return a.ld <= 2048; }
 
 hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, bool fuse, hipStream_t s) {
-    const size_t lds = (size_t)a.ld * sizeof(double) + 4 * 8 + 64 * 4 + 4 * 8 + (size_t)kCandCap * 8 +
-                       (fuse ? (size_t)kCandCap * sizeof(CandEntry) + 8 * 4 : 0);
+    const size_t lds = (size_t)a.ld * sizeof(double) + 65 * sizeof(double) + 64 * 4 + 256 * 4 + 24 * 4 + (size_t)kCandCap * 4 +
+                       (fuse ? (size_t)kCandCap * sizeof(CandEntry) : 0);
     auto kern = a.space == kSpaceL2 ? filter_refine_thr_kernel<kSpaceL2>
                 : a.space == kSpaceCosine ? filter_refine_thr_kernel<kSpaceCosine> : filter_refine_thr_kernel<kSpaceIp>;
     static std::atomic<uint64_t> configured[3];
     if (hipError_t e = ensure_dynamic_lds(configured[a.space], reinterpret_cast<const void*>(kern), 160 * 1024); e != hipSuccess)
         return e;
-    kern<<<a.nq, 256, lds, s>>>(a, k, forced_cnt, fuse);
+    // rows scored exactly per query and round: 1.5 k (at least 16, at most 64); MLVDB_REFINE_PICKS overrides (tuning; = k
+    // gives "the smallest exact score of the k largest bounds").  10M x 768, k = 10, per wave: 10 picks 1.962 ms, 16 1.935,
+    // 30 1.953, 48 1.976 (profiles/r02/scan_ab_refine_picks_10m.txt): more picks are more page walks per round
+    const char* pv = getenv("MLVDB_REFINE_PICKS");
+    int picks = pv ? atoi(pv) : k + k / 2;
+    if (!pv && picks < 16) picks = 16;
+    picks = picks < k ? k : (picks > 64 ? 64 : picks);
+    kern<<<a.nq, 256, lds, s>>>(a, k, forced_cnt, fuse, picks);
     return hipGetLastError();
 }
 
@@ -1832,17 +2103,18 @@ hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s) {
 
 hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
                                  int32_t* out_counts, double* out_d64, unsigned long long* rescored, hipStream_t s) {
-    const size_t lds = (size_t)a.ld * sizeof(double) + kRescoreRankMax * (sizeof(double) + sizeof(int32_t)) +
-                       kRescoreWaves * 64 * (sizeof(double) + sizeof(int32_t)) + 16;
+    // every wave keeps its current query in LDS as fp64; at least 96 KiB per block, so that the dispatcher cannot put two on one CU
+    int waves = kRescoreWaves;
+    while (waves > 1 && (size_t)waves * a.ld * sizeof(double) > 144 * 1024) waves >>= 1;
+    const size_t lds = std::max((size_t)waves * a.ld * sizeof(double), (size_t)96 * 1024);
     hipError_t e = hipSuccess;
 #define MLVDB_LAUNCH_RESCORE(SP)                                                                                     \
     do {                                                                                                             \
-        auto kern = filter_rescore_kernel<SP>;                                                                       \
+        auto kern = filter_rescore_score_kernel<SP>;                                                                 \
         if (lds > 48 * 1024)                                                                                         \
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds);                                                                       \
-        if (e == hipSuccess)                                                                                         \
-            kern<<<a.nq, kRescoreWaves * 64, lds, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored); \
+        if (e == hipSuccess) kern<<<kRescoreGrid, waves * 64, lds, s>>>(a);                                          \
     } while (0)
     switch (a.space) {
         case kSpaceL2: MLVDB_LAUNCH_RESCORE(kSpaceL2); break;
@@ -1851,6 +2123,8 @@ hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int
     }
 #undef MLVDB_LAUNCH_RESCORE
     if (e != hipSuccess) return e;
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    filter_rescore_rank_kernel<<<a.nq, kRankWaves * 64, 0, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored);
     return hipGetLastError();
 }
 
