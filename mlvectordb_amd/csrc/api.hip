@@ -416,7 +416,14 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
             HIP_TRY(h, launch_filter_seed_scan(fa, n_seed, k, s));  // includes the first threshold update
         }
     }
-    const int64_t bounds[] = {first_row, (int64_t)kFilterTile * 64, (int64_t)kFilterTile * 2048, h->total};
+    // scan rounds: [seed, r1) [r1, r2) [r2, total), each followed by an exact-threshold refine; in units of kFilterTile rows
+    // (MLVDB_ROUND1 / MLVDB_ROUND2: tuning, read per call)
+    // r1 = 85: 3840 + 240 tiles of 256 rows -- one tile for (nearly) every CU costs what 192 tiles did (64: +1.5 % per 10M-row
+    // wave; 170: the same as 85; r2 = 1024 .. 2389: within noise, 4096: +2.5 %; profiles/r02/scan_ab_round_sizes_10m.txt)
+    int64_t r1 = 85, r2 = 2048;
+    if (const char* v = getenv("MLVDB_ROUND1")) r1 = std::max<int64_t>(6, atoll(v));
+    if (const char* v = getenv("MLVDB_ROUND2")) r2 = std::max<int64_t>(r1, atoll(v));
+    const int64_t bounds[] = {first_row, (int64_t)kFilterTile * r1, (int64_t)kFilterTile * r2, h->total};
     for (int r = 0; r < 3; ++r) {
         const int64_t b = std::min(bounds[r], h->total), e = std::min(bounds[r + 1], h->total);
         if (e <= b) continue;

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 N, D, K = 1_000_000, 768, 10
 N10, B = 10_000_000, 256
-PLANT = [123_456, 5_000_001, 9_999_999, 1_572_863, 1_572_864]  # incl. both sides of the round-3 boundary
+PLANT = [123_456, 5_000_001, 9_999_999, 1_572_863, 1_572_864, 65_279, 65_280]  # incl. both sides of the round-2 / round-3 boundaries
 
 
 @pytest.fixture(scope="module")
