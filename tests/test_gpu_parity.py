@@ -485,6 +485,28 @@ def test_int8_shadow_and_rows_with_outlier_components(space, dtype):
         eng.close()
 
 
+@pytest.mark.parametrize("space,d,copies", [("cosine", 768, 100), ("l2", 256, 40), ("cosine", 256, 3000), ("ip", 512, 70)])
+def test_many_identical_rows_at_the_top_of_the_lists(space, d, copies):
+    """`copies` exact copies of one row, spread over the corpus, are the nearest rows of some queries: their bounds are
+    bit-identical, so the exact-threshold refine finds more equal keys at its selection boundary than it may pick (it then
+    takes the ones with the lowest list indices) and the rescoring ranks long runs of equal distances by label.  The
+    answer is the oracle's: the copies with the lowest labels first."""
+    n, nq, k = 60_000, 24, 10
+    rows, qs = make_case(4100 + copies, n, d, nq)
+    rng = np.random.default_rng(copies)
+    where = np.sort(rng.choice(np.arange(5000, n), copies, replace=False))  # past the seeding pass too
+    rows[where] = rows[7]
+    qs[1] = rows[7] + 1e-3 * qs[1]
+    qs[2] = -rows[7]           # ... and the farthest rows of another
+    qs[3] = rows[7]
+    (gl, gd, gc), stats = run_hip(rows, qs, k, space, "filter", append_chunks=3)
+    assert stats["strategy_used"] == 2 and stats["bound_dtype"] == 2
+    assert_knn_matches((gl, gd, gc), oracle_knn(qs, rows, k, space), f"copies/{space}/{copies}")
+    if space != "ip":
+        want = np.sort(np.concatenate([[7], where]))[:k]
+        assert gl[3].tolist() == want.tolist() and gl[1].tolist() == want.tolist()
+
+
 @pytest.mark.parametrize("space", ["cosine", "l2", "ip"])
 def test_int8_bounds_hold_for_queries_with_a_dominant_component(space):
     """A query with one dominant component quantises its small components badly (int8 error ~0.1 of its norm, and
