@@ -1329,10 +1329,10 @@ __device__ __forceinline__ int64_t layout_offset_i8(int64_t row, int32_t col, in
 // 16-column group (one coalesced 1 KiB load per group, as everywhere); pass 1 finds the row maxima, pass 2 (the slab is
 // in L2 by then) quantises and measures the error.  Whole slabs are (re)written: idempotent for rows converted before.
 //
-// Scales.  l2 / ip: one scale per row, sx = max|x_i| / 127.  Cosine: the 8 rows that one lane of the scan holds for a
-// query tile -- rows 4g'..4g'+3 of both panels of the slab -- share ONE ratio sx / (|x| + 1e-30), the largest of their
-// own ratios (so nobody clips; the others quantise ~10 % coarser, and every row's error is still measured, not
-// assumed).  The scan's row constant a = sx/(|x|+1e-30) is then the same for the lane's 8 rows, which makes the
+// Scales.  l2: one scale per row, sx = max|x_i| / 127.  ip / cosine: the 8 rows that one lane of the scan holds for a
+// query tile -- rows 4g'..4g'+3 of both panels of the slab -- share ONE scale (ip: the group's largest |x_i| / 127) or,
+// cosine, ONE ratio sx / (|x| + 1e-30), the largest of their own ratios (so nobody clips; the others quantise ~10 %
+// coarser, and every row's error is still measured, not assumed).  The scan's row constant a = sx/(|x|+1e-30) is then the same for the lane's 8 rows, which makes the
 // one-compare pre-test of the folded admission test (tools/gen_scan_asm.py, gen_pretest: max_j(I_j) * max_j(a_j) +
 // max_j(b_j K) >= T) as sharp as the 8 exact tests it stands for.
 __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const float* rn, int8_t* X8, float* rp8,
@@ -1343,7 +1343,7 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
     if (slab >= slab_end) return;
     const int g = lane >> 4, r = lane & 15;
     const int ngroups = ld / 16;
-    float amax[2] = {0.f, 0.f}, nrm[2], ratio = 0.f;
+    float amax[2] = {0.f, 0.f}, nrm[2], ratio = 0.f, gmax = 0.f;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int64_t panel = slab * 2 + p;
@@ -1360,11 +1360,16 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
         m = __builtin_fmaxf(m, __shfl_xor(m, 32));
         amax[p] = m;
         nrm[p] = rn[panel * kPanelRows + r];  // NaN: tombstoned / not a row
-        if (nrm[p] == nrm[p]) ratio = __builtin_fmaxf(ratio, m / (nrm[p] + 1e-30f));
+        if (nrm[p] == nrm[p]) {
+            ratio = __builtin_fmaxf(ratio, m / (nrm[p] + 1e-30f));
+            gmax = __builtin_fmaxf(gmax, m);
+        }
     }
-    // the group's ratio: rows r with the same r >> 2, both panels
+    // the group's ratio (cosine) / largest component (l2, ip): rows r with the same r >> 2, both panels
     ratio = __builtin_fmaxf(ratio, __shfl_xor(ratio, 1));
     ratio = __builtin_fmaxf(ratio, __shfl_xor(ratio, 2));
+    gmax = __builtin_fmaxf(gmax, __shfl_xor(gmax, 1));
+    gmax = __builtin_fmaxf(gmax, __shfl_xor(gmax, 2));
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int64_t panel = slab * 2 + p;
@@ -1374,6 +1379,7 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
             const float shared = ratio * (nrm[p] + 1e-30f) * (1.0f / 127.0f) * 1.0000005f;
             if (shared > sx) sx = shared;  // never finer than the row's own scale: nothing clips
         }
+        if (space == kSpaceIp && nrm[p] == nrm[p] && gmax > amax[p]) sx = gmax / 127.0f;  // the group's scale (>= the row's own)
         const float inv = 1.0f / sx;
         double err2 = 0.0, n2 = 0.0;
         const float4* src = reinterpret_cast<const float4*>(X + panel * (int64_t)(kPanelRows * ld) + lane_group_offset(lane));

@@ -153,6 +153,8 @@ def gen_pretest(s, n, part):
     part 0 / 1: the halves issued after the first / second MFMA of the query tile two steps later."""
     a = s.emit
     regs = [acc_reg(m, n, i) for m in range(MT) for i in range(4)]
+    if I8_SPACE != "cosine":
+        return gen_pretest_l2ip(s, n, part, regs)
     t0, t1 = (("%[e0]", "%[e1]") if n & 1 == 0 else ("%[e2]", "%[e3]"))
     if part == 0:
         a(f"v_max3_i32 {t0}, {regs[0]}, {regs[1]}, {regs[2]}")
@@ -168,8 +170,84 @@ def gen_pretest(s, n, part):
         a(f".Lback{n}c{s.copy}_%=:")
 
 
+# l2 / ip folded pre-test: the e registers that only the serial admission test used (the append routine keeps e5..e9, e11)
+# plus four of the tq pool (the thresholds come from LDS per query tile here)
+L2IP_SMAX, L2IP_NMAX, L2IP_PMAX, L2IP_T0, L2IP_T1 = "%[e10]", "%[e12]", "%[e4]", "%[e0]", "%[e1]"
+L2IP_TQ = 4
+
+
+def l2ip_consts(n):
+    """(thr, ke, sq) registers of query tile n's per-query constants: two sets, by parity."""
+    return ("%[e2]", "%[e3]", "%[tq0]") if n & 1 == 0 else ("%[tq1]", "%[tq2]", "%[tq3]")
+
+
+def l2ip_fetch(s, n):
+    thr, ke, sq = l2ip_consts(n)
+    s.lds(f"ds_read_b32 {thr}, %[thra]" + (f" offset:{n * 64}" if n else ""), ("thr", n))
+    s.lds(f"ds_read_b32 {ke}, %[thra] offset:{2048 + n * 64}", ("ke", n))
+    if I8_SPACE == "l2":
+        s.lds(f"ds_read_b32 {sq}, %[thra] offset:{1024 + n * 64}", ("sq", n))
+
+
+def gen_pretest_l2ip(s, n, part, regs):
+    """Folded admission pre-test of query tile n, l2 / ip (int8, ArchVGPR accumulators).
+
+    Exact test per row j (gen_admission / the hit stub, in this order of operations): u = float(I_j); u = u s_j;
+    u = fma(ke, N_j, u); l2: u = fma(sq, u, p_j); u >= thr, with s_j the row's scale, N_j = |x_j|, p_j = -(1 - slack) N_j^2,
+    and ke, sq, thr >= 0-scaled constants of the lane's query.  The pre-test runs the SAME operations on a virtual row that
+    dominates the lane's 8 rows -- I* = max(0, max_j I_j), S = max_j s_j, N = max_j N_j, P = max_j p_j: every operation is
+    monotone in each of its inputs (ke, sq >= 0; rounding is monotone), so its result is >= every row's u, and a lane whose
+    virtual row stays below thr holds no admissible row.  It is as sharp as the rows of a lane group are alike: the shadow
+    builder gives them one scale (shadow8_rows_kernel), the norms are what they are (Gaussian rows: ~12 % of the (wave,
+    query tile) pairs reach the stub in the last round, where the exact test passes 0.7 %)."""
+    a = s.emit
+    thr, ke, sq = l2ip_consts(n)
+    if part == 0:
+        a(f"v_max3_i32 {L2IP_T0}, {regs[0]}, {regs[1]}, {regs[2]}")
+        a(f"v_max3_i32 {L2IP_T1}, {regs[3]}, {regs[4]}, {regs[5]}")
+        a(f"v_max3_i32 {L2IP_T0}, {L2IP_T0}, {regs[6]}, {regs[7]}")
+        a(f"v_max3_i32 {L2IP_T0}, {L2IP_T0}, {L2IP_T1}, 0")
+        if n + 1 < 16:
+            l2ip_fetch(s, n + 1)
+    else:
+        a(f"v_cvt_f32_i32 {L2IP_T0}, {L2IP_T0}")
+        a(f"v_mul_f32 {L2IP_T0}, {L2IP_T0}, {L2IP_SMAX}")
+        s.need_lg(("ke", n), ("thr", n), *([("sq", n)] if I8_SPACE == "l2" else []))
+        a(f"v_fma_f32 {L2IP_T0}, {ke}, {L2IP_NMAX}, {L2IP_T0}")
+        if I8_SPACE == "l2":
+            a(f"v_fma_f32 {L2IP_T0}, {sq}, {L2IP_T0}, {L2IP_PMAX}")
+        a(f"v_cmp_ge_f32 vcc, {L2IP_T0}, {thr}")
+        if "nohit" not in DBG:
+            a(f"s_cbranch_vccnz .Lhit{n}c{s.copy}_%=")
+        a(f".Lback{n}c{s.copy}_%=:")
+
+
+def gen_rowmax_l2ip(s, part):
+    """Start of the last k-step, l2 / ip: p_j = k1 N_j^2 (l2), then S = max s_j, N = max N_j, P = max p_j over the lane's
+    rows (NaN = tombstoned rows drop out of v_max_f32), and the constants of query tile 0."""
+    a = s.emit
+    NR = 4 * MT
+    if part == 0:
+        if I8_SPACE == "l2":
+            for j in range(NR):
+                a(f"v_mul_f32 %[p{j}], %[r{j}], %[r{j}]")
+            for j in range(NR):
+                a(f"v_mul_f32 %[p{j}], %[k1], %[p{j}]")        # k1 = -(1 - slack)
+    else:
+        trees = [(L2IP_SMAX, "s"), (L2IP_NMAX, "r")] + ([(L2IP_PMAX, "p")] if I8_SPACE == "l2" else [])
+        for dst, src in trees:
+            a(f"v_max3_f32 {dst}, %[{src}0], %[{src}1], %[{src}2]")
+            for j in range(3, NR - 1, 2):
+                a(f"v_max3_f32 {dst}, {dst}, %[{src}{j}], %[{src}{j + 1}]")
+            if (NR - 3) % 2:
+                a(f"v_max_f32 {dst}, {dst}, %[{src}{NR - 1}]")
+        l2ip_fetch(s, 0)
+
+
 def gen_rowmax(s, part):
     """Start of the last k-step: p_j *= K, then R = max r_j and P = max p_j over this lane's rows (e10, e12)."""
+    if I8_SPACE != "cosine":
+        return gen_rowmax_l2ip(s, part)
     a = s.emit
     NR = 4 * MT
     if part == 0:
@@ -529,12 +607,24 @@ def gen_hit_stubs(copy=""):
     out = []
     for n in range(16):
         out.append(f".Lhit{n}{copy}_%=:")
-        if FUSE:   # the pre-test let a lane through: the 8 exact bounds of this query tile (gen_admission's arithmetic)
+        if FUSE and I8_SPACE == "cosine":   # the pre-test let a lane through: the 8 exact bounds of this query tile (gen_admission's arithmetic)
             for j in range(4 * MT):
                 out.append(f"v_cvt_f32_i32 %[u{j}], {acc_reg(j >> 2, n, j & 3)}")
             for j in range(4 * MT):
                 out.append(f"v_fma_f32 %[u{j}], %[u{j}], %[r{j}], %[p{j}]")
-        out += [f"v_mov_b32 %[e6], %[tq{n}]" if FUSE else f"v_mov_b32 %[e6], %[e{n & 1}]",          # the threshold of this query tile
+        elif FUSE:   # l2 / ip: the same, with the constants the pre-test holds in registers (gen_pretest_l2ip)
+            thr, ke, sq = l2ip_consts(n)
+            for j in range(4 * MT):
+                out.append(f"v_cvt_f32_i32 %[u{j}], {acc_reg(j >> 2, n, j & 3)}")
+            for j in range(4 * MT):
+                out.append(f"v_mul_f32 %[u{j}], %[u{j}], %[s{j}]")
+            for j in range(4 * MT):
+                out.append(f"v_fma_f32 %[u{j}], {ke}, %[r{j}], %[u{j}]")
+            if I8_SPACE == "l2":
+                for j in range(4 * MT):
+                    out.append(f"v_fma_f32 %[u{j}], {sq}, %[u{j}], %[p{j}]")
+        thr_src = (f"%[tq{n}]" if I8_SPACE == "cosine" else l2ip_consts(n)[0]) if FUSE else f"%[e{n & 1}]"
+        out += [f"v_mov_b32 %[e6], {thr_src}",          # the threshold of this query tile
                 f"s_movk_i32 %[sn64], 0x{n * 16:x}",      # first query of this tile
                 f"s_getpc_b64 {RET}",
                 "s_add_u32 s92, s92, 12",                 # return to the instruction after the branch below
@@ -637,7 +727,10 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     VA = va
     assert not va or (i8 and mt == 2 and dma)
     global FUSE, Q4
-    FUSE = va and space == "cosine" and "noadm" not in DBG
+    # (l2 keeps the serial test after the k-loop: its row term -|x|^2 differs too much between the 8 rows of a lane for the
+    # dominating-row pre-test -- measured on 10M x 768: scan 2.002 ms per wave folded against 1.895 for round 1's body,
+    # profiles/r02/scan_ab_l2_ip_folded_pretest_tried.txt; "fuse_l2" in DBG regenerates that variant)
+    FUSE = va and "noadm" not in DBG and (space in ("cosine", "ip") or "fuse_l2" in DBG)
     # q4: four 32 KiB Q buffers (128 KiB), chunk c + 2 is staged while chunk c is consumed, and the workgroup meets at
     # ONE barrier per two chunks (after the odd ones) instead of one per chunk: half the parking, half the refills of
     # the software pipeline.  Needs the DMA staging and a ring of 4 k-steps (one loop body = one pair of chunks).
@@ -737,7 +830,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
             a(f"buffer_load_dwordx4 %[{setname}{i}], %[qvoff], %[qsrd], %[st0] offen")
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")   # counted waits below assume the steady-state issue pattern
     a("s_barrier")
-    if FUSE:   # the thresholds of this lane's query column in the 16 query tiles: constant for the whole launch
+    if FUSE and space == "cosine":   # the thresholds of this lane's query column in the 16 query tiles: constant for the whole launch
         for n in range(16):
             a(f"ds_read_b32 %[tq{n}], %[thra]" + (f" offset:{n * 64}" if n else ""))
         a("s_waitcnt lgkmcnt(0)")
@@ -851,7 +944,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     for j in range(13):
         ops_out.append(f'[e{j}] "=&v"(ve[{j}])')
     if FUSE:
-        for n in range(16):
+        for n in range(16 if space == "cosine" else L2IP_TQ):
             ops_out.append(f'[tq{n}] "=&v"(vt[{n}])')
     ops_out += ['[ldr] "=&v"(ldr)'] + (['[sldw] "=&s"(s_sldw)'] if dma else ['[ldw] "=&v"(ldw)'])
     for name in [f"xso{m}" for m in range(MT)] + ["qcur", "cnt", "st0", "tl", "trow", "sn64", "wcnt", "sacc0", "sacc1"]:
