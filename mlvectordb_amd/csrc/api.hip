@@ -476,7 +476,11 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
 #ifdef MLVDB_SCAN_DIAGNOSTICS
     if (fa.wgbuf && getenv("MLVDB_DEBUG_REFINE")) HIP_TRY(h, hipMemsetAsync(fa.wgbuf, 0, (16384 + 1024) * 8, s));
 #endif
-    HIP_TRY(h, launch_filter_rescore(fa, k, q0, out_labels, out_dist, out_counts, out_d64, stats, s));
+    // (its ranking kernel also compacts the overflowed queries for the device-decided fallback below: qsel, nflag)
+    HIP_TRY(h, h->qsel.ensure(kFilterQueries * sizeof(int32_t)));
+    int32_t* nflag = reinterpret_cast<int32_t*>(stats + 2);
+    HIP_TRY(h, launch_filter_rescore(fa, k, q0, out_labels, out_dist, out_counts, out_d64, stats,
+                                     defer_fallback ? nullptr : h->qsel.as<int32_t>(), nflag, s));
 #ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: where the ranking kernel's time goes (its blocks stamp their phases)
     if (fa.wgbuf && getenv("MLVDB_DEBUG_REFINE")) {
         std::vector<unsigned long long> st(16384 + 1024, 0ull);
@@ -518,7 +522,6 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
     // overflowed queries (adversarial near-ties) are re-run on the exact scan.  The decision stays on
     // the device: the list is compacted there and the scan's blocks exit at once when it is empty,
     // so the call never waits for the host.
-    HIP_TRY(h, h->qsel.ensure(kFilterQueries * sizeof(int32_t)));
     if (defer_fallback) {
         // host-pointer entry, single pass: the caller synchronises anyway to copy the results out, so the overflow
         // flags ride along to pinned memory and the exact fallback is only launched if a query needs it (search_host)
@@ -528,8 +531,6 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
         h->deferred = true;
         return MLVDB_OK;
     }
-    int32_t* nflag = reinterpret_cast<int32_t*>(stats + 2);
-    HIP_TRY(h, launch_filter_collect(fa, h->qsel.as<int32_t>(), nflag, stats, s));
     rc = run_exact(h, s, fa.Qpad, fa.qaux, nq, h->qsel.as<int32_t>(), 0, h->total, k, out_labels + (size_t)q0 * k,
                    out_dist + (size_t)q0 * k, out_counts + q0, out_d64 ? out_d64 + (size_t)q0 * k : nullptr, false,
                    nflag);

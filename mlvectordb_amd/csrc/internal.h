@@ -188,11 +188,11 @@ hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t ro
 constexpr int kSeedRows = 3840;  // a multiple of every scan tile (128, 192) and <= kCandCap
 hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t k, hipStream_t s);
 hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s);
+// rescored[0] += rescored pairs; qsel != nullptr: also compacts the overflowed queries of the pass, qsel[0..*nflag) = their
+// indices, rescored[1] += *nflag (the device-decided exact fallback that follows reads them)
 hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
-                                 int32_t* out_counts, double* out_d64, unsigned long long* rescored, hipStream_t s);
-// compact the overflowed queries of a pass: qsel[0..*nflag) = their indices; stats[0] += rescored, stats[1] += *nflag
-hipError_t launch_filter_collect(const FilterArgs& a, int32_t* qsel, int32_t* nflag, unsigned long long* stats,
-                                 hipStream_t s);
+                                 int32_t* out_counts, double* out_d64, unsigned long long* rescored, int32_t* qsel,
+                                 int32_t* nflag, hipStream_t s);
 // range variant: fixed per-query threshold from the radius, then exact rescoring with emit
 hipError_t launch_filter_range_thr(const FilterArgs& a, float radius, hipStream_t s);
 // exact candidate generator for range queries (any dim): appends every live row with dist <= radius

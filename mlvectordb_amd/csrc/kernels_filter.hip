@@ -1054,16 +1054,37 @@ __global__ __launch_bounds__(kRescoreWaves * 64) void filter_rescore_score_kerne
 #undef SCORE_STAMP
 }
 
+// Block 0 also compacts the indices of the overflowed queries (ascending) for the exact fallback that follows when the
+// call cannot ask the host (qsel != nullptr; a launch of its own until round 2).
 __global__ __launch_bounds__(kRankWaves * 64) void filter_rescore_rank_kernel(const FilterArgs a, const int32_t k, const int32_t q0,
                                                                                   int64_t* out_labels, float* out_dist,
                                                                                   int32_t* out_counts, double* out_d64,
-                                                                                  unsigned long long* rescored) {
+                                                                                  unsigned long long* rescored, int32_t* qsel,
+                                                                                  int32_t* nflag) {
     __shared__ double ed[kRescoreRankMax];  // exact distances
     __shared__ int32_t el[kRescoreRankMax];  // labels
     __shared__ double sd[kRankWaves][64];
     __shared__ int32_t sl[kRankWaves][64];
     __shared__ int32_t s_nvalid;
+    __shared__ int32_t s_flagged[4];
     const int q = blockIdx.x;
+    if (blockIdx.x == 0 && qsel) {  // block-uniform
+        const int t = threadIdx.x;
+        const bool flagged = t < kFilterQueries && t < a.nq && a.overflow[t] != 0;
+        const unsigned long long bal = __ballot(flagged);
+        if (t < kFilterQueries && (t & 63) == 0) s_flagged[t >> 6] = __popcll(bal);
+        __syncthreads();
+        if (t < kFilterQueries) {
+            int base = 0;
+            for (int w = 0; w < (t >> 6); ++w) base += s_flagged[w];
+            if (flagged) qsel[base + __popcll(bal & ((1ull << (t & 63)) - 1ull))] = t;
+        }
+        if (t == 0) {
+            const int n = s_flagged[0] + s_flagged[1] + s_flagged[2] + s_flagged[3];
+            *nflag = n;
+            if (rescored) rescored[1] += (unsigned long long)n;
+        }
+    }
 #ifdef MLVDB_SCAN_DIAGNOSTICS
     unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.wgbuf) + 16384 + (size_t)blockIdx.x * 4;
 #define RANK_STAMP(i) do { if (threadIdx.x == 0 && a.wgbuf) stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -1269,33 +1290,7 @@ __global__ __launch_bounds__(256) void range_sort_kernel(const FilterArgs a, con
     if (threadIdx.x == 0) out_counts[q0 + q] = n;
 }
 
-// One block: compact the indices of the overflowed queries (ascending) and publish their count.
-__global__ __launch_bounds__(256) void filter_collect_kernel(const FilterArgs a, int32_t* qsel, int32_t* nflag,
-                                                             unsigned long long* stats) {
-    __shared__ int32_t wave_cnt[4];
-    const int q = threadIdx.x;
-    const int lane = q & 63, wave = q >> 6;
-    const bool flagged = q < a.nq && a.overflow[q] != 0;
-    const unsigned long long b = __ballot(flagged);
-    if (lane == 0) wave_cnt[wave] = __popcll(b);
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wave; ++w) base += wave_cnt[w];
-    if (flagged) qsel[base + __popcll(b & ((1ull << lane) - 1))] = q;
-    if (q == 0) {
-        const int n = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        *nflag = n;
-        if (stats) stats[1] += (unsigned long long)n;
-    }
-}
-
 // ------------------------------------------------------------------ launchers
-hipError_t launch_filter_collect(const FilterArgs& a, int32_t* qsel, int32_t* nflag, unsigned long long* stats,
-                                 hipStream_t s) {
-    filter_collect_kernel<<<1, 256, 0, s>>>(a, qsel, nflag, stats);
-    return hipGetLastError();
-}
-
 hipError_t launch_filter_prep(const FilterArgs& a, hipStream_t s) {
     const int nkc = a.ld / kFilterChunkK;
     filter_prep_kernel<<<nkc > 0 ? nkc * 16 : 1, 256, 0, s>>>(a);  // nkc == 0: only the per-query state
@@ -2108,7 +2103,8 @@ static hipError_t launch_update(const FilterArgs& a, int32_t k, int32_t forced_c
 hipError_t launch_filter_update(const FilterArgs& a, int32_t k, hipStream_t s) { return launch_update(a, k, -1, s); }
 
 hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
-                                 int32_t* out_counts, double* out_d64, unsigned long long* rescored, hipStream_t s) {
+                                 int32_t* out_counts, double* out_d64, unsigned long long* rescored, int32_t* qsel,
+                                 int32_t* nflag, hipStream_t s) {
     // every wave keeps its current query in LDS as fp64; at least 96 KiB per block, so that the dispatcher cannot put two on one CU
     int waves = kRescoreWaves;
     while (waves > 1 && (size_t)waves * a.ld * sizeof(double) > 144 * 1024) waves >>= 1;
@@ -2130,7 +2126,8 @@ hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int
 #undef MLVDB_LAUNCH_RESCORE
     if (e != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    filter_rescore_rank_kernel<<<a.nq, kRankWaves * 64, 0, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored);
+    filter_rescore_rank_kernel<<<a.nq, kRankWaves * 64, 0, s>>>(a, k, q0, out_labels, out_dist, out_counts, out_d64, rescored, qsel,
+                                                                nflag);
     return hipGetLastError();
 }
 

@@ -205,6 +205,41 @@ def test_get_rows_roundtrip_and_reset():
         eng.close()
 
 
+def test_device_pointer_entry_runs_the_exact_fallback_for_overflowed_queries():
+    """Two tight clusters of 20,000 rows: a query near a centre has more candidates than a list holds (8192), its list
+    overflows and the query is re-run on the exact scan.  On the device-pointer entry that decision stays on the device
+    (the ranking kernel compacts the flagged queries, the exact kernels read the list); queries far from both centres
+    keep the filter's answer."""
+    import torch
+
+    rng = np.random.default_rng(404)
+    n, d, nq, k = 40_000, 128, 24, 10
+    centres = rng.standard_normal((2, d)).astype(np.float32)
+    rows = (centres[rng.integers(0, 2, n)] + 1e-4 * rng.standard_normal((n, d))).astype(np.float32)
+    qs = rng.standard_normal((nq, d)).astype(np.float32)
+    qs[::3] = centres[0] + 1e-3 * qs[::3]
+    qs[1::3] = centres[1] + 1e-3 * qs[1::3]
+    eng = HipScanEngine(d, "cosine", device=0, strategy="filter")
+    try:
+        eng.append(rows)
+        t_q = torch.from_numpy(qs).cuda()
+        lab = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+        dist = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+        cnt = torch.empty(nq, dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        eng.search_device(t_q.data_ptr(), nq, k, lab.data_ptr(), dist.data_ptr(), cnt.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        stats = eng.last_stats()
+        assert stats["strategy_used"] == 2 and stats["fallback_queries"] >= 8, stats
+        assert_knn_matches((lab.cpu().numpy(), dist.cpu().numpy(), cnt.cpu().numpy()), oracle_knn(qs, rows, k, "cosine"),
+                           "device-entry/fallback")
+        got = eng.search(qs, k)  # host-pointer entry: the same decision, taken on the host after its own sync
+        assert eng.last_stats()["fallback_queries"] == stats["fallback_queries"]
+        assert_knn_matches(got, oracle_knn(qs, rows, k, "cosine"), "host-entry/fallback")
+    finally:
+        eng.close()
+
+
 def test_device_pointer_entry_and_fp64_distances():
     import torch
 
