@@ -1669,7 +1669,10 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
         const bool split = ties != 0xffffffffu;  // more equal keys at the boundary than fit (block-uniform)
         for (uint32_t idx = threadIdx.x; idx < cnt; idx += 256) {
             const uint32_t key = keys[idx];
-            if (key != 0 && (split ? key > tkey : key >= tkey)) pick[atomicAdd(&s_scan[16], 1u)] = fuse ? stage[idx].row : list[idx].row;
+            if (key != 0 && (split ? key > tkey : key >= tkey)) {
+                const uint32_t pos = atomicAdd(&s_scan[16], 1u);
+                if (pos < 64u) pick[pos] = fuse ? stage[idx].row : list[idx].row;  // (pos < m by construction: never past pick[])
+            }
         }
         if (split && wave == 0) {  // ... the `ties` entries with that key and the lowest list indices (rare: duplicates)
             uint32_t taken = 0;
@@ -1679,12 +1682,13 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
                 const bool hit = idx < cnt && keys[idx] == tkey;
                 const unsigned long long bal = __ballot(hit);
                 const uint32_t pos = taken + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
-                if (hit && pos < ties) pick[above + pos] = fuse ? stage[idx].row : list[idx].row;
+                if (hit && pos < ties && above + pos < 64u) pick[above + pos] = fuse ? stage[idx].row : list[idx].row;
                 taken += (uint32_t)__popcll(bal);
             }
         }
     }
     __syncthreads();
+    if (ok) m = min(m, 64u);  // (the selection's own count; the gather below never reads past pick[])
     REFINE_STAMP(2);
     // exact scores of the picked rows: 32 rows per step, lane l8 of a row takes the 16-column groups l8, l8 + 8, ...
     const int rslot = threadIdx.x >> 3, l8 = threadIdx.x & 7;
