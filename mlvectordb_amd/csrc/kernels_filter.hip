@@ -597,7 +597,7 @@ static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagre
 // the bf16 body; 208..219 = int8 bodies (208 AccVGPR accumulators; 211 ArchVGPR accumulators, cosine: admission folded into the
 // last k-step; 214 / 215 / 216 tuning variants of 211: ring of 6, read-ahead 8, no wave priorities; 209 / 210 / 212 / 213
 // timing diagnostics).
-constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 229; }
+constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 230; }
 constexpr int scan_code_qd(int qd) { return qd == 215 ? 8 : (qd > 8 ? 4 : qd); }
 constexpr int scan_code_qbufs(int qd) { return qd == 219 || qd == 229 ? 4 : 2; }  // 219 / 229: four Q chunk buffers
 constexpr int scan_code_stage_cap(int qd, int nw, int mt) {
@@ -1990,6 +1990,7 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                         return launch_scan_asm<SPACE, 4, 8, true, 222, true, 2, true, true>(a, row_begin, row_end, s, info);
                     if (var == 220) return launch_scan_asm<SPACE, 4, 8, true, 220, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 221) return launch_scan_asm<SPACE, 4, 8, true, 221, true, 2, true>(a, row_begin, row_end, s, info);
+                    if (var == 230) return launch_scan_asm<SPACE, 4, 4, true, 230, false, 4, true>(a, row_begin, row_end, s, info);
                     if (var == 217) return launch_scan_asm<SPACE, 4, 4, true, 217, false, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 218) return launch_scan_asm<SPACE, 4, 4, true, 218, true, 2, true>(a, row_begin, row_end, s, info);
                 }

@@ -329,6 +329,7 @@ SCAN_VARIANTS = [
     {"MLVDB_I8": "0", "MLVDB_SCAN_NT": "0"},         # (cosine only) temporal X loads
     {"MLVDB_I8": "0", "MLVDB_SCAN_ASM": "0"},        # the hipcc-scheduled kernel (also serves corpora without shadow)
     {"MLVDB_I8": "0", "MLVDB_SCAN_STAG": "1"},       # later half of the waves half a tile behind (rotated k origin)
+    {"MLVDB_SCAN_VAR": "230"},                       # (cosine, int8) one wave per SIMD, 64 rows per wave, AccVGPR accumulators
 ]
 
 NARROW_CASES = [

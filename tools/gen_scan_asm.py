@@ -1005,7 +1005,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_diag223.inc", "scan_asm_diag224.inc", "scan_asm_diag225.inc", "scan_asm_diag226.inc", "scan_asm_diag227.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc", "scan_asm_cosine_i8_va_r6b3.inc", "scan_asm_cosine_i8_va_q3d.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_diag223.inc", "scan_asm_diag224.inc", "scan_asm_diag225.inc", "scan_asm_diag226.inc", "scan_asm_diag227.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc", "scan_asm_cosine_i8_va_r6b3.inc", "scan_asm_cosine_i8_va_q3d.inc", "scan_asm_cosine_i8_mt4.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -1043,6 +1043,9 @@ def main():
     (Path(args.outdir) / "scan_asm_cosine_i8_va_r6b3.inc").write_text(generate("cosine", 6, 4, 8, True, True, 2, True, False, True, True, False, None, 3))
     # 229: ring of 6 + Q staged three chunks ahead, awaited two chunks later
     (Path(args.outdir) / "scan_asm_cosine_i8_va_q3d.inc").write_text(generate("cosine", 6, 4, 8, True, True, 2, True, False, True, True, False, None, 0, True))
+    # 230: 64 rows per wave, one wave per SIMD (4-wave workgroups), AccVGPR accumulators a[0:255], serial admission test --
+    # the int8 counterpart of MLVDB_SCAN_MT=4, to be compared with the 32-row body of the same structure (QD slot 208)
+    (Path(args.outdir) / "scan_asm_cosine_i8_mt4.inc").write_text(generate("cosine", 4, 4, 4, True, False, 4, True, False, True))
     # 219: four Q buffers, one barrier per two chunks
     (Path(args.outdir) / "scan_asm_cosine_i8_va_q4.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, True))
     DBG.update({"nohit"})   # 212: the folded pre-test computed, no hit ever taken
@@ -1090,6 +1093,8 @@ def main():
     for code, nm in ((220, "p0"), (221, "p4")):
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
         disp.append(f'#include "scan_asm_cosine_i8_va_{nm}.inc"')
+    disp.append("} else if constexpr (SPACE == 1 && NW == 4 && R == 4 && NT == true && QD == 230 && PRIO == false && MT == 4 && DMA == true && STAG == false) {")
+    disp.append('#include "scan_asm_cosine_i8_mt4.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 219 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_cosine_i8_va_q4.inc"')
     disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
