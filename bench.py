@@ -3,10 +3,12 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-N=1 runs BASELINE.json configs[2] (10M x 768, batch 256, 1 x MI355X).  N>1 is launched by
-`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`: one process per
-GPU, every rank holds 10M rows (weak scaling; N=8 is configs[4], 80M rows, batch 1024), scans
-its shard for the whole query wave, and rank 0 merges the per-shard top-k on the host.
+N=1 runs BASELINE.json configs[2] (10M x 768, batch 256, 1 x MI355X).  N>1 runs one process per GPU: either the
+caller starts the ranks (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`) or a bare
+`python bench.py --gpus N` starts them itself as a child `torch.distributed.run` and relays rank 0's JSON line and the
+exit code (launch_plan / spawn_ranks); a WORLD_SIZE that contradicts --gpus is an error, never a silent 1-GPU run.
+Every rank holds 10M rows (weak scaling; N=8 is configs[4], 80M rows, batch 1024), scans its shard for the whole query
+wave, and rank 0 merges the per-shard top-k on the host.
 
 A step = one query wave through the hot path with queries and corpus resident in HBM:
 query prep -> int8- (cosine) or bf16-MFMA filter scan of the shard -> threshold updates -> exact fp64 rescoring
@@ -204,8 +206,55 @@ def config4_side(eng_l2, q_host: np.ndarray, k: int) -> dict:
                        "range_hits_equal_exact_range_scan_all_queries": bool(range_ok)}}
 
 
+def launch_plan(args, environ, argv):
+    """What `python bench.py --gpus N` has to do before anything touches the GPU (north star: "reported at
+    1, 2, 4 and 8 GPUs").  Returns ("run", None) when this process is a rank (or the one-GPU / in-process job),
+    ("spawn", cmd) when it was started bare with --gpus N > 1 and has to start its N ranks itself, and ("error", msg)
+    when the environment contradicts the command line -- a run that asked for N GPUs never reports fewer."""
+    world = environ.get("WORLD_SIZE")
+    if args.in_process:
+        return "run", None
+    if world is not None:
+        if int(world) != args.gpus:
+            return "error", (f"--gpus {args.gpus} but WORLD_SIZE={world}: start the job with "
+                             f"--nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}` bare)")
+        return "run", None
+    if args.gpus <= 1:
+        return "run", None
+    import socket
+
+    with socket.socket() as s:  # a free rendezvous port on the loopback (the container hostname may not resolve)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    return "spawn", cmd
+
+
+def spawn_ranks(cmd) -> int:
+    """Start the N ranks as a CHILD process (never exec: this process may not be replaced once a GPU runtime could have
+    been initialised), relay the one JSON line rank 0 prints and return the child's exit code."""
+    import subprocess
+
+    log("bare --gpus N: starting " + " ".join(cmd[1:8]) + " ...")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return proc.returncode if (lines or proc.returncode) else 1
+
+
 def main() -> None:
     args = parse_args()
+    what, arg = launch_plan(args, os.environ, sys.argv[1:])
+    if what == "error":
+        log(arg)
+        sys.exit(2)
+    if what == "spawn":
+        sys.exit(spawn_ranks(arg))
     # stdout carries exactly one JSON line: libraries that print there (gloo's rendezvous banner does) go to stderr
     sys.stdout.flush()
     json_fd = os.dup(1)
@@ -222,8 +271,7 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
+    assert world == args.gpus  # launch_plan() refused anything else
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -235,6 +283,18 @@ def main() -> None:
         else:
             dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
+    # n_gpus of the JSON line = the ranks that really joined (one collective over the data-path group), never the flag
+    ranks_ran, rccl_ranks, rank_devices = 1, 0, [local_rank]
+    if world > 1:
+        one = torch.ones(1, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        ranks_ran = int(round(one.item()))
+        rccl_ranks = dist.get_world_size() if args.backend == "nccl" else 0
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, local_rank, group=host_group)
+        if ranks_ran != args.gpus:
+            log(f"{ranks_ran} ranks joined but --gpus {args.gpus}")
+            sys.exit(2)
 
     n_local, d, k = args.rows_per_gpu, args.dim, args.k
     batch = args.batch or (256 if world == 1 else 1024)
@@ -508,7 +568,8 @@ def main() -> None:
         "metric": "queries/sec, exact cosine kNN k=10 over a row-sharded Nx768 fp32 corpus (10M rows per GPU)",
         "value": round(shard_queries_per_s, 1),
         "unit": "queries/s (each query scanned against one 10M-row shard; whole-corpus QPS = value / n_gpus)",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "n_gpus": ranks_ran, "rccl_ranks": rccl_ranks, "rank_devices": rank_devices,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": (("i8" if stats0.get("bound_dtype") == 2 else "bf16") + " (MFMA bounds) + f64 (exact rescoring of the f32 rows)")
                  if stats0["strategy_used"] == 2 else "f64 (exact scan of the f32 rows)",

@@ -45,3 +45,53 @@ def test_pmc_traffic_file_matches_the_kernel_sources_in_the_tree():
         pytest.xfail("the scan kernel sources changed after profiles/r02/pmc_traffic_i8.json was measured: re-run the two "
                      "rocprofv3 --pmc passes and tools/pmc_traffic.py")
     assert pmc["traffic_bytes_per_launch_avg"] > 0
+
+
+# ---- `python bench.py --gpus N` must run N ranks or fail: the launch decision, without a GPU
+class _Args:
+    def __init__(self, gpus, in_process=False):
+        self.gpus, self.in_process = gpus, in_process
+
+
+def test_launch_plan_runs_in_place_as_a_rank_or_as_the_one_gpu_job():
+    assert bench.launch_plan(_Args(1), {}, ["--gpus", "1"]) == ("run", None)
+    assert bench.launch_plan(_Args(4), {"WORLD_SIZE": "4", "RANK": "2"}, []) == ("run", None)
+    assert bench.launch_plan(_Args(8, in_process=True), {}, []) == ("run", None)
+
+
+def test_launch_plan_refuses_a_world_size_that_contradicts_the_flag():
+    what, msg = bench.launch_plan(_Args(8), {"WORLD_SIZE": "1"}, [])
+    assert what == "error" and "--gpus 8" in msg and "WORLD_SIZE=1" in msg
+    assert bench.launch_plan(_Args(1), {"WORLD_SIZE": "2"}, [])[0] == "error"
+
+
+def test_bare_gpus_n_spawns_n_ranks_under_torch_distributed_run():
+    argv = ["--gpus", "2", "--steps", "3", "--single-device"]
+    what, cmd = bench.launch_plan(_Args(2), {}, argv)
+    assert what == "spawn"
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-len(argv) - 1].endswith("bench.py") and cmd[-len(argv):] == argv  # same arguments, same script
+
+
+def test_spawn_relays_the_json_line_and_the_exit_code(tmp_path, capsys):
+    import sys
+
+    child = tmp_path / "child.py"
+    child.write_text("import sys\nprint('banner')\nprint('{\"n_gpus\": 2}')\nsys.exit(int(sys.argv[1]))\n")
+    assert bench.spawn_ranks([sys.executable, str(child), "0"]) == 0
+    assert capsys.readouterr().out.strip() == '{"n_gpus": 2}'
+    assert bench.spawn_ranks([sys.executable, str(child), "3"]) == 3
+    silent = tmp_path / "silent.py"
+    silent.write_text("pass\n")
+    assert bench.spawn_ranks([sys.executable, str(silent)]) == 1  # no JSON line is a failure even at exit code 0
+
+
+def test_a_contradicting_world_size_exits_non_zero_before_any_gpu_work():
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "8"], env=env, capture_output=True, timeout=120)
+    assert r.returncode == 2 and b"WORLD_SIZE=1" in r.stderr and r.stdout.strip() == b""
