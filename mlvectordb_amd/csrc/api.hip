@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <new>
 
 #include "internal.h"
@@ -656,6 +657,22 @@ int check_handle(mlvdb_index* h) {
     return MLVDB_OK;
 }
 
+// The header promises "never throws, returns an int status": every extern "C" body runs inside this guard, so that a
+// host-side allocation failure (std::vector / std::string growth) or any other C++ exception becomes a status code
+// instead of unwinding through the caller's C / ctypes frames (std::terminate -> SIGABRT).
+template <class F>
+int guarded(mlvdb_index* h, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try { return fail(h, MLVDB_ERR_OUT_OF_MEMORY, "host allocation failed (std::bad_alloc)"); } catch (...) { return MLVDB_ERR_OUT_OF_MEMORY; }
+    } catch (const std::exception& e) {
+        try { return fail(h, MLVDB_ERR_INTERNAL, e.what()); } catch (...) { return MLVDB_ERR_INTERNAL; }
+    } catch (...) {
+        try { return fail(h, MLVDB_ERR_INTERNAL, "unknown C++ exception"); } catch (...) { return MLVDB_ERR_INTERNAL; }
+    }
+}
+
 }  // namespace
 
 // ============================================================================== C ABI
@@ -668,6 +685,7 @@ const char* mlvdb_last_global_error(void) { return g_error.c_str(); }
 const char* mlvdb_last_error(const mlvdb_index* h) { return h ? h->err.c_str() : g_error.c_str(); }
 
 int mlvdb_device_count(int* count) {
+    return guarded(nullptr, [&]() -> int {
     if (!count) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "count is null");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -677,12 +695,14 @@ int mlvdb_device_count(int* count) {
     }
     *count = n;
     return MLVDB_OK;
+    });
 }
 
 int64_t mlvdb_layout_offset(int64_t row, int32_t col, int32_t ld) { return layout_offset(row, col, ld); }
 int32_t mlvdb_layout_ld(int32_t dim) { return layout_ld(dim); }
 
 int mlvdb_index_create(int device, int32_t dim, int32_t space, int64_t capacity_hint, mlvdb_index** out) {
+    return guarded(nullptr, [&]() -> int {
     if (!out) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "out is null");
     *out = nullptr;
     if (dim <= 0 || dim > 8192) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "dim must be in 1..8192");
@@ -727,9 +747,11 @@ int mlvdb_index_create(int device, int32_t dim, int32_t space, int64_t capacity_
     }
     *out = h;
     return MLVDB_OK;
+    });
 }
 
 int mlvdb_index_destroy(mlvdb_index* h) {
+    return guarded(h, [&]() -> int {
     if (!h) return MLVDB_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -753,9 +775,11 @@ int mlvdb_index_destroy(mlvdb_index* h) {
     if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
     delete h;
     return MLVDB_OK;
+    });
 }
 
 int mlvdb_index_append_device(mlvdb_index* h, const float* rows_device, int64_t n, int64_t* first_label) {
+    return guarded(h, [&]() -> int {
     int rc = check_handle(h);
     if (rc) return rc;
     if (n < 0 || (n > 0 && !rows_device)) return fail(h, MLVDB_ERR_INVALID_ARG, "bad rows / n");
@@ -770,9 +794,11 @@ int mlvdb_index_append_device(mlvdb_index* h, const float* rows_device, int64_t 
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     h->total += n;
     return MLVDB_OK;
+    });
 }
 
 int mlvdb_index_append(mlvdb_index* h, const float* rows, int64_t n, int64_t* first_label) {
+    return guarded(h, [&]() -> int {
     int rc = check_handle(h);
     if (rc) return rc;
     if (n < 0 || (n > 0 && !rows)) return fail(h, MLVDB_ERR_INVALID_ARG, "bad rows / n");
@@ -794,9 +820,11 @@ int mlvdb_index_append(mlvdb_index* h, const float* rows, int64_t n, int64_t* fi
     }
     h->total += n;
     return MLVDB_OK;
+    });
 }
 
 int mlvdb_index_tombstone(mlvdb_index* h, const int64_t* labels, int64_t n, int64_t* newly_deleted) {
+    return guarded(h, [&]() -> int {
     int rc = check_handle(h);
     if (rc) return rc;
     if (n < 0 || (n > 0 && !labels)) return fail(h, MLVDB_ERR_INVALID_ARG, "bad labels / n");
@@ -818,9 +846,11 @@ int mlvdb_index_tombstone(mlvdb_index* h, const int64_t* labels, int64_t n, int6
     h->deleted += (int64_t)changed;
     if (newly_deleted) *newly_deleted = (int64_t)changed;
     return MLVDB_OK;
+    });
 }
 
 int mlvdb_index_compact(mlvdb_index* h, int64_t* old_labels, int64_t capacity, int64_t* live_out) {
+    return guarded(h, [&]() -> int {
     int rc = check_handle(h);
     if (rc) return rc;
     const int64_t want = h->total - h->deleted;
@@ -875,16 +905,20 @@ int mlvdb_index_compact(mlvdb_index* h, int64_t* old_labels, int64_t capacity, i
     h->deleted = 0;
     h->i8_rows = 0;
     return MLVDB_OK;
+    });
 }
 
 int mlvdb_index_counts(const mlvdb_index* h, int64_t* total, int64_t* deleted) {
+    return guarded(const_cast<mlvdb_index*>(h), [&]() -> int {
     if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");
     if (total) *total = h->total;
     if (deleted) *deleted = h->deleted;
     return MLVDB_OK;
+    });
 }
 
 int mlvdb_index_reset(mlvdb_index* h, int32_t space) {
+    return guarded(h, [&]() -> int {
     int rc = check_handle(h);
     if (rc) return rc;
     if (space > 2) return fail(h, MLVDB_ERR_INVALID_ARG, "space must be < 0 (keep) or a MLVDB_SPACE_* value");
@@ -900,9 +934,11 @@ int mlvdb_index_reset(mlvdb_index* h, int32_t space) {
     h->i8_rows = 0;
     if (space >= 0) h->space = space;
     return MLVDB_OK;
+    });
 }
 
 int mlvdb_index_get_rows(mlvdb_index* h, int64_t first, int64_t n, float* out_rows) {
+    return guarded(h, [&]() -> int {
     int rc = check_handle(h);
     if (rc) return rc;
     if (first < 0 || n < 0 || first + n > h->total || (n > 0 && !out_rows))
@@ -917,9 +953,11 @@ int mlvdb_index_get_rows(mlvdb_index* h, int64_t first, int64_t n, float* out_ro
         HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
     return MLVDB_OK;
+    });
 }
 
 int mlvdb_index_get_rows_at(mlvdb_index* h, const int64_t* labels, int64_t n, float* out_rows) {
+    return guarded(h, [&]() -> int {
     int rc = check_handle(h);
     if (rc) return rc;
     if (n < 0 || (n > 0 && (!labels || !out_rows))) return fail(h, MLVDB_ERR_INVALID_ARG, "bad labels / n / out_rows");
@@ -940,6 +978,7 @@ int mlvdb_index_get_rows_at(mlvdb_index* h, const int64_t* labels, int64_t n, fl
         HIP_TRY(h, hipStreamSynchronize(s));
     }
     return MLVDB_OK;
+    });
 }
 
 static int search_device_impl(mlvdb_index* h, const float* queries_device, int64_t nq, int32_t k,
@@ -949,16 +988,18 @@ static int search_device_impl(mlvdb_index* h, const float* queries_device, int64
 int mlvdb_search_batch_device(mlvdb_index* h, const float* queries_device, int64_t nq, int32_t k,
                               int64_t* out_labels_device, float* out_dist_device, int32_t* out_counts_device,
                               double* out_dist64_device, void* stream) {
+    return guarded(h, [&]() -> int {
     return search_device_impl(h, queries_device, nq, k, out_labels_device, out_dist_device, out_counts_device,
                               out_dist64_device, stream, false);
+    });
 }
 
 static int search_device_impl(mlvdb_index* h, const float* queries_device, int64_t nq, int32_t k,
                               int64_t* out_labels_device, float* out_dist_device, int32_t* out_counts_device,
                               double* out_dist64_device, void* stream, bool defer_fallback) {
     int rc = check_handle(h);
-    h->deferred = false;
     if (rc) return rc;
+    h->deferred = false;
     if (nq < 0 || nq > (1 << 24)) return fail(h, MLVDB_ERR_INVALID_ARG, "nq out of range");
     if (k < 1) return fail(h, MLVDB_ERR_INVALID_ARG, "k must be >= 1");
     if (k > MLVDB_MAX_TOPK_PAGED) return fail(h, MLVDB_ERR_UNSUPPORTED, "k above MLVDB_MAX_TOPK_PAGED");
@@ -1051,6 +1092,7 @@ int search_host(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, int
 
 int mlvdb_search_batch_ex(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, const uint8_t* row_mask,
                           int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_dist64) {
+    return guarded(h, [&]() -> int {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!row_mask || h->total == 0) return search_host(h, queries, nq, k, out_labels, out_dist, out_counts, out_dist64);
@@ -1077,20 +1119,26 @@ int mlvdb_search_batch_ex(mlvdb_index* h, const float* queries, int64_t nq, int3
     h->mask_active = false;
     h->mask_pairs_ready = false;
     return rc;
+    });
 }
 
 int mlvdb_search_batch(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, int64_t* out_labels,
                        float* out_dist, int32_t* out_counts) {
+    return guarded(h, [&]() -> int {
     return mlvdb_search_batch_ex(h, queries, nq, k, nullptr, out_labels, out_dist, out_counts, nullptr);
+    });
 }
 
 int mlvdb_search_batch_filtered(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, const uint8_t* row_mask,
                                 int64_t* out_labels, float* out_dist, int32_t* out_counts) {
+    return guarded(h, [&]() -> int {
     return mlvdb_search_batch_ex(h, queries, nq, k, row_mask, out_labels, out_dist, out_counts, nullptr);
+    });
 }
 
 int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float radius, int64_t capacity,
                       int64_t* out_labels, float* out_dist, int64_t* out_counts) {
+    return guarded(h, [&]() -> int {
     int rc = check_handle(h);
     if (rc) return rc;
     if (nq < 0 || nq > (1 << 24)) return fail(h, MLVDB_ERR_INVALID_ARG, "nq out of range");
@@ -1250,24 +1298,30 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
                     "outputs the nearest MLVDB_MAX_TOPK_PAGED");
     if (over) return fail(h, MLVDB_ERR_OVERFLOW, "some query has more hits than `capacity`; out_counts holds the exact counts");
     return MLVDB_OK;
+    });
 }
 
 int mlvdb_index_set_strategy(mlvdb_index* h, int32_t strategy) {
+    return guarded(h, [&]() -> int {
     if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");
     if (strategy < 0 || strategy > 2) return fail(h, MLVDB_ERR_INVALID_ARG, "unknown strategy");
     if (strategy == MLVDB_STRATEGY_FILTER && !filter_supported(h->ld))
         return fail(h, MLVDB_ERR_UNSUPPORTED, "filter strategy needs dim padded to a multiple of 64");
     h->strategy = strategy;
     return MLVDB_OK;
+    });
 }
 
 int mlvdb_index_set_profiling(mlvdb_index* h, int32_t enabled) {
+    return guarded(h, [&]() -> int {
     if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");
     h->profiling = enabled != 0;
     return MLVDB_OK;
+    });
 }
 
 int mlvdb_index_last_stats(mlvdb_index* h, mlvdb_stats* out) {
+    return guarded(h, [&]() -> int {
     int rc = check_handle(h);
     if (rc) return rc;
     if (!out) return fail(h, MLVDB_ERR_INVALID_ARG, "out is null");
@@ -1301,6 +1355,7 @@ int mlvdb_index_last_stats(mlvdb_index* h, mlvdb_stats* out) {
     h->stats.strategy_used = strategy;
     h->scan_events_used = 0;
     return MLVDB_OK;
+    });
 }
 
 }  // extern "C"

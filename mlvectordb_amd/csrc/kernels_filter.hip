@@ -653,7 +653,13 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     const int64_t my_tiles = ntiles_all > blockIdx.x ? (ntiles_all - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     if (my_tiles == 0) return;
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
-    if (lds_base != 0) __builtin_trap();  // the assembly toggles the Q buffers with xor 0x8000
+    // The assembly toggles the Q buffers with xor 0x8000, so the dynamic LDS must start at 0, i.e. the kernel may have no
+    // static LDS: launch_scan_asm checks that on the host (hipFuncGetAttributes) before the first launch.  Should it ever be
+    // violated all the same, the workgroup hands its queries to the exact fallback (overflow flags) instead of trapping.
+    if (lds_base != 0) {
+        for (int t = threadIdx.x; t < a.nq; t += kThreads) a.overflow[t] = 1u;
+        return;
+    }
 
     const uint32_t chunk_bytes = (uint32_t)(kChunkVec * sizeof(uint4));
     const uint32_t pb = (uint32_t)a.ld * (I8 ? 16u : 32u);  // bytes of one shadow panel (16 rows)
@@ -1925,6 +1931,13 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     const int grid = (int)(ntiles < max_grid ? ntiles : max_grid);
     auto kern = filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT, DMA, STAG>;
     static std::atomic<uint64_t> configured{0};  // per instantiation
+    static std::atomic<int> lds_base_ok{0};      // 0 = not checked yet, 1 = ok, -1 = the kernel has static LDS
+    if (lds_base_ok.load(std::memory_order_acquire) == 0) {
+        hipFuncAttributes attr{};
+        if (hipError_t e = hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(kern)); e != hipSuccess) return e;
+        lds_base_ok.store(attr.sharedSizeBytes == 0 ? 1 : -1, std::memory_order_release);
+    }
+    if (lds_base_ok.load(std::memory_order_acquire) < 0) return hipErrorInvalidConfiguration;  // dynamic LDS would not start at 0
     if (hipError_t e = ensure_dynamic_lds(configured, reinterpret_cast<const void*>(kern), (int)lds); e != hipSuccess)
         return e;
     kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end);

@@ -10,12 +10,12 @@ src/mlvectordb/implementations/index.py:21-22,56-63).  At the corpus sizes this 
 * ``uuid.UUID`` objects are kept only as a cache (an object array: the ids of rows that were added as
   ``Vector`` objects are already alive in the caller's storage, so the cache costs one pointer per row; rows
   added in bulk get their object on the first hit);
-* id -> label is a sorted array of the ids' first 8 bytes (uuid4: random) + ``searchsorted``, built on the first
+* id -> label is a sorted array of 8-byte keys mixed from all 16 id bytes + ``searchsorted``, built on the first
   ``remove`` / filtered search and extended by merging, never a dict.
 
 Semantics kept from the reference: labels are dense in insertion order; an id removed twice is a no-op the second
-time (index.py:76-81, ``dict.pop``); when the same id was added twice the newest row is the one ``remove`` finds
-(the dict entry was overwritten, index.py:62).
+time (index.py:76-81, ``dict.pop``); when the same id was added twice the newest row is the only one the id resolves
+to (the dict entry was overwritten, index.py:62): after it is removed the id is unknown, the older row stays.
 """
 from __future__ import annotations
 
@@ -114,7 +114,10 @@ class IdTable:
 
     # ------------------------------------------------------------------ id -> label
     def _key_of(self, raw: np.ndarray) -> np.ndarray:
-        return np.ascontiguousarray(raw[:, :8]).view(np.uint64).ravel()
+        # all 16 bytes take part (hi ^ lo * odd constant, wrapping): ids that share their first 8 bytes -- UUID(int=i)
+        # -- still get distinct keys, so lookups stay on the vectorised one-candidate path
+        halves = np.ascontiguousarray(raw).view(np.uint64).reshape(-1, 2)
+        return halves[:, 0] ^ (halves[:, 1] * np.uint64(0x9E3779B97F4A7C15))
 
     def _extend_index(self) -> None:
         if self._indexed == self.n:
@@ -156,10 +159,12 @@ class IdTable:
             cand = self._labels[lo[one]]
             match = (self.raw[cand] == raw[one]).all(axis=1) & self.live[cand]
             out[good[one[match]]] = cand[match]
-        for j in np.flatnonzero(hi - lo > 1).tolist():  # key collision or the same id added twice: newest live row
+        for j in np.flatnonzero(hi - lo > 1).tolist():  # key collision or the same id added twice
             cand = self._labels[lo[j]:hi[j]]
-            match = cand[(self.raw[cand] == raw[j]).all(axis=1) & self.live[cand]]
-            if match.size:
+            match = cand[(self.raw[cand] == raw[j]).all(axis=1)]
+            # the reference's dict holds ONE entry per id, the newest row (index.py:62); once that row is removed the id
+            # is unknown (dict.pop, index.py:76-81) -- an older row of the same id is never found again
+            if match.size and self.live[match.max()]:
                 out[good[j]] = match.max()
         return out
 

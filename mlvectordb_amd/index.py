@@ -203,13 +203,31 @@ class Index:
             bad = int(np.flatnonzero(~np.isfinite(rows).all(axis=1))[0])
             raise RuntimeError(f"row {bad} of the batch holds a non-finite value (NaN / inf): not indexable")
 
-    def _append(self, ns: _Namespace, vectors: Sequence[VectorProtocol]) -> None:
-        rows = self._stack_rows(vectors, ns.dim)
+    @staticmethod
+    def _check_ids(vectors: Sequence[VectorProtocol]) -> List[UUID]:
+        # the id table stores 16 bytes per row: anything else (SimpleVector("abc", ...)) is refused BEFORE the rows
+        # reach the engine, so a bad batch leaves the namespace exactly as it was
+        ids = [v.id for v in vectors]
+        for i, u in enumerate(ids):
+            if not isinstance(u, UUID):
+                raise RuntimeError(f"row {i} of the batch has id {u!r}: this index keys rows by uuid.UUID")
+        return ids
+
+    def _stage(self, vectors: Sequence[VectorProtocol], dim: int):
+        """Everything that can refuse a batch, before anything is mutated: (rows float32 [n, dim], ids)."""
+        for i, v in enumerate(vectors):
+            if getattr(v, "values", None) is None:
+                raise RuntimeError(f"row {i} of the batch carries no values (a storage row whose values live in HBM only)")
+        rows = self._stack_rows(vectors, dim)
         self._check_finite(rows)
+        return rows, self._check_ids(vectors)
+
+    def _append(self, ns: _Namespace, vectors: Sequence[VectorProtocol], staged=None) -> None:
+        rows, ids = staged if staged is not None else self._stage(vectors, ns.dim)
         first = ns.engine.append(rows)
-        if first != ns.total or ns.ids.append_uuids([v.id for v in vectors]) != first:
+        if first != ns.total or ns.ids.append_uuids(ids) != first:
             raise RuntimeError(f"engine label base {first} != host row count {ns.total}")
-        ns.total += len(vectors)
+        ns.total += len(ids)
 
     # ------------------------------------------------------------------ IndexProtocol
     def add(self, vectors: Iterable[VectorProtocol], namespace: str) -> None:
@@ -217,9 +235,23 @@ class Index:
         vectors = list(vectors)
         if not vectors:
             return
-        dim = int(np.asarray(vectors[0].values).shape[0])
+        known = self._ns.get(namespace)
+        dim = known.dim if known is not None else int(np.asarray(vectors[0].values).shape[0])
+        staged = self._stage(vectors, dim)  # a refused batch creates no namespace and appends nothing
         ns = self._get_or_create(namespace, dim, self._space)
-        self._append(ns, vectors)
+        self._append(ns, vectors, staged)
+
+    def validate_arrays(self, rows: np.ndarray, namespace: str, handles: Optional[np.ndarray] = None) -> None:
+        """Raises what ``add_arrays`` would raise for this batch, without touching the index: a caller that writes to a
+        second store first (``QueryProcessor.upsert_arrays``) checks here before it writes anything."""
+        if rows.ndim != 2:
+            raise RuntimeError(f"Wrong dimensionality of the vectors: expected a matrix, got shape {rows.shape}")
+        ns = self._ns.get(namespace)
+        if ns is not None and rows.shape[0] and rows.shape[1] != ns.dim:
+            raise RuntimeError(f"Wrong dimensionality of the vectors: got {rows.shape}, index dim {ns.dim}")
+        if handles is not None and np.asarray(handles).shape != (rows.shape[0],):
+            raise RuntimeError(f"{rows.shape[0]} rows but handles of shape {np.asarray(handles).shape}")
+        self._check_finite(rows)
 
     def add_arrays(self, rows: np.ndarray, namespace: str, ids: Optional[np.ndarray] = None,
                    handles: Optional[np.ndarray] = None) -> np.ndarray:
@@ -236,13 +268,9 @@ class Index:
             raise RuntimeError(f"{n} rows but {ids.shape[0]} ids")
         if n == 0:
             return ids
+        self.validate_arrays(rows, namespace, handles)  # every refusal happens before the engine is touched
         ns = self._get_or_create(namespace, rows.shape[1], self._space)
-        if rows.shape[1] != ns.dim:
-            raise RuntimeError(f"Wrong dimensionality of the vectors: got {rows.shape}, index dim {ns.dim}")
-        self._check_finite(rows)
         first = ns.engine.append(rows)
-        if handles is not None and np.asarray(handles).shape != (n,):
-            raise RuntimeError(f"{n} rows but handles of shape {np.asarray(handles).shape}")
         if first != ns.total or ns.ids.append_raw(ids, handles) != first:
             raise RuntimeError(f"engine label base {first} != host row count {ns.total}")
         ns.total += n
@@ -270,17 +298,28 @@ class Index:
         return self.search_many(values[None, :], top_k, namespace, metric)[0]
 
     def rebuild(self, source: Mapping[str, Iterable[VectorProtocol]], metric: str) -> None:
-        """Replace *every* namespace by ``source``, searching ``metric`` as the space (index.py:131-162)."""
-        for ns in self._ns.values():
-            ns.engine.close()
-        self._ns.clear()
+        """Replace *every* namespace by ``source``, searching ``metric`` as the space (index.py:131-162).
+
+        The whole source is staged and validated on the host first (values present, one dimensionality per namespace,
+        finite, UUID ids, a known space): a source that cannot be indexed raises and leaves the index as it was --
+        closing the engines first would have destroyed the only copy of rows that live in HBM only."""
+        if _SPACE_ALIASES.get(metric) is None:
+            raise RuntimeError(f"Space name must be one of l2, ip, cosine or euclidean (got {metric!r})")
+        staged = []
         for namespace, vectors in source.items():
             vectors = list(vectors)
             if not vectors:
                 continue
+            if getattr(vectors[0], "values", None) is None:
+                raise RuntimeError(f"namespace {namespace!r}: the source rows carry no values")
             dim = int(np.asarray(vectors[0].values).shape[0])
+            staged.append((namespace, dim, vectors, self._stage(vectors, dim)))
+        for ns in self._ns.values():
+            ns.engine.close()
+        self._ns.clear()
+        for namespace, dim, vectors, st in staged:
             ns = self._get_or_create(namespace, dim, metric)
-            self._append(ns, vectors)
+            self._append(ns, vectors, st)
 
     def is_rebuild_required(self, namespace: str) -> bool:
         ns = self._ns.get(namespace)

@@ -205,8 +205,9 @@ class MultiDeviceEngine:
 
     def _resolve_fp32_ties(self, q: np.ndarray, lab: np.ndarray, d: np.ndarray, sh: np.ndarray) -> np.ndarray:
         """A single index ranks hits by the fp64 distance and returns its fp32 rounding; shards return only the
-        rounding.  Hits of different shards whose fp32 distances are equal are re-ranked here by the fp64 distance
-        recomputed on the host from the stored rows (rare: a handful of rows per query at most)."""
+        rounding.  Hits whose fp32 distances are equal (same shard or not: the label-ordered merge above has lost the
+        shard's own fp64 order too) are re-ranked here by the fp64 distance recomputed on the host from the stored rows
+        (rare: a handful of rows per query at most)."""
         if lab.size < 2:
             return lab
         same = np.flatnonzero(d[1:] == d[:-1])
@@ -215,8 +216,8 @@ class MultiDeviceEngine:
         lab = lab.copy()
         edges = np.flatnonzero(d[1:] != d[:-1]) + 1
         for a, b in zip(np.concatenate([[0], edges]).tolist(), np.concatenate([edges, [lab.size]]).tolist()):
-            if b - a < 2 or (sh[a:b] == sh[a]).all():
-                continue
+            if b - a < 2:
+                continue  # (groups from one shard too: the merge above ordered them by label, not by the shard's fp64 rank)
             rows = self.get_rows_at(lab[a:b]).astype(np.float64)
             q64 = q.astype(np.float64)
             if self.space == "l2":

@@ -167,8 +167,27 @@ class QueryProcessor:
             else:
                 source = dict(full)
                 source.setdefault(namespace, [])
-            self._index.rebuild(source, metric=self._index._space)
+            self._index.rebuild(self._with_values(source), metric=self._index._space)
         return removed
+
+    def _with_values(self, source):
+        """Rebuild sources whose rows keep their values in HBM only (``upsert_arrays(keep_host_copy=False)``): the
+        values are read back from the index BEFORE ``rebuild`` closes the engines that hold the only copy."""
+        fetch = getattr(self._index, "fetch_values_by_id", None)
+        out = {}
+        for name, rows in source.items():
+            rows = list(rows)
+            missing = [i for i, v in enumerate(rows) if getattr(v, "values", None) is None]
+            if missing:
+                if fetch is None:
+                    raise RuntimeError(f"namespace {name!r}: stored rows carry no values and the index cannot supply them")
+                from .storage import StoredRow
+
+                vals = fetch(name, [rows[i].id for i in missing])
+                for i, val in zip(missing, vals):
+                    rows[i] = StoredRow(rows[i].id, val, rows[i].metadata)
+            out[name] = rows
+        return out
 
     # ---- introspection (query_processor.py:64-82)
     def list_namespaces(self) -> List[str]:
@@ -197,6 +216,13 @@ class QueryProcessor:
         values = np.ascontiguousarray(values, dtype=np.float32)
         if values.ndim != 2:
             raise RuntimeError(f"Wrong dimensionality of the vectors: expected a matrix, got shape {values.shape}")
+        if not keep_host_copy and self._rebuild_scope == "namespace":
+            # Q4's rebuild drops every other namespace from the index; with the values in HBM only that would be data loss
+            raise ValueError('keep_host_copy=False needs rebuild_scope="all": a namespace-scoped rebuild closes the other '
+                             "namespaces' engines, which would hold the only copy of their rows")
+        # the index's refusals (dimension, non-finite rows) come before the storage is written: no ghost rows
+        if hasattr(self._index, "validate_arrays"):
+            self._index.validate_arrays(values, namespace)
         ids = mint_uuid4_bytes(values.shape[0])
         first = self._storage.write_arrays(ids, namespace, values if keep_host_copy else None, metadata)
         self._index.add_arrays(values, namespace, ids=ids,

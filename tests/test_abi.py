@@ -83,3 +83,51 @@ def test_panel_layout_restatement():
             assert o == base + 16 * r + 4 * g
             offs.update(range(o - base, o - base + 4))
         assert offs == set(range(256))
+
+
+def test_every_handle_entry_refuses_a_null_handle_with_a_status_code():
+    """No entry point dereferences the handle before checking it (mlvdb_search_batch_device(NULL, ...) used to
+    segfault), and none lets a C++ exception cross the ABI: a status comes back, never a signal.  No HIP call is made for a
+    null handle, so this runs without a GPU."""
+    lib = _native.load()
+    null = C.c_void_p()
+    z64 = C.c_int64(0)
+    buf = (C.c_float * 4)()
+    calls = {
+        "mlvdb_index_append": (null, buf, 1, C.byref(z64)),
+        "mlvdb_index_append_device": (null, buf, 1, C.byref(z64)),
+        "mlvdb_index_tombstone": (null, buf, 1, C.byref(z64)),
+        "mlvdb_index_compact": (null, buf, 1, C.byref(z64)),
+        "mlvdb_index_counts": (null, C.byref(z64), C.byref(z64)),
+        "mlvdb_index_reset": (null, -1),
+        "mlvdb_index_get_rows": (null, 0, 1, buf),
+        "mlvdb_index_get_rows_at": (null, buf, 1, buf),
+        "mlvdb_search_batch": (null, buf, 1, 1, buf, buf, buf),
+        "mlvdb_search_batch_filtered": (null, buf, 1, 1, buf, buf, buf, buf),
+        "mlvdb_search_batch_ex": (null, buf, 1, 1, buf, buf, buf, buf, buf),
+        "mlvdb_search_batch_device": (null, buf, 1, 1, buf, buf, buf, buf, None),
+        "mlvdb_range_batch": (null, buf, 1, 1.0, 1, buf, buf, buf),
+        "mlvdb_index_set_strategy": (null, 0),
+        "mlvdb_index_set_profiling": (null, 0),
+        "mlvdb_index_last_stats": (null, C.byref(_native.Stats())),
+    }
+    handle_entries = [n for n, (_, argtypes) in _native.SIGNATURES.items()
+                      if argtypes[:1] == [C.c_void_p] and n not in ("mlvdb_index_destroy", "mlvdb_last_error")]
+    assert sorted(calls) == sorted(handle_entries), "a handle-taking entry point is missing from this test"
+    for name, args in calls.items():
+        assert getattr(lib, name)(*args) == 1, name  # MLVDB_ERR_INVALID_ARG
+        assert b"null index handle" in lib.mlvdb_last_global_error(), name
+    assert lib.mlvdb_index_destroy(null) == 0  # destroying nothing is not an error (free(NULL) convention)
+
+
+def test_every_extern_c_entry_runs_inside_the_exception_guard():
+    """The header's promise "never throws" is structural: each non-trivial extern "C" function body in api.hip is one
+    `return guarded(...)` statement (catch bad_alloc -> OUT_OF_MEMORY, anything else -> INTERNAL)."""
+    text = (ROOT / "mlvectordb_amd" / "csrc" / "api.hip").read_text()
+    region = text[text.index('extern "C" {'):text.index('}  // extern "C"')]
+    bodies = re.findall(r"^int (mlvdb_\w+)\([^)]*\) \{\n(.*?)^\}", region, flags=re.S | re.M)
+    assert len(bodies) >= 19
+    for name, body in bodies:
+        if name == "mlvdb_abi_version":
+            continue
+        assert body.lstrip().startswith("return guarded("), f"{name} is not wrapped by guarded()"

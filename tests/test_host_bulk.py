@@ -56,7 +56,12 @@ def test_idtable_same_id_twice_newest_row_wins_and_minted_ids_are_uuid4():
     t.append_uuids([u, uuid.uuid4(), u])
     assert t.lookup([u]).tolist() == [2]       # the dict entry was overwritten (index.py:62)
     t.kill([2])
-    assert t.lookup([u]).tolist() == [0]
+    assert t.lookup([u]).tolist() == [-1]      # dict.pop removed the id's one entry (index.py:76-81): the old row is unreachable
+    seq = IdTable()                            # ids that share their first 8 bytes still get distinct sorted keys
+    seq.append_uuids([uuid.UUID(int=i) for i in range(1, 400)])
+    assert seq.lookup([uuid.UUID(int=7), uuid.UUID(int=399), uuid.UUID(int=400)]).tolist() == [6, 398, -1]
+    seq._extend_index()
+    assert np.unique(seq._keys).size == 399
     raw = mint_uuid4_bytes(100)
     assert len({bytes(r) for r in raw}) == 100
     assert all(uuid.UUID(bytes=bytes(r)).version == 4 and uuid.UUID(bytes=bytes(r)).variant == uuid.RFC_4122 for r in raw)

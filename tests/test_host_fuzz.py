@@ -20,11 +20,13 @@ _ops = st.lists(st.tuples(st.sampled_from(["add_obj", "add_raw", "kill", "lookup
 @settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow])
 @given(_ops)
 def test_idtable_behaves_like_the_two_dicts(ops):
-    # model: {label: id} of the live rows; an id resolves to its newest live row (idtable.py header)
-    t, live, known = IdTable(), {}, []
+    # model: the reference's two dicts -- {label: id} of the live rows and {id: label}, whose entry is overwritten when an
+    # id is added again (index.py:62) and popped when it is removed (index.py:76-81): an older row of a removed id is
+    # never found again
+    t, live, known, u2l = IdTable(), {}, [], {}
 
     def model_lookup(u):
-        return max((lab for lab, x in live.items() if x == u), default=-1)
+        return u2l.get(u, -1)
 
     for op, seed in ops:
         rng = np.random.default_rng(seed)
@@ -36,6 +38,7 @@ def test_idtable_behaves_like_the_two_dicts(ops):
             first = t.append_uuids(batch) if op == "add_obj" else t.append_raw(uuids_to_bytes(batch))
             assert first == rows_before and t.n == rows_before + len(batch)
             live.update({first + i: u for i, u in enumerate(batch)})
+            u2l.update({u: first + i for i, u in enumerate(batch)})
             known += batch
         elif op == "kill" and known:
             victims = [known[int(i)] for i in rng.integers(0, len(known), 3)] + [uuid.UUID(bytes=rng.bytes(16))]
@@ -44,7 +47,7 @@ def test_idtable_behaves_like_the_two_dicts(ops):
             hit = np.unique(labels[labels >= 0])
             t.kill(hit)
             for lab in hit.tolist():
-                del live[lab]
+                del u2l[live.pop(lab)]
             assert set(t.dead_labels().tolist()) == set(range(t.n)) - set(live)
         elif op == "lookup" and known:
             probe = [known[int(i)] for i in rng.integers(0, len(known), 5)] + [None, "not-an-id"]
@@ -54,6 +57,7 @@ def test_idtable_behaves_like_the_two_dicts(ops):
             keep = np.array(sorted(live), dtype=np.int64)
             t = t.take(keep)
             live = {new: live[old] for new, old in enumerate(keep.tolist())}
+            u2l = {u: lab for lab, u in live.items()}  # a rebuild re-adds the survivors in order: the newest row wins again
     got = t.uuids_at(np.arange(-1, t.n + 1))
     assert got[0] is None and got[-1] is None
     assert {i: u for i, u in enumerate(got[1:-1].tolist()) if u is not None} == live

@@ -269,3 +269,98 @@ def test_load_index_missing_or_inconsistent_snapshot(tmp_path):
     assert i.namespace_counts("a") == (6, 0)  # validation happens before anything is dropped
     empty = idx("ip")
     assert empty.save_index(str(tmp_path / "empty")) and idx("l2").load_index(str(tmp_path / "empty"))
+
+
+# ---- nothing is mutated by a batch the index refuses; rebuild never destroys the only copy of the rows
+def _oracle_qp(scope="all"):
+    from mlvectordb_amd import ArrayStorage
+
+    index = Index(space="l2", engine_factory=OracleScanEngine)
+    return QueryProcessor(ArrayStorage(), index, rebuild_scope=scope), index
+
+
+def test_a_refused_batch_leaves_the_namespace_exactly_as_it_was():
+    from mlvectordb_amd import SimpleVector
+
+    index = Index(space="l2", engine_factory=OracleScanEngine)
+    good = [Vector(values=[float(i), 1.0, 2.0]) for i in range(4)]
+    index.add(good, "ns")
+    with pytest.raises(RuntimeError, match="uuid.UUID"):  # a non-UUID id is refused before the rows reach the engine
+        index.add([Vector(values=[9.0, 9.0, 9.0]), SimpleVector("abc", [1.0, 2.0, 3.0])], "ns")
+    with pytest.raises(RuntimeError, match="non-finite"):
+        index.add([Vector(values=[np.nan, 0.0, 0.0])], "ns")
+    with pytest.raises(RuntimeError, match="handles"):
+        index.add_arrays(np.ones((2, 3), np.float32), "ns", handles=np.arange(3))
+    with pytest.raises(RuntimeError):  # a refused first batch does not even create the namespace
+        index.add([SimpleVector("x", [1.0, 2.0])], "fresh")
+    assert index.namespace_counts("fresh") == (0, 0) and "fresh" not in index._ns
+    assert index.namespace_counts("ns") == (4, 0) and index._ns["ns"].engine.counts() == (4, 0)
+    index.add([Vector(values=[5.0, 5.0, 5.0])], "ns")  # engine and host row counts still agree: adds keep working
+    assert index.namespace_counts("ns") == (5, 0)
+
+
+def test_upsert_arrays_validates_before_the_storage_is_written():
+    qp, index = _oracle_qp()
+    qp.upsert_arrays(np.ones((3, 4), np.float32), "ns")
+    bad = np.ones((2, 4), np.float32)
+    bad[1, 2] = np.inf
+    with pytest.raises(RuntimeError, match="non-finite"):
+        qp.upsert_arrays(bad, "ns")
+    with pytest.raises(RuntimeError, match="dimensionality"):
+        qp.upsert_arrays(np.ones((2, 5), np.float32), "ns")
+    assert qp.get_namespace_count("ns") == 3 and index.namespace_counts("ns") == (3, 0)  # no ghost rows in the storage
+
+
+def test_rebuild_stages_its_source_before_it_closes_anything():
+    index = Index(space="l2", engine_factory=OracleScanEngine)
+    rows = [Vector(values=[float(i), 0.0]) for i in range(5)]
+    index.add(rows, "a")
+
+    class NoValues:
+        id, values, metadata = rows[0].id, None, {}
+
+    for bad_source in ({"a": [NoValues()]}, {"a": rows, "b": [Vector(values=[np.nan, 1.0])]},
+                       {"a": [Vector(values=[1.0, 2.0]), Vector(values=[1.0, 2.0, 3.0])]}):
+        with pytest.raises(RuntimeError):
+            index.rebuild(bad_source, metric="l2")
+        assert index.namespace_counts("a") == (5, 0)  # untouched
+        assert index.search(VectorDTO(values=[3.0, 0.0], metadata={}), 1, "a", "l2")[0].vector_id == rows[3].id
+    with pytest.raises(RuntimeError, match="Space name"):
+        index.rebuild({"a": rows}, metric="manhattan")
+    assert index.namespace_counts("a") == (5, 0)
+
+
+def test_delete_with_rows_kept_in_hbm_only_survives_the_rebuild_path():
+    """ArrayStorage without a host copy of the values + an index without compact(): the rebuild source is read back
+    from the index before its engines are closed (round 2: IndexError after the rows were already gone)."""
+    qp, index = _oracle_qp()
+    index.compact = None  # force the rebuild-from-storage path (what an index without device compaction takes)
+    vals = np.arange(40, dtype=np.float32).reshape(10, 4)
+    ids = qp.upsert_arrays(vals, "ns", keep_host_copy=False)
+    other = qp.upsert_arrays(vals[:3] + 100.0, "other", keep_host_copy=False)
+    from uuid import UUID
+
+    victims = [UUID(bytes=ids[i].tobytes()) for i in (0, 1, 2)]  # 3/10 >= 0.2: the trigger fires
+    assert list(qp.delete(victims, "ns")) == victims
+    assert index.namespace_counts("ns") == (7, 0) and index.namespace_counts("other") == (3, 0)
+    hit = qp.find_similar(VectorDTO(values=vals[5], metadata={}), top_k=1, namespace="ns", metric="l2")[0]
+    assert hit["id"] == UUID(bytes=ids[5].tobytes()) and np.array_equal(hit["values"], vals[5])
+    hit = qp.find_similar(VectorDTO(values=vals[1] + 100.0, metadata={}), top_k=1, namespace="other", metric="l2")[0]
+    assert hit["id"] == UUID(bytes=other[1].tobytes())
+
+
+def test_namespace_scoped_rebuild_refuses_rows_kept_in_hbm_only():
+    qp, _ = _oracle_qp(scope="namespace")
+    with pytest.raises(ValueError, match="rebuild_scope"):
+        qp.upsert_arrays(np.ones((2, 4), np.float32), "ns", keep_host_copy=False)
+    qp.upsert_arrays(np.ones((2, 4), np.float32), "ns")  # with a host copy the reference's Q4 behaviour is available
+
+
+def test_remove_of_an_id_added_twice_is_a_no_op_the_second_time():
+    index = Index(space="l2", engine_factory=OracleScanEngine, rebuild_threshold=2.0)
+    v = Vector(values=[1.0, 0.0])
+    index.add([v, Vector(values=[0.0, 1.0]), v], "ns")
+    index.remove([v.id], "ns")
+    assert index.namespace_counts("ns") == (3, 1)
+    index.remove([v.id], "ns")  # reference: dict.pop already dropped the id (index.py:76-81)
+    assert index.namespace_counts("ns") == (3, 1)
