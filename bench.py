@@ -38,10 +38,18 @@ def kernel_source_sha16() -> str:
     kernel version; variant / diagnostic plumbing elsewhere in the sources does not invalidate it."""
     import hashlib
 
+    import importlib.util
+
     h = hashlib.sha256()
     csrc = ROOT / "mlvectordb_amd" / "csrc"
-    for rel in ("scan_asm_cosine_i8_va.inc", "scan_asm_l2_i8_va.inc", "scan_asm_ip_i8_va.inc", "scan_common.h"):
-        h.update((csrc / rel).read_bytes())
+    # the generated bodies are build products (not tracked): their text is regenerated here from tools/gen_scan_asm.py,
+    # exactly as `make` writes scan_asm_<space>_i8_va.inc
+    spec = importlib.util.spec_from_file_location("_mlvdb_gen_scan_asm", ROOT / "tools" / "gen_scan_asm.py")
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    for space in ("cosine", "l2", "ip"):
+        h.update(gen.default_i8_body(space).encode())
+    h.update((csrc / "scan_common.h").read_bytes())
     src = (csrc / "kernels_filter.hip").read_text()
     a = src.index("void filter_scan_asm_kernel(")
     b = src.index("// ------------------------------------------------------------------ threshold update + compaction")

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLVDB_ABI_VERSION 3
+#define MLVDB_ABI_VERSION 4
 
 /* status codes */
 #define MLVDB_OK 0
@@ -181,6 +181,16 @@ int mlvdb_search_batch_ex(mlvdb_index* h, const float* queries, int64_t nq, int3
  */
 int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float radius, int64_t capacity,
                       int64_t* out_labels, float* out_dist, int64_t* out_counts);
+
+/*
+ * Exact distances of given (query, row) pairs, in the index's space: out_dist64[q*m + j] = distance of queries[q] to the
+ * row labels[q*m + j] (fp64; out_dist, optional, its fp32 rounding).  The vector-level face of the search arithmetic --
+ * what the reference's README calls SimpleVector.distance() / similarity() (README.md:30-41,178-181; no reference code)
+ * -- computed by the same summation as the scans, so a pair scored here equals, bit for bit, the distance a search
+ * returns for it.  A label < 0 (search padding) gives +inf; labels >= total are an error; tombstoned rows still score.
+ */
+int mlvdb_pair_distances(mlvdb_index* h, const float* queries, int64_t nq, const int64_t* labels, int64_t m,
+                         double* out_dist64, float* out_dist);
 
 /* Strategy override (testing / benchmarking); default MLVDB_STRATEGY_AUTO. */
 int mlvdb_index_set_strategy(mlvdb_index* h, int32_t strategy);

@@ -1301,6 +1301,40 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
     });
 }
 
+int mlvdb_pair_distances(mlvdb_index* h, const float* queries, int64_t nq, const int64_t* labels, int64_t m,
+                         double* out_dist64, float* out_dist) {
+    return guarded(h, [&]() -> int {
+    int rc = check_handle(h);
+    if (rc) return rc;
+    if (nq < 0 || nq > (1 << 24) || m < 0 || m > (1 << 24)) return fail(h, MLVDB_ERR_INVALID_ARG, "nq / m out of range");
+    if (nq == 0 || m == 0) return MLVDB_OK;
+    if (!queries || !labels || !out_dist64) return fail(h, MLVDB_ERR_INVALID_ARG, "null buffer");
+    for (int64_t i = 0; i < nq * m; ++i)
+        if (labels[i] >= h->total) return fail(h, MLVDB_ERR_INVALID_ARG, "label out of range");
+    hipStream_t s = h->aux_stream;  // rows are immutable once appended: may overlap a search in flight on h->stream
+    // private buffers of the auxiliary stream (gather_out / gather_lab) + query staging of its own
+    const size_t qbytes = (size_t)nq * h->dim * sizeof(float), pbytes = (size_t)nq * h->ld * sizeof(float);
+    const size_t abytes = (size_t)nq * sizeof(double), o64 = (size_t)nq * m * sizeof(double), o32 = (size_t)nq * m * sizeof(float);
+    HIP_TRY(h, h->gather_lab.ensure((size_t)nq * m * sizeof(int64_t)));
+    HIP_TRY(h, h->gather_out.ensure(qbytes + pbytes + abytes + o64 + o32 + 64));
+    char* base = h->gather_out.as<char>();
+    double* d_o64 = reinterpret_cast<double*>(base);  // 8-byte aligned pieces first
+    double* d_aux = reinterpret_cast<double*>(base + o64);
+    float* d_pad = reinterpret_cast<float*>(base + o64 + abytes);
+    float* d_q = reinterpret_cast<float*>(base + o64 + abytes + pbytes);
+    float* d_o32 = reinterpret_cast<float*>(base + o64 + abytes + pbytes + qbytes);
+    HIP_TRY(h, hipMemcpyAsync(d_q, queries, qbytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(h, hipMemcpyAsync(h->gather_lab.p, labels, (size_t)nq * m * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, launch_query_prep(d_q, (int32_t)nq, h->dim, h->ld, h->space, d_pad, d_aux, nullptr, s));
+    HIP_TRY(h, launch_pair_distances(h->X, d_pad, d_aux, h->gather_lab.as<int64_t>(), (int32_t)nq, (int32_t)m, h->ld, h->space,
+                                     d_o64, out_dist ? d_o32 : nullptr, s));
+    HIP_TRY(h, hipMemcpyAsync(out_dist64, d_o64, o64, hipMemcpyDeviceToHost, s));
+    if (out_dist) HIP_TRY(h, hipMemcpyAsync(out_dist, d_o32, o32, hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    return MLVDB_OK;
+    });
+}
+
 int mlvdb_index_set_strategy(mlvdb_index* h, int32_t strategy) {
     return guarded(h, [&]() -> int {
     if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");

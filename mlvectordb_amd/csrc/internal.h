@@ -96,6 +96,10 @@ hipError_t launch_exact_merge(const TopEntry* partial, int32_t nq_sel, const int
                               int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_d64,
                               hipStream_t s);
 
+// exact fp64 distances of given pairs: out[q][j] = d(query q, row labels[q][j]) (labels on the device, each < total or < 0 = +inf)
+hipError_t launch_pair_distances(const float* X, const float* Qpad, const double* qaux, const int64_t* labels, int32_t nq,
+                                 int32_t m, int32_t ld, int32_t space, double* out64, float* out32, hipStream_t s);
+
 // ---------------------------------------------------------------- filter path (kernels_filter.hip)
 constexpr int kFilterQueries = 256;   // queries per filter pass
 constexpr int kFilterChunkK = 64;     // columns per Q chunk staged in LDS

@@ -255,6 +255,63 @@ hipError_t launch_exact_range_scan(const FilterArgs& a, float radius, const int3
 }
 
 // ------------------------------------------------------------------------------ host side
+// ------------------------------------------------------------------ exact distances of given (query, label) pairs
+// The vector-level face of the same arithmetic (reference README.md:30-41,178-181: SimpleVector.distance / similarity):
+// out[q][j] = distance of query q to row labels[q][j] in the index's space, fp64, by the very accumulate_rows the exact
+// scan and the rescoring use -- so a pair scored here is bit-identical to the score a search returns for it.
+// Block (q, chunk): 4 waves, each scores 16 pairs per step.  label < 0: +inf (search padding passes through).
+template <int SPACE>
+__global__ __launch_bounds__(256) void pair_distance_kernel(const float* __restrict__ X, const float* __restrict__ Qpad,
+                                                            const double* __restrict__ qaux, const int64_t* __restrict__ labels,
+                                                            int32_t m, int32_t ld, double* __restrict__ out64,
+                                                            float* __restrict__ out32) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* qs = reinterpret_cast<double*>(smem);  // [ld]
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    for (int c = threadIdx.x; c < ld; c += 256) qs[c] = (double)Qpad[(int64_t)q * ld + c];
+    __syncthreads();
+    const double qinv = qaux[q];
+    const int64_t* lab = labels + (int64_t)q * m;
+    for (int j0 = (blockIdx.y * 4 + wave) * 16; j0 < m; j0 += gridDim.y * 64) {
+        const int j = j0 + r;
+        const bool have = j < m;
+        const int64_t row = have ? lab[j] : -1;
+        const int64_t rr = row >= 0 ? row : 0;
+        const float* base[1] = {X + (rr >> 4) * (int64_t)(kPanelRows * ld) + (rr & 15) * 16 + g * 4};
+        double acc[1][1], nx[1];
+        accumulate_rows<SPACE, 1, 1, 8>(base, qs, ld, g, acc, nx);
+        const double d = row >= 0 ? finish_distance<SPACE>(acc[0][0], nx[0], qinv) : __builtin_inf();
+        if (have && lane < 16) {
+            out64[(int64_t)q * m + j] = d;
+            if (out32) out32[(int64_t)q * m + j] = (float)d;
+        }
+    }
+}
+
+hipError_t launch_pair_distances(const float* X, const float* Qpad, const double* qaux, const int64_t* labels, int32_t nq,
+                                 int32_t m, int32_t ld, int32_t space, double* out64, float* out32, hipStream_t s) {
+    if (nq <= 0 || m <= 0) return hipSuccess;
+    const size_t lds = (size_t)ld * sizeof(double);
+    const dim3 grid((unsigned)nq, (unsigned)std::min<int64_t>(64, ((int64_t)m + 63) / 64));
+    hipError_t e = hipSuccess;
+#define MLVDB_LAUNCH_PAIRS(SP)                                                                                         \
+    do {                                                                                                               \
+        auto kern = pair_distance_kernel<SP>;                                                                          \
+        if (lds > 48 * 1024)                                                                                           \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) kern<<<grid, 256, lds, s>>>(X, Qpad, qaux, labels, m, ld, out64, out32);                   \
+    } while (0)
+    switch (space) {
+        case kSpaceL2: MLVDB_LAUNCH_PAIRS(kSpaceL2); break;
+        case kSpaceCosine: MLVDB_LAUNCH_PAIRS(kSpaceCosine); break;
+        default: MLVDB_LAUNCH_PAIRS(kSpaceIp); break;
+    }
+#undef MLVDB_LAUNCH_PAIRS
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
 ExactPlan plan_exact(int64_t nrows, int32_t ld, int32_t nq_sel, int32_t k) {
     ExactPlan p;
     int qt = nq_sel >= 8 ? 8 : nq_sel >= 4 ? 4 : nq_sel >= 2 ? 2 : 1;

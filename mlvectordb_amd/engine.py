@@ -33,6 +33,8 @@ class ScanEngine(Protocol):
 
     def get_rows_at(self, labels: np.ndarray) -> np.ndarray: ...
 
+    def pair_distances(self, queries: np.ndarray, labels: np.ndarray) -> Tuple[np.ndarray, np.ndarray]: ...
+
     def search(self, queries: np.ndarray, k: int, mask: np.ndarray | None = None
                ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]: ...
 
@@ -139,6 +141,21 @@ class HipScanEngine:
         self._check(self._lib.mlvdb_index_get_rows_at(self._h, labels.ctypes.data, labels.size, out.ctypes.data),
                     "get_rows_at")
         return out
+
+    def pair_distances(self, queries: np.ndarray, labels: np.ndarray):
+        """Exact distances of the pairs (queries[q], row labels[q, j]) in this index's space, by the kernels' own fp64
+        summation (``mlvdb_pair_distances``): (float64 [nq, m], float32 [nq, m]); label -1 gives +inf."""
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        if queries.ndim != 2 or queries.shape[1] != self.dim:
+            raise RuntimeError(f"Wrong dimensionality of the vectors: got {queries.shape}, index dim {self.dim}")
+        labels = np.ascontiguousarray(labels, dtype=np.int64)
+        if labels.ndim != 2 or labels.shape[0] != queries.shape[0]:
+            raise RuntimeError(f"labels must be [nq, m]; got {labels.shape} for {queries.shape[0]} queries")
+        d64 = np.empty(labels.shape, dtype=np.float64)
+        d32 = np.empty(labels.shape, dtype=np.float32)
+        self._check(self._lib.mlvdb_pair_distances(self._h, queries.ctypes.data, queries.shape[0], labels.ctypes.data,
+                                                   labels.shape[1], d64.ctypes.data, d32.ctypes.data), "pair_distances")
+        return d64, d32
 
     def search64(self, queries: np.ndarray, k: int, mask: np.ndarray | None = None):
         """kNN; ``mask`` (optional, one byte per row, non-zero = allowed) restricts the search to those rows.

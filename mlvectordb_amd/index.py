@@ -443,6 +443,31 @@ class Index:
         ns = self._ns[namespace]
         return ns.engine.get_rows_at(np.asarray(labels, dtype=np.int64))
 
+    def distances(self, queries, ids, namespace: str, metric: str) -> np.ndarray:
+        """Additive (SURVEY 8a row a8': the vector-level ``distance()`` / ``similarity()`` of reference README.md:30-41,
+        178-181, on the device): the score ``search`` reports for each pair (queries[q], stored vector ids[q][j]) --
+        float64 array ``[nq, m]`` of the float32-rounded distance in the namespace's space, post-processed like
+        ``search`` (``1 - d`` for metric "cosine", sqrt for "euclidean").  ``ids`` is ``[nq][m]`` UUIDs or an int64 label
+        array; unknown / removed ids give NaN.  Computed by the kernels' own fp64 summation over the rows in HBM, so
+        ``distances(q, [hit.vector_id])`` equals that hit's score exactly."""
+        q = self._coerce_queries(queries)
+        ns = self._ns.get(namespace)
+        if ns is None or q.shape[1] != ns.dim:
+            raise RuntimeError(f"namespace {namespace!r} is unknown or its dimensionality differs from the queries'")
+        if isinstance(ids, np.ndarray) and ids.dtype.kind in "iu":
+            labels = np.asarray(ids, dtype=np.int64).reshape(q.shape[0], -1)
+        else:
+            rows = [list(r) for r in ids]
+            m = len(rows[0]) if rows else 0
+            if any(len(r) != m for r in rows) or len(rows) != q.shape[0]:
+                raise RuntimeError("ids must hold the same number of ids for every query")
+            labels = ns.ids.lookup([u for r in rows for u in r]).reshape(q.shape[0], m)
+        known = labels >= 0
+        _, d32 = ns.engine.pair_distances(q, np.where(known, labels, -1))
+        out = self._scores(d32, metric)
+        out[~known] = np.nan
+        return out
+
     def fetch_values_by_id(self, namespace: str, ids: Sequence[UUID]) -> np.ndarray:
         """``fetch_values`` addressed by id (every id must be live in the namespace)."""
         ns = self._ns[namespace]

@@ -144,6 +144,27 @@ class MultiDeviceEngine:
                 out[p[0]] = rows
         return out
 
+    def pair_distances(self, queries: np.ndarray, labels: np.ndarray):
+        """``HipScanEngine.pair_distances`` over global labels: every pair is scored by the shard that holds the row."""
+        queries = np.ascontiguousarray(queries, dtype=np.float32)
+        labels = np.ascontiguousarray(labels, dtype=np.int64)
+        if labels.ndim != 2 or labels.shape[0] != queries.shape[0]:
+            raise RuntimeError(f"labels must be [nq, m]; got {labels.shape} for {queries.shape[0]} queries")
+        if labels.size and labels.max() >= self._total:
+            raise RuntimeError("label out of range")
+        d64 = np.full(labels.shape, np.inf)
+        d32 = np.full(labels.shape, np.inf, dtype=np.float32)
+        which = np.where(labels >= 0, self._g2s[np.maximum(labels, 0)] if self._total else -1, -1)
+        args = []
+        for s in range(len(self.shards)):
+            mine = which == s
+            args.append((queries, np.where(mine, self._g2l[np.maximum(labels, 0)], -1)) if mine.any() else None)
+        for s, r in enumerate(self._each(lambda sh, q, loc: sh.pair_distances(q, loc), args)):
+            if r is not None:
+                mine = which == s
+                d64[mine], d32[mine] = r[0][mine], r[1][mine]
+        return d64, d32
+
     def get_rows(self, first: int, n: int) -> np.ndarray:
         if first < 0 or n < 0 or first + n > self._total:
             raise RuntimeError("row range out of bounds")

@@ -59,6 +59,14 @@ class OracleScanEngine:
     def get_rows_at(self, labels: np.ndarray) -> np.ndarray:
         return self._rows[np.asarray(labels, dtype=np.int64).ravel()].copy()
 
+    def pair_distances(self, queries: np.ndarray, labels: np.ndarray):
+        labels = np.asarray(labels, dtype=np.int64)
+        if labels.size and labels.max() >= self._rows.shape[0]:
+            raise RuntimeError("label out of range")
+        full = exact_scan.exact_distances(queries, self._rows, self.space)
+        d64 = np.where(labels >= 0, np.take_along_axis(full, np.maximum(labels, 0), axis=1), np.inf)
+        return d64, d64.astype(np.float32)
+
     def search64(self, queries: np.ndarray, k: int, mask=None):
         labels, dist, counts = self.search(queries, k, mask)
         d64 = np.full(labels.shape, np.inf)

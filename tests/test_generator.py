@@ -1,5 +1,6 @@
-"""The committed scan bodies (mlvectordb_amd/csrc/scan_asm_*.inc) are exactly what tools/gen_scan_asm.py emits, and the
-dispatch header covers every generated body (CPU only: text generation, no assembler)."""
+"""The scan bodies (mlvectordb_amd/csrc/scan_asm_*.inc: build products of `make`, not tracked) are what
+tools/gen_scan_asm.py emits into any directory: every listed file is written, the dispatch header covers every body, each
+body is one asm statement; a built tree must hold exactly the generator's current output (CPU only: text generation)."""
 import subprocess
 import sys
 from pathlib import Path
@@ -8,7 +9,7 @@ ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "mlvectordb_amd" / "csrc"
 
 
-def test_committed_scan_bodies_match_the_generator(tmp_path):
+def test_scan_bodies_are_what_the_generator_emits(tmp_path):
     gen = ROOT / "tools" / "gen_scan_asm.py"
     names = subprocess.run([sys.executable, str(gen), "--list"], check=True, capture_output=True, text=True).stdout.split()
     subprocess.run([sys.executable, str(gen), "--outdir", str(tmp_path)], check=True, capture_output=True)
@@ -16,9 +17,22 @@ def test_committed_scan_bodies_match_the_generator(tmp_path):
     dispatch = (tmp_path / "scan_asm_dispatch.inc").read_text()
     for name in names:
         fresh = (tmp_path / name).read_text()
-        assert (CSRC / name).read_text() == fresh, f"{name}: regenerate with `make -C mlvectordb_amd/csrc`"
+        if (CSRC / name).exists():  # a built tree: what the library was compiled from is the generator's current output
+            assert (CSRC / name).read_text() == fresh, f"{name}: regenerate with `make -C mlvectordb_amd/csrc`"
         if name.startswith("scan_asm_") and name not in ("scan_asm_dispatch.inc", "scan_asm_consts.inc"):
             assert f'#include "{name}"' in dispatch, f"{name} is generated but never dispatched"
             assert fresh.count("asm volatile(") == 1  # one statement: nothing in flight crosses compiler-managed code
     body = (tmp_path / "scan_asm_cosine_i8.inc").read_text()
     assert "v_mfma_i32_16x16x64_i8" in body and "v_mfma_f32_16x16x32_bf16" not in body
+
+
+def test_bench_hash_of_the_default_bodies_needs_no_built_tree():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen", ROOT / "tools" / "gen_scan_asm.py")
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    body = gen.default_i8_body("cosine")
+    assert body.count("asm volatile(") == 1 and "v_mfma_i32_16x16x64_i8" in body
+    if (CSRC / "scan_asm_cosine_i8_va.inc").exists():
+        assert (CSRC / "scan_asm_cosine_i8_va.inc").read_text() == body

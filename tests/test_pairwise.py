@@ -76,3 +76,109 @@ def test_simple_vector_dict_round_trip_and_protocol_shape():
     assert a == b and b.values is b.data and b.shape() == (2,) and b.dimension == 2
     assert a.distance(np.float32([1.0, 2.0]), "l2") == 0.0  # raw arrays are accepted too
     assert Vector([1.0, 2.0]).distance(a, "l2") == 0.0
+
+
+# ---- the same arithmetic behind the index: Index.distances (SURVEY 8a row a8' on the engine; HIP under -m gpu)
+def _index_with(rows, space, factory):
+    from mlvectordb_amd import Index
+
+    index = Index(space=space, **({} if factory is None else {"engine_factory": factory}))
+    vs = [Vector(r) for r in rows]
+    index.add(vs, "ns")
+    return index, vs
+
+
+def _check_index_distances(space, factory, dim=37):
+    from mlvectordb_amd import VectorDTO
+
+    rng = np.random.default_rng(11)
+    rows = rng.standard_normal((300, dim), dtype=np.float32)
+    rows[17] = rows[3]  # a duplicate row: equal distances
+    qs = rng.standard_normal((5, dim), dtype=np.float32)
+    index, vs = _index_with(rows, space, factory)
+    metric = space
+    try:
+        # (1) a hit's score IS Index.distances of that pair, exactly (the same fp64 summation, rounded once to fp32)
+        hits = index.search_many(qs, 8, "ns", metric)
+        ids = [[h.vector_id for h in hits[i]] for i in range(5)]
+        got = index.distances(qs, ids, "ns", metric)
+        assert got.shape == (5, 8)
+        assert np.array_equal(got, np.array([[h.score for h in hits[i]] for i in range(5)]))
+        # (2) == the oracle's matrix entry (fp32 rounding), == Vector.distance / similarity of the stored vectors
+        want = exact_scan.exact_distances(qs, rows, space)
+        pick = np.array([[0, 3, 17, 299], [5, 6, 7, 8], [100, 1, 2, 3], [42, 42, 42, 42], [299, 298, 297, 296]])
+        got = index.distances(qs, pick, "ns", metric)  # int64 labels are accepted too
+        for i in range(5):
+            for j in range(4):
+                d = np.float32(want[i, pick[i, j]])
+                score = 1.0 - np.float64(d) if metric == "cosine" else np.float64(d)
+                assert abs(got[i, j] - score) <= 1e-6 * max(1.0, abs(score))
+                pw = (Vector(qs[i]).similarity(vs[pick[i, j]], "cosine") if metric == "cosine"
+                      else Vector(qs[i]).distance(vs[pick[i, j]], metric))
+                assert abs(got[i, j] - pw) <= 1e-5
+        assert got[0, 1] == got[0, 2]  # the duplicated row
+        # (3) "euclidean" = sqrt of the l2 namespace's score; unknown / removed ids -> NaN
+        if space == "l2":
+            e = index.distances(qs[:1], [[vs[9].id]], "ns", "euclidean")
+            assert abs(e[0, 0] - Vector(qs[0]).distance(vs[9], "euclidean")) <= 1e-5
+        index.remove([vs[5].id], "ns")
+        import uuid
+
+        out = index.distances(qs[:1], [[vs[5].id, uuid.uuid4(), vs[6].id]], "ns", metric)
+        assert np.isnan(out[0, 0]) and np.isnan(out[0, 1]) and np.isfinite(out[0, 2])
+        with pytest.raises(RuntimeError):
+            index.distances(qs[:, :3], [[vs[0].id]] * 5, "ns", metric)
+        # the reference's hand case through the index (tests/test_query_processor.py:52-67 restated)
+        one = index.search(VectorDTO(values=qs[0], metadata={}), 1, "ns", metric)[0]
+        assert index.distances(qs[:1], [[one.vector_id]], "ns", metric)[0, 0] == one.score
+    finally:
+        index.close()
+
+
+@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+def test_index_distances_on_the_oracle_engine(space):
+    from oracle.engine import OracleScanEngine
+
+    _check_index_distances(space, OracleScanEngine)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+@pytest.mark.parametrize("dim", [37, 768])
+def test_index_distances_on_hip_equal_search_scores_pairwise_and_oracle(space, dim):
+    """Vector.distance / similarity == Index.distances (mlvdb_pair_distances: the rescoring kernel's
+    accumulate_rows) == the score Index.search returns == oracle.exact_distances (fp32 rounding)."""
+    _check_index_distances(space, None, dim)
+
+
+@pytest.mark.gpu
+def test_pair_distances_through_logical_shards_and_on_hand_case():
+    from mlvectordb_amd import Index
+
+    rng = np.random.default_rng(3)
+    rows = rng.standard_normal((500, 64), dtype=np.float32)
+    qs = rng.standard_normal((3, 64), dtype=np.float32)
+    one, many = Index(space="cosine"), Index(space="cosine", devices=[0, 0, 0])
+    try:
+        one.add_arrays(rows, "ns")
+        many.add_arrays(rows, "ns")
+        lab = rng.integers(0, 500, (3, 40))
+        lab[1, 5] = -1
+        a = one._ns["ns"].engine.pair_distances(qs, lab)
+        b = many._ns["ns"].engine.pair_distances(qs, lab)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.isinf(a[0][1, 5])
+        want = exact_scan.exact_distances(qs, rows, "cosine")
+        assert np.abs(a[0][lab >= 0] - np.take_along_axis(want, np.maximum(lab, 0), axis=1)[lab >= 0]).max() < 1e-12
+    finally:
+        one.close()
+        many.close()
+    hand = Index(space="cosine")
+    try:
+        vs = {k: Vector(v) for k, v in HAND.items()}
+        hand.add(list(vs.values()), "h")
+        got = hand.distances(np.float32([QUERY]), [[v.id for v in vs.values()]], "h", "cosine")[0]
+        for g, (k, v) in zip(got, vs.items()):
+            assert g == pytest.approx(ref_cosine_similarity(np.float32(QUERY), np.float32(HAND[k])), abs=1e-6)
+            assert g == pytest.approx(Vector(QUERY).similarity(v, "cosine"), abs=1e-6)
+    finally:
+        hand.close()

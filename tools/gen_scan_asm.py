@@ -1000,6 +1000,12 @@ def inc_name(space, nw, r, nt, qd, prio, mt, dma, stag=False):
             f"{'_pr' if prio else ''}{'_mt4' if mt == 4 else ''}{'_dma' if dma else ''}{'_stag' if stag else ''}.inc")
 
 
+def default_i8_body(space):
+    """The int8 body the library runs by default for `space` (ArchVGPR accumulators, wave priorities): scan_asm_<space>_i8_va.inc."""
+    DBG.clear()
+    return generate(space, 4, 4, 8, True, True, 2, True, False, True, True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
@@ -1015,7 +1021,7 @@ def main():
     for space, nw, r, nt, qd, prio, mt, dma, stag in I8_CONFIGS:
         (Path(args.outdir) / f"scan_asm_{space}_i8{'_pr' if prio else ''}.inc").write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag, True))
     for space in SPACES:   # the int8 bodies with ArchVGPR accumulators (wave priorities on): QD slot 211
-        (Path(args.outdir) / f"scan_asm_{space}_i8_va.inc").write_text(generate(space, 4, 4, 8, True, True, 2, True, False, True, True))
+        (Path(args.outdir) / f"scan_asm_{space}_i8_va.inc").write_text(default_i8_body(space))
     for code, knobs in DIAG.items():
         DBG.clear()
         DBG.update(knobs)
