@@ -447,6 +447,31 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
             fprintf(stderr, "[mlvdb] scan rows [%lld, %lld): %llu entries appended (%.1f per query), max per wave %llu\n",
                     (long long)b, (long long)e, (unsigned long long)sum, (double)sum / fa.nq, (unsigned long long)mx);
         }
+#ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1, MLVDB_SCAN_DIAG=234: where a scan launch's time goes (its waves stamp their phases)
+        if (fa.wgbuf && getenv("MLVDB_SCAN_DIAG") && atoi(getenv("MLVDB_SCAN_DIAG")) == 234) {
+            const int nwg = (int)std::min<int64_t>(256, (e - b + 255) / 256);
+            std::vector<unsigned long long> st((size_t)nwg * 8 * 8, 0ull);
+            HIP_TRY(h, hipMemcpyAsync(st.data(), fa.wgbuf + (size_t)256 * kWgCap, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipStreamSynchronize(s));
+            unsigned long long t0 = ~0ull, t5 = 0;
+            double ph[3] = {0, 0, 0};
+            const double tiles = (double)((e - b + 255) / 256);
+            int n = 0;
+            for (int w = 0; w < nwg * 8; ++w) {
+                const unsigned long long* p = &st[(size_t)w * 8];
+                if (!p[0] || !p[5]) continue;
+                ++n;
+                t0 = std::min(t0, p[0]);
+                t5 = std::max(t5, p[5]);
+                ph[0] += (double)(p[1] - p[0]) * 0.01;  // C++ preamble
+                ph[1] += (double)(p[4] - p[1]) * 0.01;  // the assembly: prologue + tiles
+                ph[2] += (double)(p[5] - p[4]) * 0.01;  // scatter tail
+            }
+            fprintf(stderr, "[mlvdb] scan rows [%lld, %lld): %d waves, first start -> last end %.1f us; mean per wave: preamble %.1f, "
+                    "assembly %.1f (%.1f tiles per workgroup), tail %.1f us\n", (long long)b, (long long)e, n,
+                    (double)(t5 - t0) * 0.01, ph[0] / n, ph[1] / n, tiles / nwg, ph[2] / n);
+        }
+#endif
         h->stats.scan_launches += 1;
         h->stats.rows_scanned += e - b;
         // int8 bounds are loose: thresholds from exact scores of the k best bounds; the same kernel prunes the lists

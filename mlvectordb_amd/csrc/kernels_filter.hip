@@ -597,16 +597,17 @@ static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagre
 // the bf16 body; 208..219 = int8 bodies (208 AccVGPR accumulators; 211 ArchVGPR accumulators, cosine: admission folded into the
 // last k-step; 214 / 215 / 216 tuning variants of 211: ring of 6, read-ahead 8, no wave priorities; 209 / 210 / 212 / 213
 // timing diagnostics).
-constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 230; }
+constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 240; }
 constexpr int scan_code_qd(int qd) { return qd == 215 ? 8 : (qd > 8 ? 4 : qd); }
-constexpr int scan_code_qbufs(int qd) { return qd == 219 || qd == 229 ? 4 : 2; }  // 219 / 229: four Q chunk buffers
+constexpr bool scan_code_q4(int qd) { return qd == 219 || qd == 229 || qd == 231 || qd == 233; }  // four Q chunk buffers
+constexpr int scan_code_qbufs(int qd) { return scan_code_q4(qd) ? 4 : 2; }
 constexpr int scan_code_stage_cap(int qd, int nw, int mt) {
-    return qd == 219 || qd == 229 ? kAsmStageCapNw8Q4 : (mt == 4 ? kAsmStageCapNw4Mt4 : (nw == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4));
+    return scan_code_q4(qd) ? kAsmStageCapNw8Q4 : (mt == 4 ? kAsmStageCapNw4Mt4 : (nw == 8 ? kAsmStageCapNw8 : kAsmStageCapNw4));
 }
 
 template <int SPACE, int R, int NW, bool NT, int QD, bool PRIO, int MT, bool DMA, bool STAG>
 __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kernel(const FilterArgs a, const int64_t tile_begin,
-                                                                                  const int64_t tile_end) {
+                                                                                  const int64_t tile_end, const int xcd_mode) {
     constexpr int kThreads = NW * 64;
     constexpr int kQPer = 1024 / kThreads;  // uint4 of a Q half-chunk moved per thread
     constexpr int kWaveRows = 16 * MT;  // MT = 2: two waves per SIMD; MT = 4: one, 64 rows each
@@ -620,6 +621,16 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     float* sq_l = thr_l + kFilterQueries;
     float* ke_l = sq_l + kFilterQueries;
     if (threadIdx.x < NW) a.wgcnt[blockIdx.x * NW + threadIdx.x] = 0;  // workgroups without tiles return below
+#ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1, MLVDB_SCAN_DIAG=234: phase stamps (100 MHz) per wave, in the unused upper half of wgbuf
+    // (the pointer is recomputed at every stamp: kept live across the assembly it costs the SGPRs the statement's "s"
+    // operands need -- they then come out as VGPRs and the assembler refuses them)
+    auto phase = [&]() __attribute__((always_inline)) {
+        return reinterpret_cast<unsigned long long*>(a.wgbuf + (size_t)256 * kWgCap) +
+               ((size_t)blockIdx.x * NW + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * 8;
+    };
+    constexpr bool stamping = QD == 234;  // wave-uniform: every lane stores the same word
+    if (stamping) phase()[0] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -650,7 +661,19 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
         ke_l[t] = kev;
     }
     const int64_t ntiles_all = tile_end - tile_begin;
-    const int64_t my_tiles = ntiles_all > blockIdx.x ? (ntiles_all - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    // Which tiles this workgroup scans: tile0 + i * tstride, i < my_tiles.  Default: the grid walks the range together
+    // (workgroup b takes tiles b, b + grid, ...).  xcd_mode (MLVDB_SCAN_XCD=1, tuning): workgroups b, b + 8, ... share an
+    // XCD under the observed round-robin placement (speed only, never correctness), so each XCD gets one contiguous
+    // eighth of the range and its workgroups walk that eighth together.
+    int64_t tile0 = tile_begin + blockIdx.x, my_tiles = ntiles_all > blockIdx.x ? (ntiles_all - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    uint32_t tstride = gridDim.x;
+    if (xcd_mode) {  // (the launcher only sets it for grids that are multiples of 8)
+        const int64_t per = (ntiles_all + 7) / 8, x = blockIdx.x & 7, slot = blockIdx.x >> 3, gs = gridDim.x >> 3;
+        const int64_t n_x = per * x < ntiles_all ? (per * (x + 1) <= ntiles_all ? per : ntiles_all - per * x) : 0;
+        tile0 = tile_begin + per * x + slot;
+        my_tiles = n_x > slot ? (n_x - slot + gs - 1) / gs : 0;
+        tstride = (uint32_t)gs;
+    }
     if (my_tiles == 0) return;
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(smem);
     // The assembly toggles the Q buffers with xor 0x8000, so the dynamic LDS must start at 0, i.e. the kernel may have no
@@ -665,17 +688,17 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     const uint32_t pb = (uint32_t)a.ld * (I8 ? 16u : 32u);  // bytes of one shadow panel (16 rows)
     const uint32_t wbytes = MT * pb;           // this wave's panels of a tile
     const uint64_t tile_bytes = (uint64_t)NW * wbytes;
-    const int64_t first_tile = tile_begin + blockIdx.x;
+    const int64_t first_tile = tile0;
     const uint64_t xbase = reinterpret_cast<uint64_t>(I8 ? a.X8 : a.Xb) + (uint64_t)first_tile * tile_bytes + (uint64_t)wave * wbytes;
-    const uint64_t xstride = (uint64_t)gridDim.x * tile_bytes;
+    const uint64_t xstride = (uint64_t)tstride * tile_bytes;
     const uint64_t rnbase = reinterpret_cast<uint64_t>(I8 ? a.rp8 + 2 * (first_tile * kTileRowsV + wave * kWaveRows)  // pairs per row
                                                           : a.rn + first_tile * kTileRowsV + wave * kWaveRows);
     const uint32_t xlo = (uint32_t)xbase, xhi = (uint32_t)(xbase >> 32) & 0xffffu;
     const uint32_t xslo = (uint32_t)xstride, xshi = (uint32_t)(xstride >> 32);
     const uint32_t rnlo = (uint32_t)rnbase, rnhi = (uint32_t)(rnbase >> 32) & 0xffffu;
-    const uint32_t rnstride = gridDim.x * (uint32_t)(kTileRowsV * (I8 ? 8 : 4));
+    const uint32_t rnstride = tstride * (uint32_t)(kTileRowsV * (I8 ? 8 : 4));
     const uint32_t row0 = (uint32_t)(first_tile * kTileRowsV);
-    const uint32_t rowstride = gridDim.x * (uint32_t)kTileRowsV;
+    const uint32_t rowstride = tstride * (uint32_t)kTileRowsV;
     const uint32_t ntiles = (uint32_t)my_tiles;
     const uint32_t qbytes = (uint32_t)nkc * chunk_bytes;
     const uint32_t nb = (uint32_t)(2 * nkc / R);
@@ -738,7 +761,13 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     (void)s_xso2;
     (void)s_xso3;
     (void)k1;
+#ifdef MLVDB_SCAN_DIAGNOSTICS
+    if (stamping) phase()[1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #include "scan_asm_dispatch.inc"
+#ifdef MLVDB_SCAN_DIAGNOSTICS
+    if (stamping) phase()[4] = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- the workgroup's own scatter: append buffers -> per-query candidate lists (what filter_scatter_kernel did in a
     // launch of its own).  Every wave staged its entries {u[], row[], q[]} in its LDS area (the first kStageCap of
     // them; later ones went to its slice of a.wgbuf, same slot numbering, stores drained); s_wcnt = how many it
@@ -800,6 +829,9 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
             }
         }
     }
+#ifdef MLVDB_SCAN_DIAGNOSTICS
+    if (stamping) phase()[5] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ------------------------------------------------------------------ threshold update + compaction
@@ -1940,7 +1972,8 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     if (lds_base_ok.load(std::memory_order_acquire) < 0) return hipErrorInvalidConfiguration;  // dynamic LDS would not start at 0
     if (hipError_t e = ensure_dynamic_lds(configured, reinterpret_cast<const void*>(kern), (int)lds); e != hipSuccess)
         return e;
-    kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end);
+    const int xcd_mode = grid % 8 == 0 && ntiles >= grid && env_int("MLVDB_SCAN_XCD", 0) ? 1 : 0;
+    kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end, xcd_mode);
     // (the kernel's own tail moves the entries into the candidate lists: there is no scatter launch)
     info->nw = NW;
     info->dbg = QD == 108 ? 1 : 0;
@@ -1978,6 +2011,7 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                 if (env_int("MLVDB_SCAN_DIAG", 0) == 213)
                     return launch_scan_asm<SPACE, 4, 8, true, 213, true, 2, true>(a, row_begin, row_end, s, info);
                 switch (env_int("MLVDB_SCAN_DIAG", 0)) {
+                    case 234: return launch_scan_asm<SPACE, 4, 8, true, 234, true, 2, true>(a, row_begin, row_end, s, info);
                     case 223: return launch_scan_asm<SPACE, 4, 8, true, 223, true, 2, true>(a, row_begin, row_end, s, info);
                     case 224: return launch_scan_asm<SPACE, 4, 8, true, 224, true, 2, true>(a, row_begin, row_end, s, info);
                     case 225: return launch_scan_asm<SPACE, 4, 8, true, 225, true, 2, true>(a, row_begin, row_end, s, info);
@@ -2004,6 +2038,11 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                     if (var == 220) return launch_scan_asm<SPACE, 4, 8, true, 220, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 221) return launch_scan_asm<SPACE, 4, 8, true, 221, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 230) return launch_scan_asm<SPACE, 4, 4, true, 230, false, 4, true>(a, row_begin, row_end, s, info);
+                    if (var == 231) return launch_scan_asm<SPACE, 4, 8, true, 231, true, 2, true>(a, row_begin, row_end, s, info);
+                    if (var == 232) return launch_scan_asm<SPACE, 4, 8, true, 232, true, 2, true>(a, row_begin, row_end, s, info);
+                    if (var == 233) return launch_scan_asm<SPACE, 4, 8, true, 233, true, 2, true>(a, row_begin, row_end, s, info);
+                    if (var == 235) return launch_scan_asm<SPACE, 4, 8, true, 235, true, 2, true>(a, row_begin, row_end, s, info);
+                    if (var == 236) return launch_scan_asm<SPACE, 4, 8, true, 236, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 217) return launch_scan_asm<SPACE, 4, 4, true, 217, false, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 218) return launch_scan_asm<SPACE, 4, 4, true, 218, true, 2, true>(a, row_begin, row_end, s, info);
                 }

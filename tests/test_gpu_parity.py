@@ -330,6 +330,11 @@ SCAN_VARIANTS = [
     {"MLVDB_I8": "0", "MLVDB_SCAN_ASM": "0"},        # the hipcc-scheduled kernel (also serves corpora without shadow)
     {"MLVDB_I8": "0", "MLVDB_SCAN_STAG": "1"},       # later half of the waves half a tile behind (rotated k origin)
     {"MLVDB_SCAN_VAR": "230"},                       # (cosine, int8) one wave per SIMD, 64 rows per wave, AccVGPR accumulators
+    {"MLVDB_SCAN_VAR": "231"},                       # (cosine, int8) four Q buffers, B-fragment reads across the chunk barrier
+    {"MLVDB_SCAN_VAR": "233"},                       # ... with the early-out hit stubs
+    {"MLVDB_SCAN_VAR": "235"},                       # (cosine, int8) straight-line append routine
+    {"MLVDB_SCAN_VAR": "236"},                       # ... with the early-out hit stubs
+    {"MLVDB_SCAN_XCD": "1"},                         # every XCD scans one contiguous eighth of the tile range
 ]
 
 NARROW_CASES = [

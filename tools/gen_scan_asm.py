@@ -56,6 +56,11 @@ BURST = 0      # generate(): ring refills issued in bursts of BURST consecutive 
 Q3D = False    # generate(): four Q buffers, chunk c+3 staged during chunk c, its landing awaited TWO chunks later (see generate)
 Q4 = False     # generate(): four Q chunk buffers in LDS, chunk c+2 staged during chunk c, ONE barrier per two chunks
 FUSE = False   # generate(): the admission test is folded into the tile's last k-step (cosine, VA; see gen_pretest)
+QA = False     # generate(): four Q buffers, chunk c+2 staged during chunk c, one barrier per chunk, and the B-fragment read
+#                stream runs ACROSS the chunk (and tile) boundary: the first QD fragments of chunk c+1 are read during the
+#                last QD fragments of chunk c, before the barrier (see generate)
+EO = False     # generate(): hit stubs leave at once when none of the 8 exact bounds passes (see gen_hit_stubs)
+FS = False     # generate(): append routine with a straight-line common case (see gen_slow_fast)
 DBG = set()   # timing diagnostics only (wrong results): 'nolds' drops the B-fragment reads, 'nox' the X refills
 
 
@@ -265,7 +270,10 @@ def gen_rowmax(s, part):
 def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=False, final=False, sync=True, ch=0):
     """One 64-column chunk = 2 k-steps = 32 fragments x MT MFMAs.  final: the tile's last chunk, whose second k-step
     carries the admission pre-tests (FUSE)."""
-    if Q4 or Q3D:   # buffers 0..3 in rotation: this chunk reads the next one, its DMAs fill the one after the next (Q3D: one further)
+    if QA:   # the read base moved on when the previous chunk started reading this one's fragments (below)
+        s.emit("s_add_u32 %[sldw], %[sldw], 0x8000")
+        s.emit("s_and_b32 %[sldw], %[sldw], 0x1ffff")
+    elif Q4 or Q3D:   # buffers 0..3 in rotation: this chunk reads the next one, its DMAs fill the one after the next (Q3D: one further)
         s.emit("v_add_u32 %[ldr], 0x8000, %[ldr]")
         s.emit("v_and_b32 %[ldr], 0x1ffff, %[ldr]")
         s.emit("s_add_u32 %[sldw], %[sldw], 0x8000")
@@ -346,8 +354,9 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
 
     if prio:
         s.emit("s_setprio 3")
-    for f0 in range(QD):
-        read(f0)
+    if not QA:   # (QA: fragments 0..QD-1 were read at the end of the previous chunk / by the prologue)
+        for f0 in range(QD):
+            read(f0)
     for f in range(32):
         h, n = f >> 4, f & 15
         b = (step0 + h) % R
@@ -384,6 +393,14 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
                     gen_pretest(s, n - 2, m)
         if f + QD < 32:
             read(f + QD)
+        elif QA:
+            # the next chunk's first fragments: its buffer was published by the PREVIOUS barrier (staged two chunks
+            # ahead), so the read stream never stops at a chunk boundary -- after the barrier the MFMAs go on at once
+            # instead of both waves of the SIMD waiting out an LDS round trip with the pipe idle
+            if f + QD == 32:
+                s.emit("v_add_u32 %[ldr], 0x8000, %[ldr]")
+                s.emit("v_and_b32 %[ldr], 0x1ffff, %[ldr]")
+            read(f + QD - 32)
         if f in plan:
             kind, setname, i, half = plan[f]
             reg = f"%[{setname}{i}]"
@@ -424,7 +441,8 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
         s.need_vm(*[(sn, i, (ch + 1) % nch) for sn in ("qb", "qa") for i in range(KQ)])
     elif dma:   # this wave's share of the chunk(s) staged since the last barrier has landed in LDS
         s.need_vm(*[(sn, i) for sn in ("qb", "qa") for i in range(KQ)])
-    s.drain_lg()
+    if not QA:   # (QA: the reads in flight are of the next chunk's buffer, which nobody writes for two more chunks)
+        s.drain_lg()
     if "stamp" in DBG:   # cycles parked at the barrier, summed in an SGPR (timing diagnostic)
         s.emit("s_memtime s[78:79]")
         s.emit("s_waitcnt lgkmcnt(0)")
@@ -612,6 +630,14 @@ def gen_hit_stubs(copy=""):
                 out.append(f"v_cvt_f32_i32 %[u{j}], {acc_reg(j >> 2, n, j & 3)}")
             for j in range(4 * MT):
                 out.append(f"v_fma_f32 %[u{j}], %[u{j}], %[r{j}], %[p{j}]")
+            if EO and MT == 2:
+                # Most calls are false alarms of the pre-test (it tests a row that dominates the lane's 8): one max tree
+                # and one compare send those straight back, instead of through the append routine's 8 compares and 8
+                # skipped row blocks (a taken branch each).  All 8 waves meet at the next barrier, so a tile is as slow
+                # as the wave with the most stub calls: the call's length is what counts.
+                out += ["v_max3_f32 %[e4], %[u0], %[u1], %[u2]", "v_max3_f32 %[e5], %[u3], %[u4], %[u5]",
+                        "v_max3_f32 %[e4], %[u6], %[u7], %[e4]", "v_max_f32 %[e4], %[e4], %[e5]",
+                        f"v_cmp_ge_f32 vcc, %[e4], %[tq{n}]", f"s_cbranch_vccz .Lback{n}{copy}_%="]
         elif FUSE:   # l2 / ip: the same, with the constants the pre-test holds in registers (gen_pretest_l2ip)
             thr, ke, sq = l2ip_consts(n)
             for j in range(4 * MT):
@@ -636,7 +662,7 @@ def gen_hit_stubs(copy=""):
 
 def lds_stage_cap(NW, mt=2, qbufs=None):
     """Entries of a wave's staging area in LDS (12 B each, SoA): what is left of the 160 KiB per CU."""
-    qbufs = qbufs or (4 if (Q4 or Q3D) else 2)
+    qbufs = qbufs or (4 if (Q4 or Q3D or QA) else 2)
     wgs_per_cu = (16 // mt) // NW      # mt = 2: two waves per SIMD, mt = 4: one
     per_wg = (160 * 1024) // wgs_per_cu - (qbufs * CHUNK_BYTES + 3072)   # Q buffers + thr[256], qscale[256], ke[256]
     return min(WG_CAP // NW, (per_wg // NW) // 12 // 8 * 8)
@@ -698,6 +724,68 @@ def gen_slow(NW):
     return o
 
 
+def gen_slow_fast(NW):
+    """gen_slow with the common case as a straight line (FS).  A call appends, typically, ONE entry: one row of one lane.
+    gen_slow walks 8 row blocks and skips the 7 empty ones with a taken branch each, and inside the one block that has a hit
+    it takes another (no entry beyond the LDS staging area); all 8 waves of the workgroup meet at the next chunk barrier, so
+    a tile is as slow as the wave with the most calls (phase stamps, profiles/r03: 11.2 us per tile in the second scan round,
+    8 calls per wave and tile, against 9.3 us in the third with 1.3).  Here an empty row costs two scalar instructions and a
+    branch that is NOT taken; the row blocks sit out of line, their own rare part (slots beyond the staging area) too."""
+    capw = WG_CAP // NW
+    lcw = lds_stage_cap(NW, MT)
+    NR = 4 * MT
+    assert NR == 8
+    o = [".Lslow_%=:",
+         "v_add_u32 %[e9], %[sn64], %[c16v]",                       # e9 = query
+         "v_add_u32 %[e11], %[trow], %[crow]"]                      # e11 = this lane's first row
+    for j in range(NR):
+        o.append(f"v_cmp_ge_f32_e64 s[{60 + 2 * j}:{61 + 2 * j}], %[u{j}], %[e6]")
+    for j in range(NR):
+        lo, hi = 60 + 2 * j, 61 + 2 * j
+        o += [f"s_cmp_lg_u64 s[{lo}:{hi}], 0",
+              f"s_cbranch_scc1 .Lrow{j}_%=",
+              f".Lrowret{j}_%=:"]
+    o.append(f"s_setpc_b64 {RET}")
+    for j in range(NR):
+        lo, hi = 60 + 2 * j, 61 + 2 * j
+        o += [f".Lrow{j}_%=:",
+              f"s_bcnt1_i32_b64 %[st0], s[{lo}:{hi}]",
+              f"s_mov_b64 exec, s[{lo}:{hi}]",
+              f"v_mbcnt_lo_u32_b32 %[e8], s{lo}, 0",
+              f"v_mbcnt_hi_u32_b32 %[e8], s{hi}, %[e8]",
+              "v_add_u32 %[e8], %[wcnt], %[e8]",                    # e8 = this entry's slot
+              f"v_add_u32 %[e5], {16 * (j >> 2) + (j & 3)}, %[e11]",  # e5 = row
+              f"v_cmp_gt_u32 vcc, 0x{lcw:x}, %[e8]",
+              "s_and_b64 exec, exec, vcc",                          # slots inside the LDS staging area
+              "v_lshl_add_u32 %[e7], %[e8], 2, %[stg]",
+              f"ds_write_b32 %[e7], %[u{j}]",
+              f"ds_write_b32 %[e7], %[e5] offset:{lcw * 4}",
+              f"ds_write_b32 %[e7], %[e9] offset:{lcw * 8}",
+              f"s_andn2_b64 exec, s[{lo}:{hi}], vcc",               # the rest: none, unless the staging area is full
+              f"s_cbranch_execnz .Lovf{j}_%=",
+              f".Lovfret{j}_%=:",
+              "s_add_u32 %[wcnt], %[wcnt], %[st0]",
+              "s_mov_b64 exec, -1",
+              f"s_branch .Lrowret{j}_%="]
+    for j in range(NR):
+        o += [f".Lovf{j}_%=:",
+              f"v_cmp_gt_u32 vcc, 0x{capw:x}, %[e8]",
+              "s_mov_b64 s[76:77], exec",
+              "s_and_b64 exec, exec, vcc",                          # slots inside the global buffer
+              "v_lshlrev_b32 %[e7], 2, %[e8]",
+              f"global_store_dword %[e7], %[u{j}], %[wgbu]",
+              "global_store_dword %[e7], %[e5], %[wgbr]",
+              "global_store_dword %[e7], %[e9], %[wgbq]",
+              "s_andn2_b64 exec, s[76:77], vcc",                    # slots past the buffer
+              "v_lshlrev_b32 %[e7], 2, %[e9]",
+              "v_mov_b32 %[e5], 1",
+              "global_store_dword %[e7], %[e5], %[ovfb]",           # overflow[q] = 1: the query is re-run exactly
+              "s_mov_b64 exec, -1",
+              "s_waitcnt vmcnt(0)",   # stores may complete before older loads: no counted vmcnt wait may see them
+              f"s_branch .Lovfret{j}_%="]
+    return o
+
+
 def gen_flush(NW):
     """Kernel end.  The entries a wave staged in LDS are moved into the per-query candidate lists by the C++ tail of
     filter_scan_asm_kernel (the workgroup's own scatter: LDS histogram, one device atomic per query it has entries
@@ -706,7 +794,8 @@ def gen_flush(NW):
     return ["s_waitcnt vmcnt(0) lgkmcnt(0)"]   # ring / Q sets still in flight that nobody consumes; staged entries landed
 
 
-def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False, q4=False, place=None, burst=0, q3d=False):
+def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False, q4=False, place=None, burst=0, q3d=False,
+             qa=False, eo=False, fs=False):
     """stag: both waves of a SIMD reach the admission test (VALU only) together and leave the MFMA pipe idle for it.
     With the stagger the later-dispatched half of a workgroup's waves (wtype 1) runs half a tile behind: it sits out
     the first nkc/2 chunk periods (staging only), starts every row tile at column ld/2 (k origin rotated by xrot,
@@ -743,6 +832,15 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     global Q3D
     Q3D = q3d
     assert not q3d or (dma and R == 6 and not stag and not q4)
+    # qa: see the QA flag.  Why: with two Q buffers a chunk's first B fragments can only be read after the barrier that
+    # publishes it, so after every barrier both waves of a SIMD wait for an LDS round trip (~200 cycles with all eight waves
+    # asking at once) before their first MFMA -- ~7 % of a chunk period with the matrix pipe idle.  Staged two chunks ahead,
+    # the chunk read next is already public one barrier earlier.
+    global QA, EO, FS
+    QA = qa
+    EO = eo
+    FS = fs
+    assert not qa or (dma and R == 4 and not stag and not q4 and not q3d and va)
     global BURST
     BURST = burst
     assert not burst or (R % burst == 0 and not stag)
@@ -776,7 +874,10 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
         a("s_memtime s[78:79]")
         a("s_waitcnt lgkmcnt(0)")
         a("s_mov_b32 %[sacc1], s78")
-    a("v_add_u32 %[ldr], 0x18000, %[lane16]" if (q4 or q3d) else "v_add_u32 %[ldr], 0x8000, %[lane16]")   # the first chunk moves it to buffer 0
+    if qa:
+        a("v_mov_b32 %[ldr], %[lane16]")   # buffer 0: the prologue below reads its first fragments itself
+    else:
+        a("v_add_u32 %[ldr], 0x18000, %[lane16]" if (q4 or q3d) else "v_add_u32 %[ldr], 0x8000, %[lane16]")   # the first chunk moves it to buffer 0
     if not dma:
         a("v_mov_b32 %[ldw], %[qvoff]")        # ... and this one to buffer 1
     # ---- prologue: Q chunk 0 -> LDS buffer 0, chunk 1 -> the sets (register staging only), k-steps 0..R-1 -> the ring
@@ -787,7 +888,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
             a(f"s_add_u32 m0, %[sldw], 0x{const:x}")
             a(f"s_movk_i32 %[st0], 0x{const:x}")
             a("buffer_load_dwordx4 %[qvoff], %[qsrd], %[st0] offen lds")
-        if q4 or q3d:   # chunk 1 -> buffer 1 as well; the first chunk then moves the write base to buffer 2
+        if q4 or q3d or qa:   # chunk 1 -> buffer 1 as well; the first chunk then moves the write base to buffer 2
             a("s_add_u32 %[sldw], %[sldw], 0x8000")
             for const, setname, i in pieces:
                 a(f"s_add_u32 m0, %[sldw], 0x{const:x}")
@@ -834,6 +935,9 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
         for n in range(16):
             a(f"ds_read_b32 %[tq{n}], %[thra]" + (f" offset:{n * 64}" if n else ""))
         a("s_waitcnt lgkmcnt(0)")
+    if qa:   # the first tile's first fragments (every later chunk's are read at the end of the chunk before it)
+        for f0 in range(QD):
+            a(f"ds_read_b128 %[t{f0}], %[ldr] offset:{f0 * 2048}")
     if stag:
         a("s_mov_b32 %[qcur], %[qc1]")   # the Q cursor follows the shared chunk stream from here on, never reset
         a("s_cmp_eq_u32 %[wtype], 1")
@@ -855,7 +959,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     a("s_add_u32 s84, s80, %[st0]")
     a("s_addc_u32 s85, s81, %[cnt]")
     if not stag and not q3d:   # (q3d: the cursor simply keeps running: a tile is a whole number of image periods)
-        a("s_mov_b32 %[qcur], %[qc1]" if dma and not q4 else "s_mov_b32 %[qcur], %[qcur0]")   # first chunk staged inside this tile's loop
+        a("s_mov_b32 %[qcur], %[qc1]" if dma and not (q4 or qa) else "s_mov_b32 %[qcur], %[qcur0]")   # first chunk staged inside this tile's loop
     a(f"s_add_u32 %[xso0], %[xrot], 0x{R * 1024:x}" if stag else f"s_movk_i32 %[xso0], 0x{R * 1024:x}")
     a("s_add_u32 %[xso1], %[pb], %[xso0]")
     for m in range(2, MT):
@@ -916,7 +1020,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
         out += gen_hit_stubs("c200") + gen_hit_stubs("c300")
     else:
         out += gen_hit_stubs()
-    out += gen_slow(NW)
+    out += gen_slow_fast(NW) if (FS and MT == 2) else gen_slow(NW)
     a(".Ldone_%=:")
 
     ops_out, ops_in = [], []
@@ -1011,7 +1115,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_diag223.inc", "scan_asm_diag224.inc", "scan_asm_diag225.inc", "scan_asm_diag226.inc", "scan_asm_diag227.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc", "scan_asm_cosine_i8_va_r6b3.inc", "scan_asm_cosine_i8_va_q3d.inc", "scan_asm_cosine_i8_mt4.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_diag223.inc", "scan_asm_diag224.inc", "scan_asm_diag225.inc", "scan_asm_diag226.inc", "scan_asm_diag227.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc", "scan_asm_cosine_i8_va_r6b3.inc", "scan_asm_cosine_i8_va_q3d.inc", "scan_asm_cosine_i8_mt4.inc", "scan_asm_cosine_i8_va_qa.inc", "scan_asm_cosine_i8_va_eo.inc", "scan_asm_cosine_i8_va_qa_eo.inc", "scan_asm_cosine_i8_va_fs.inc", "scan_asm_cosine_i8_va_eo_fs.inc", "scan_asm_diag234.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -1063,6 +1167,17 @@ def main():
         DBG.update(knobs)
         (Path(args.outdir) / f"scan_asm_diag{code}.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
         DBG.clear()
+    # round 3: B-fragment reads across the chunk barrier (231), early-out hit stubs (232), both (233)
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_qa.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, qa=True))
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_eo.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, eo=True))
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_qa_eo.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, qa=True, eo=True))
+    # straight-line append routine (235), with the early-out stubs (236)
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_fs.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, fs=True))
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_eo_fs.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True))
+    # 234: the default body; the C++ wrapper stamps its phases around it (correct results; DIAG builds only).  Stamps INSIDE
+    # the statement were tried: two more live SGPR outputs do not fit (the "s" inputs then come out as VGPRs and the
+    # assembler refuses them), two more VGPR outputs make hipcc's register allocator hang (> 40 minutes, killed)
+    (Path(args.outdir) / "scan_asm_diag234.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
     DBG.update({"noadm"})   # 213: ArchVGPR accumulators, no admission test at all
     (Path(args.outdir) / "scan_asm_diag213.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
     DBG.clear()
@@ -1103,6 +1218,9 @@ def main():
     disp.append('#include "scan_asm_cosine_i8_mt4.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 219 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_cosine_i8_va_q4.inc"')
+    for code, nm in ((231, "qa"), (232, "eo"), (233, "qa_eo"), (235, "fs"), (236, "eo_fs")):
+        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
+        disp.append(f'#include "scan_asm_cosine_i8_va_{nm}.inc"')
     disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
     for code in DIAG:
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2 && DMA == false && STAG == false) {{")
@@ -1111,7 +1229,7 @@ def main():
     disp.append('#include "scan_asm_diag209.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 210 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_diag210.inc"')
-    for code in (212, 213, 223, 224, 225, 226, 227):
+    for code in (212, 213, 223, 224, 225, 226, 227, 234):
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
         disp.append(f'#include "scan_asm_diag{code}.inc"')
     disp.append("#endif")
