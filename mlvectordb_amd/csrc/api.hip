@@ -71,6 +71,7 @@ struct mlvdb_index {
     DevBuf x8, rp8, rowerr8, qimg8, sq8;
     int64_t i8_rows = 0;      // rows [0, i8_rows) of the int8 shadow are current (0 after compact / reset / regrowth)
     float i8_err = 0.f;       // host copy of rowerr8 (read back whenever rows were converted)
+    bool sqmin_fresh = false;  // fmisc was just (re)allocated: FilterArgs::sqmin[] not initialised yet
     bool mask_active = false;  // h->rn is a masked copy (mlvdb_search_batch_filtered)
     bool mask_pairs_ready = false;  // ... and rp8_masked holds the masked copy of the int8 shadow's row pairs
     DevBuf rp8_masked;
@@ -264,7 +265,11 @@ struct FilterWs {
 
 int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const double* qaux, const float* qerr, int32_t nq) {
     HIP_TRY(h, h->qimg.ensure(filter_qimg_bytes(h->ld)));
-    HIP_TRY(h, h->fmisc.ensure(8 * kFilterQueries * sizeof(uint32_t)));
+    {
+        const void* before = h->fmisc.p;
+        HIP_TRY(h, h->fmisc.ensure(8 * kFilterQueries * sizeof(uint32_t)));
+        if (h->fmisc.p != before) h->sqmin_fresh = true;  // the two scalars the fused prep's atomics start from: see run_filter_pass
+    }
     HIP_TRY(h, h->cand.ensure((size_t)kFilterQueries * kCandCap * sizeof(CandEntry)));
     HIP_TRY(h, h->rescr.ensure((size_t)kFilterQueries * kCandCap * sizeof(RangeHit)));  // exact scores of the rescored candidates
     if (h->Xb || h->i8_only) {  // the assembly scan appends through workgroup-private buffers
@@ -380,7 +385,12 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
 }
 
 // One pass of <= 256 queries through the filter path; outputs at query index q0.. of the batch.
-int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qaux, int32_t q0, int32_t nq,
+int finish_filter_pass(mlvdb_index* h, hipStream_t s, FilterArgs& fa, int32_t q0, int32_t nq, int32_t k, int64_t* out_labels,
+                       float* out_dist, int32_t* out_counts, double* out_d64, bool defer_fallback);
+
+// `queries_raw`: the pass's queries [nq][dim] as the caller gave them (device); this pass prepares them itself (padded copy,
+// norms, images: one fused launch) into Qpad / qaux / qerr at q0.
+int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, float* Qpad, double* qaux, int32_t q0, int32_t nq,
                     int32_t k, int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_d64,
                     bool defer_fallback = false) {
     FilterArgs fa{};
@@ -388,9 +398,47 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
     if (rc) return rc;
     rc = attach_i8(h, s, fa);
     if (rc) return rc;
-    HIP_TRY(h, launch_filter_prep(fa, s));
-    if (fa.X8) HIP_TRY(h, launch_filter_prep8(fa, s));  // int8 query image; ke becomes the int8 error term
+    if (h->sqmin_fresh) {  // what the fused prep's atomicMin / atomicMax start from; afterwards every fin kernel restores it
+        HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fa.sqmin), 0x7f7f7f7f, 1, s));
+        HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fa.sqmin + 1), 0, 1, s));
+        h->sqmin_fresh = false;
+    }
+    HIP_TRY(h, launch_filter_prep_fused(fa, queries_raw + (size_t)q0 * h->dim, h->dim, Qpad + (size_t)q0 * h->ld, qaux + q0,
+                                        h->qerr.as<float>() + q0, s));
     h->stats.bound_dtype = fa.X8 ? 2 : 1;
+    // ---- tried in round 3 for small batches on small corpora (BASELINE configs[1]: 1M x 768, batch 1), OFF by default
+    // (MLVDB_SMALL_BATCH=1): exact k-th best of a prefix of the fp32 rows (fp64 scan) -> ONE int8 scan of everything ->
+    // rescoring, instead of the rounds below.  Measured SLOWER (profiles/r03/small_batch_single_round_tried_1m.txt: 0.273 vs
+    // 0.248 ms at batch 1, 0.37-0.48 vs 0.27 ms at 4-8 queries): one scan launch takes exactly what the two rounds take
+    // together (138 us for 768 MB), the exact scan of a 12k-row prefix is a latency chain on 24 workgroups (57 us), and the
+    // ~3,500 candidates per query it leaves cost the ranking kernel 31 us -- more than the three 15 us refines it saves.
+    {
+        const char* sb = getenv("MLVDB_SMALL_BATCH");
+        const bool small = fa.X8 && nq <= 8 && !h->mask_active && h->total <= (int64_t)2500000 && filter_narrow_ok(fa) &&
+                           (sb && sb[0] == '1');
+        if (small) {
+            int64_t units = 16;  // x 768 rows
+            if (const char* v = getenv("MLVDB_SMALL_SEED")) units = std::max<int64_t>(1, atoll(v));
+            const int64_t n_exact = std::min<int64_t>(h->total, units * kFilterTile);
+            HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * k * sizeof(int64_t)));
+            HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * k * sizeof(float)));
+            HIP_TRY(h, h->seed_cnt.ensure(kFilterQueries * sizeof(int32_t)));
+            HIP_TRY(h, h->seed_d64.ensure((size_t)kFilterQueries * k * sizeof(double)));
+            rc = run_exact(h, s, fa.Qpad, fa.qaux, nq, nullptr, 0, n_exact, k, h->seed_lab.as<int64_t>(), h->seed_dist.as<float>(),
+                           h->seed_cnt.as<int32_t>(), h->seed_d64.as<double>(), false);
+            if (rc) return rc;
+            HIP_TRY(h, launch_filter_seed_thr(fa, h->seed_d64.as<double>(), k, s));
+            rc = scan_event(h, s, true);
+            if (rc) return rc;
+            ScanInfo info;
+            HIP_TRY(h, launch_filter_scan(fa, 0, h->total, s, &info));  // every row, the prefix included: the lists must hold it too
+            rc = scan_event(h, s, false);
+            if (rc) return rc;
+            h->stats.scan_launches += 1;
+            h->stats.rows_scanned += h->total;
+            return finish_filter_pass(h, s, fa, q0, nq, k, out_labels, out_dist, out_counts, out_d64, defer_fallback);
+        }
+    }
     // seed: a dense pass of the filter kernel over the first rows puts every bound into the lists,
     // the update kernel turns them into thresholds; the remaining rows follow in rounds of growing
     // size so that thresholds tighten early
@@ -497,6 +545,13 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* Qpad, const doub
 #endif
         if (!fuse) HIP_TRY(h, launch_filter_update(fa, k, s));
     }
+    return finish_filter_pass(h, s, fa, q0, nq, k, out_labels, out_dist, out_counts, out_d64, defer_fallback);
+}
+
+// The end of a kNN pass: exact fp64 rescoring of the candidate lists, then the exact fallback for overflowed queries.
+int finish_filter_pass(mlvdb_index* h, hipStream_t s, FilterArgs& fa, int32_t q0, int32_t nq, int32_t k, int64_t* out_labels,
+                       float* out_dist, int32_t* out_counts, double* out_d64, bool defer_fallback) {
+    int rc = MLVDB_OK;
     // counters: [0] rescored pairs, [1] fallback queries (accumulated over the passes of a call), [2] flag count
     unsigned long long* stats = h->counters.as<unsigned long long>();
 #ifdef MLVDB_SCAN_DIAGNOSTICS
@@ -1045,19 +1100,21 @@ static int search_device_impl(mlvdb_index* h, const float* queries_device, int64
     if (!h->counters_pending) HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 32, s));
     h->counters_stream = s;
     HIP_TRY(h, h->qerr.ensure((size_t)nq * sizeof(float)));
-    HIP_TRY(h, launch_query_prep(queries_device, (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
-                                 h->qaux.as<double>(), h->qerr.as<float>(), s));
+    const bool filt = k <= MLVDB_MAX_TOPK && use_filter(h, nq);
+    if (!filt)  // (the filter passes prepare their own queries: one fused launch each)
+        HIP_TRY(h, launch_query_prep(queries_device, (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
+                                     h->qaux.as<double>(), h->qerr.as<float>(), s));
     if (k > MLVDB_MAX_TOPK) {
         h->stats.strategy_used = MLVDB_STRATEGY_EXACT;
         rc = run_paged_exact(h, s, h->qpad.as<float>(), h->qaux.as<double>(), nq, nullptr, (int32_t)nq, k, out_labels_device,
                              out_dist_device, out_counts_device, out_dist64_device);
         if (rc) return rc;
-    } else if (use_filter(h, nq)) {
+    } else if (filt) {
         h->stats.strategy_used = MLVDB_STRATEGY_FILTER;
         h->counters_pending = true;
         for (int64_t q0 = 0; q0 < nq; q0 += kFilterQueries) {
             const int32_t n = (int32_t)std::min<int64_t>(kFilterQueries, nq - q0);
-            rc = run_filter_pass(h, s, h->qpad.as<float>(), h->qaux.as<double>(), (int32_t)q0, n, k, out_labels_device,
+            rc = run_filter_pass(h, s, queries_device, h->qpad.as<float>(), h->qaux.as<double>(), (int32_t)q0, n, k, out_labels_device,
                                  out_dist_device, out_counts_device, out_dist64_device,
                                  defer_fallback && nq <= kFilterQueries);
             if (rc) return rc;

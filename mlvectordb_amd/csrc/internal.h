@@ -171,6 +171,11 @@ struct FilterArgs {
     uint32_t* wgcnt;        // [kScanMaxGrid * 8] entries appended per wave (may exceed the slice: the excess was flagged as overflow)
 };
 hipError_t launch_filter_prep(const FilterArgs& a, hipStream_t s);
+// query_prep + filter_prep + filter_prep8 (when a.X8) of one pass in one launch (+ the one-block fin): `queries` = the pass's raw
+// [a.nq][dim] rows on the device; writes Qpad / qaux / qerr (= a.Qpad / a.qaux / a.qerr) and everything launch_filter_prep(8) does.
+// a.sqmin[] must hold {0x7f7f7f7f, 0} on entry (set when the workspace is allocated, restored by every fin kernel).
+hipError_t launch_filter_prep_fused(const FilterArgs& a, const float* queries, int32_t dim, float* Qpad, double* qaux, float* qerr,
+                                    hipStream_t s);
 // seed thresholds from exact kNN distances of a prefix of the corpus: seed_d64[q][k]
 hipError_t launch_filter_seed_thr(const FilterArgs& a, const double* seed_d64, int32_t k, hipStream_t s);
 // What a scan launch reports back (tuning aids).  The assembly scan stages its hits per wave in LDS and its own tail
@@ -186,6 +191,7 @@ hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float*
                                int64_t row_end, int32_t ld, int32_t space, hipStream_t s);
 hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s);
 bool filter_refine_can_fuse(const FilterArgs& a);
+bool filter_narrow_ok(const FilterArgs& a);  // the pass's scans run on the narrow kernel (<= 64 queries, image resident in LDS)
 hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, bool fuse, hipStream_t s);
 hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info);
 // dense seeding pass over rows [0,row_end), row_end <= kSeedRows: all bounds -> candidate lists -> thresholds (update)

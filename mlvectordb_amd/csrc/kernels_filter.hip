@@ -1519,10 +1519,17 @@ __global__ __launch_bounds__(256) void filter_prep8_kernel(const FilterArgs a) {
 //   keb     the bf16 term (filter_prep_kernel's ke): what the bf16 seeding pass adds to its bounds
 //   ke      covers both kinds of entry (the update kernel's lower bounds u - 2 eps): the larger of the two, with the
 //           int8 row term at its index-wide maximum
-__global__ __launch_bounds__(256) void filter_prep8_fin_kernel(const FilterArgs a) {
+__global__ __launch_bounds__(256) void filter_prep8_fin_kernel(const FilterArgs a, const int reset) {
     const int q = threadIdx.x;
     const float sqmin = __uint_as_float(a.sqmin[0]);
     const double eqmax = (double)__uint_as_float(a.sqmin[1]);
+    if (reset) {  // fused prep: nobody re-initialises the two scalars before the next pass's atomics -- this kernel does, once
+        __syncthreads();  // every thread of this (only) block has read them
+        if (q == 0) {
+            a.sqmin[0] = 0x7f7f7f7fu;
+            a.sqmin[1] = 0u;
+        }
+    }
     const double eq8 = (double)a.ke8[q];
     const double ratio = a.space == kSpaceCosine && q < a.nq ? (double)a.sq8[q] / (double)sqmin * 1.000001 : 1.0;
     const double rnd = 4.0 * 5.9604644775390625e-08;  // float(I) * rp8 (+ b K) * sq8: roundings of a value <= ~1
@@ -1536,10 +1543,135 @@ __global__ __launch_bounds__(256) void filter_prep8_fin_kernel(const FilterArgs 
     if (q == 0) a.ke8[kFilterQueries] = float_above((1.0 + eqmax) / (double)sqmin * 1.000001);
 }
 
+// ------------------------------------------------------------------ one launch for everything a pass needs of its queries
+// query_prep_kernel (padded copy, norm, bf16 rounding error) + filter_prep_kernel (bf16 image, per-query state) +
+// filter_prep8_kernel (int8 image, scale, error) as ONE kernel, block q = query q of the pass: three launches and their
+// two kernel boundaries less per pass (round 3; ~14 us of a 256-query wave, ~20 us of a batch-1 call).  Same arithmetic,
+// value for value, as the three kernels it replaces (they still serve the range path and the exact scans).
+__global__ __launch_bounds__(256) void filter_prep_fused_kernel(const FilterArgs a, const float* __restrict__ queries, const int32_t dim,
+                                                                float* __restrict__ Qpad, double* __restrict__ qaux,
+                                                                float* __restrict__ qerr, const int want_i8) {
+    __shared__ double dred[4];
+    __shared__ float fred[4];
+    __shared__ double s_inv;
+    const int q = blockIdx.x;
+    const bool real = q < a.nq;
+    const int ld = a.ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* dst = Qpad + (int64_t)q * ld;
+    // 1. zero-padded copy and norm (query_prep_kernel)
+    double s = 0.0;
+    if (real) {
+        const float* src = queries + (int64_t)q * dim;
+        for (int c = threadIdx.x; c < ld; c += 256) {
+            const float v = c < dim ? src[c] : 0.f;
+            dst[c] = v;
+            s = __builtin_fma((double)v, (double)v, s);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) dred[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double nrm = __builtin_sqrt((dred[0] + dred[1]) + (dred[2] + dred[3]));
+        const double aux = a.space == kSpaceCosine ? 1.0 / (nrm + 1e-30) : nrm;
+        if (real) qaux[q] = aux;
+        s_inv = a.space == kSpaceCosine ? aux : 1.0 / (aux + 1e-30);
+    }
+    __syncthreads();
+    const double inv = s_inv;
+    const float invf = (float)inv;
+    // 2. bf16 image in B-fragment order (filter_prep_kernel) and its measured rounding error (query_prep_kernel)
+    __bf16* img = reinterpret_cast<__bf16*>(a.qimg);
+    const int n16 = q >> 4, c16 = q & 15;
+    double e2 = 0.0;
+    float amax = 0.f;
+    for (int c = threadIdx.x; c < ld; c += 256) {
+        const float x = real ? dst[c] : 0.f;  // (this thread wrote dst[c] itself)
+        const float v = x * invf;
+        const __bf16 b = (__bf16)v;
+        int kc = c >> 6, ks, g, j;
+        if (a.Xb) {  // shadow k order: 8 consecutive columns per lane group
+            ks = (c >> 5) & 1; g = (c >> 3) & 3; j = c & 7;
+        } else {     // fp32 panels: columns {4g..4g+3} of two 16-column groups
+            const int t = (c >> 4) & 3;
+            ks = t >> 1; g = (c >> 2) & 3; j = (t & 1) * 4 + (c & 3);
+        }
+        img[((((int64_t)kc * 16 + n16) * 2 + ks) * 64 + (c16 + 16 * g)) * 8 + j] = b;
+        if (c < dim) {
+            const double e = (double)x * inv - (double)(float)(__bf16)(x * invf);
+            e2 = __builtin_fma(e, e, e2);
+        }
+        amax = __builtin_fmaxf(amax, __builtin_fabsf(v));
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        e2 += __shfl_xor(e2, off);
+        amax = __builtin_fmaxf(amax, __shfl_xor(amax, off));
+    }
+    __syncthreads();  // (dred is reused)
+    if (lane == 0) {
+        dred[wave] = e2;
+        fred[wave] = amax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float e = (float)(__builtin_sqrt((dred[0] + dred[1]) + (dred[2] + dred[3])) * 1.000001);
+        e = __uint_as_float(__float_as_uint(e) + 1u);  // never below the true error
+        if (real) qerr[q] = e;
+        // per-query state of the pass (filter_prep_kernel, block 0)
+        const double nrm = real ? (a.space == kSpaceCosine ? 0.0 : qaux[q]) : 0.0;
+        a.qscale[q] = a.space == kSpaceL2 ? (float)(2.0 * nrm) : 1.0f;
+        const double e1q = (real ? (double)e : 0.0) + 1.00390625 * (double)*a.row_err + (double)ld * 2.384185791015625e-07;
+        const float ke = (float)(e1q * 1.000001) + (a.space == kSpaceCosine ? 2.0f : 1.0f) * kSlack;
+        a.ke[q] = __uint_as_float(__float_as_uint(ke) + 1u);
+        a.thr[q] = real ? -3.0e38f : 3.4e38f;  // padded queries never admit anything
+        a.cnt[q] = 0;
+        a.overflow[q] = 0;
+    }
+    if (!want_i8) return;
+    // 3. int8 image, scale and error (filter_prep8_kernel); a.sqmin[] was left initialised by the previous pass's fin kernel
+    amax = __builtin_fmaxf(__builtin_fmaxf(fred[0], fred[1]), __builtin_fmaxf(fred[2], fred[3]));
+    const float sq = amax > 0.f ? amax / 127.0f : 1.0f;
+    const float isq = 1.0f / sq;
+    int8_t* img8 = reinterpret_cast<int8_t*>(a.qimg8);
+    double err2 = 0.0;
+    for (int c = threadIdx.x; c < ld; c += 256) {
+        const float v = real ? dst[c] * invf : 0.f;
+        float t = __builtin_rintf(v * isq);
+        t = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, t));
+        const double e = (double)v - (double)sq * (double)t;
+        err2 += e * e;
+        const int kc = c >> 7, ks = (c >> 6) & 1, g = (c >> 4) & 3, j = c & 15;
+        img8[((((int64_t)kc * 16 + n16) * 2 + ks) * 64 + (c16 + 16 * g)) * 16 + j] = (int8_t)t;
+    }
+    for (int off = 32; off > 0; off >>= 1) err2 += __shfl_xor(err2, off);
+    __syncthreads();
+    if (lane == 0) dred[wave] = err2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double eq8 = __builtin_sqrt(dred[0] + dred[1] + dred[2] + dred[3]) * 1.000001 + 1e-12;
+        a.sq8[q] = sq;
+        a.ke8[q] = real ? float_above(eq8) : 0.f;  // finished by filter_prep8_fin_kernel
+        if (real) {
+            atomicMin(a.sqmin, __float_as_uint(sq));
+            atomicMax(a.sqmin + 1, __float_as_uint(float_above(eq8)));
+        }
+    }
+}
+
+hipError_t launch_filter_prep_fused(const FilterArgs& a, const float* queries, int32_t dim, float* Qpad, double* qaux, float* qerr,
+                                    hipStream_t s) {
+    if (a.ld / kFilterChunkK <= 0) return hipErrorInvalidValue;
+    const int want_i8 = a.X8 != nullptr;
+    filter_prep_fused_kernel<<<kFilterQueries, 256, 0, s>>>(a, queries, dim, Qpad, qaux, qerr, want_i8);
+    if (want_i8) filter_prep8_fin_kernel<<<1, kFilterQueries, 0, s>>>(a, 1);
+    return hipGetLastError();
+}
+
 hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s) {
     // a.sqmin[0..1] were initialised by filter_prep_kernel (always launched first: launch_filter_prep)
     filter_prep8_kernel<<<kFilterQueries, 256, 0, s>>>(a);
-    filter_prep8_fin_kernel<<<1, kFilterQueries, 0, s>>>(a);
+    filter_prep8_fin_kernel<<<1, kFilterQueries, 0, s>>>(a, 1);
     return hipGetLastError();
 }
 
