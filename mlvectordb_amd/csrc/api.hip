@@ -44,6 +44,29 @@ struct DevBuf {
     }
 };
 
+// Pinned host staging (grow only): a hipMemcpyAsync from / to pageable memory goes through the runtime's own staging with
+// a synchronisation per copy -- four small D2H copies and one 786 KB H2D copy cost a 256-query wave 0.33 ms on top of its
+// 2.0 ms of kernels (round 2: p50_ms_per_wave_host_io 2.349 vs 2.016 device-resident).
+struct PinBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need) {
+        if (need <= bytes) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        const size_t want = need + need / 4;
+        hipError_t e = hipHostMalloc(&p, want, 0);
+        if (e == hipSuccess) bytes = want;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
 }  // namespace
 
 struct mlvdb_index {
@@ -77,6 +100,10 @@ struct mlvdb_index {
     DevBuf rp8_masked;
     DevBuf qimg, fmisc, cand, rescr, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, io_d64, counters, labels_in;
     DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
+    PinBuf pin_in, pin_out;          // pinned staging of the host-pointer entries (queries in; labels / distances / counts out)
+    DevBuf io_out;                   // one device buffer for all outputs of a host-pointer search: one D2H copy
+    bool flags_in_out = false;       // search_host: the deferred overflow flags travel behind the outputs (flags_out, device)
+    uint32_t* flags_out = nullptr;
     uint32_t* host_flags = nullptr;  // pinned, kFilterQueries words
     bool deferred = false;           // search_host: the pass left its overflow flags in host_flags instead of launching the
     FilterArgs deferred_fa{};        //   exact fallback; its arguments, for the (rare) fallback after the sync
@@ -308,6 +335,7 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
 
 // Collect the overflowed queries of a pass on the host; returns their count (device list in h->qsel).
 int collect_overflow(mlvdb_index* h, hipStream_t s, const FilterArgs& fa, int32_t* n_flagged) {
+    HIP_TRY(h, hipStreamSynchronize(s));  // (a D2H copy enqueued behind a long kernel parks in the copy queue: search_host)
     HIP_TRY(h, hipMemcpyAsync(h->host_flags, fa.overflow, kFilterQueries * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(h, hipStreamSynchronize(s));
     int32_t sel[kFilterQueries];
@@ -607,7 +635,10 @@ int finish_filter_pass(mlvdb_index* h, hipStream_t s, FilterArgs& fa, int32_t q0
         // host-pointer entry, single pass: the caller synchronises anyway to copy the results out, so the overflow
         // flags ride along to pinned memory and the exact fallback is only launched if a query needs it (search_host)
         // -- three launches fewer on every ordinary call, which is 5 % of a batch-1 call
-        HIP_TRY(h, hipMemcpyAsync(h->host_flags, fa.overflow, kFilterQueries * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (h->flags_in_out)
+            HIP_TRY(h, hipMemcpyAsync(h->flags_out, fa.overflow, kFilterQueries * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        else
+            HIP_TRY(h, hipMemcpyAsync(h->host_flags, fa.overflow, kFilterQueries * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         h->deferred_fa = fa;
         h->deferred = true;
         return MLVDB_OK;
@@ -845,6 +876,9 @@ int mlvdb_index_destroy(mlvdb_index* h) {
                       &h->cur_l})
         b->release();
     if (h->host_flags) (void)hipHostFree(h->host_flags);
+    h->pin_in.release();
+    h->pin_out.release();
+    h->io_out.release();
     for (auto& p : h->scan_events) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -1136,37 +1170,76 @@ int search_host(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, int
     if (k > MLVDB_MAX_TOPK_PAGED) return fail(h, MLVDB_ERR_UNSUPPORTED, "k above MLVDB_MAX_TOPK_PAGED");
     if (nq == 0) return MLVDB_OK;
     if (!queries || !out_labels || !out_dist || !out_counts) return fail(h, MLVDB_ERR_INVALID_ARG, "null buffer");
-    HIP_TRY(h, h->io_q.ensure((size_t)nq * h->dim * sizeof(float)));
-    HIP_TRY(h, h->io_lab.ensure((size_t)nq * k * sizeof(int64_t)));
-    HIP_TRY(h, h->io_dist.ensure((size_t)nq * k * sizeof(float)));
-    HIP_TRY(h, h->io_cnt.ensure((size_t)nq * sizeof(int32_t)));
-    if (out_dist64) HIP_TRY(h, h->io_d64.ensure((size_t)nq * k * sizeof(double)));
-    HIP_TRY(h, hipMemcpyAsync(h->io_q.p, queries, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    int rc = search_device_impl(h, h->io_q.as<float>(), nq, k, h->io_lab.as<int64_t>(), h->io_dist.as<float>(),
-                                h->io_cnt.as<int32_t>(), out_dist64 ? h->io_d64.as<double>() : nullptr, h->stream, true);
+    // queries: user memory -> pinned staging -> device (one DMA); outputs: ONE device buffer [d64 | labels | dist | counts]
+    // -> one DMA into pinned memory -> user arrays
+    const size_t qbytes = (size_t)nq * h->dim * sizeof(float);
+    const size_t b64 = out_dist64 ? (size_t)nq * k * sizeof(double) : 0, blab = (size_t)nq * k * sizeof(int64_t);
+    const size_t bdist = (size_t)nq * k * sizeof(float), bcnt = (size_t)nq * sizeof(int32_t);
+    const size_t obytes = b64 + blab + bdist + bcnt;
+    HIP_TRY(h, h->io_q.ensure(qbytes));
+    const size_t fbytes = kFilterQueries * sizeof(uint32_t), obytes_all = ((obytes + 15) & ~(size_t)15) + fbytes;
+    HIP_TRY(h, h->io_out.ensure(obytes_all));
+    HIP_TRY(h, h->pin_in.ensure(qbytes));
+    HIP_TRY(h, h->pin_out.ensure(obytes_all));
+    char* dout = h->io_out.as<char>();
+    double* d_d64 = out_dist64 ? reinterpret_cast<double*>(dout) : nullptr;
+    int64_t* d_lab = reinterpret_cast<int64_t*>(dout + b64);
+    float* d_dist = reinterpret_cast<float*>(dout + b64 + blab);
+    int32_t* d_cnt = reinterpret_cast<int32_t*>(dout + b64 + blab + bdist);
+    // MLVDB_PINNED_IO=0: round 2's pageable copies (A/B).  The pinned D2H copy is enqueued only AFTER the kernels have
+    // finished (one more host wait, ~10 us): enqueued behind them it parks at the head of the copy engine's queue for the
+    // whole scan and every copy of the index's other stream -- the hit-enrichment gather of find_similar_stream -- waits
+    // with it; measured on 4M rows: protocol stream 1.92 ms per wave parked vs 1.20 unparked (engine alone 1.07;
+    // profiles/r03/protocol_stream_pinned_io_modes_4m.txt).  A blocking event wait instead of hipStreamSynchronize: no change.
+    static const bool pinned = [] { const char* e = getenv("MLVDB_PINNED_IO"); return !(e && e[0] == '0'); }();
+    h->flags_in_out = pinned;  // the pass copies its overflow flags device-to-device behind the outputs (no parked D2H either)
+    h->flags_out = reinterpret_cast<uint32_t*>(dout + ((obytes + 15) & ~(size_t)15));
+    if (pinned) {
+        std::memcpy(h->pin_in.p, queries, qbytes);
+        HIP_TRY(h, hipMemcpyAsync(h->io_q.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
+    } else {
+        HIP_TRY(h, hipMemcpyAsync(h->io_q.p, queries, qbytes, hipMemcpyHostToDevice, h->stream));
+    }
+    int rc = search_device_impl(h, h->io_q.as<float>(), nq, k, d_lab, d_dist, d_cnt, d_d64, h->stream, true);
     if (rc) return rc;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        HIP_TRY(h, hipMemcpyAsync(out_labels, h->io_lab.p, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(out_dist, h->io_dist.p, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipMemcpyAsync(out_counts, h->io_cnt.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-        if (out_dist64)
-            HIP_TRY(h, hipMemcpyAsync(out_dist64, h->io_d64.p, (size_t)nq * k * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        if (pinned) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));  // the copy must not park behind the kernels (see above)
+            HIP_TRY(h, hipMemcpyAsync(h->pin_out.p, dout, obytes_all, hipMemcpyDeviceToHost, h->stream));
+        } else {  // round 2's form: pageable copies straight into the caller's arrays
+            if (out_dist64) HIP_TRY(h, hipMemcpyAsync(out_dist64, d_d64, b64, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(out_labels, d_lab, blab, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(out_dist, d_dist, bdist, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(out_counts, d_cnt, bcnt, hipMemcpyDeviceToHost, h->stream));
+        }
         HIP_TRY(h, hipStreamSynchronize(h->stream));
-        if (!h->deferred) break;
-        // the pass left the overflow decision to us (run_filter_pass, defer_fallback): usually nothing is flagged
-        h->deferred = false;
-        int32_t sel[kFilterQueries];
-        int32_t n = 0;
-        for (int q = 0; q < (int)nq; ++q)
-            if (h->host_flags[q]) sel[n++] = q;
-        if (n == 0) break;
-        h->host_fallbacks += n;
-        const FilterArgs& fa = h->deferred_fa;
-        HIP_TRY(h, hipMemcpyAsync(h->qsel.p, sel, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));  // `sel` is on this stack frame
-        rc = run_exact(h, h->stream, fa.Qpad, fa.qaux, n, h->qsel.as<int32_t>(), 0, h->total, k, h->io_lab.as<int64_t>(),
-                       h->io_dist.as<float>(), h->io_cnt.as<int32_t>(), out_dist64 ? h->io_d64.as<double>() : nullptr, false);
-        if (rc) return rc;
+        if (h->deferred) {
+            // the pass left the overflow decision to us (run_filter_pass, defer_fallback): usually nothing is flagged
+            h->deferred = false;
+            int32_t sel[kFilterQueries];
+            int32_t n = 0;
+            const uint32_t* flags = pinned ? reinterpret_cast<const uint32_t*>(static_cast<const char*>(h->pin_out.p) + ((obytes + 15) & ~(size_t)15))
+                                           : h->host_flags;
+            for (int q = 0; q < (int)nq; ++q)
+                if (flags[q]) sel[n++] = q;
+            if (n > 0) {
+                h->host_fallbacks += n;
+                const FilterArgs& fa = h->deferred_fa;
+                HIP_TRY(h, hipMemcpyAsync(h->qsel.p, sel, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+                HIP_TRY(h, hipStreamSynchronize(h->stream));  // `sel` is on this stack frame
+                rc = run_exact(h, h->stream, fa.Qpad, fa.qaux, n, h->qsel.as<int32_t>(), 0, h->total, k, d_lab, d_dist, d_cnt, d_d64,
+                               false);
+                if (rc) return rc;
+                continue;  // copy the corrected outputs
+            }
+        }
+        if (!pinned) break;
+        const char* po = static_cast<const char*>(h->pin_out.p);
+        if (out_dist64) std::memcpy(out_dist64, po, b64);
+        std::memcpy(out_labels, po + b64, blab);
+        std::memcpy(out_dist, po + b64 + blab, bdist);
+        std::memcpy(out_counts, po + b64 + blab + bdist, bcnt);
+        break;
     }
     return MLVDB_OK;
 }
@@ -1241,7 +1314,9 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
     HIP_TRY(h, h->io_lab.ensure((size_t)nq * cap_eff * sizeof(int64_t)));
     HIP_TRY(h, h->io_dist.ensure((size_t)nq * cap_eff * sizeof(float)));
     HIP_TRY(h, h->io_cnt.ensure((size_t)nq * sizeof(int64_t)));
-    HIP_TRY(h, hipMemcpyAsync(h->io_q.p, queries, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, h->pin_in.ensure(std::max((size_t)nq * h->dim * sizeof(float), ((size_t)nq + 1) * sizeof(int64_t))));
+    std::memcpy(h->pin_in.p, queries, (size_t)nq * h->dim * sizeof(float));  // pinned staging: one DMA (search_host)
+    HIP_TRY(h, hipMemcpyAsync(h->io_q.p, h->pin_in.p, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(h, h->qerr.ensure((size_t)nq * sizeof(float)));
     HIP_TRY(h, launch_query_prep(h->io_q.as<float>(), (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
                                  h->qaux.as<double>(), h->qerr.as<float>(), s));
@@ -1333,30 +1408,36 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
     // copy back.  Hit counts vary by orders of magnitude between queries, so the dense [nq, cap_eff] device
     // arrays are mostly padding: when the hits are a small part of them, pack the rows' valid prefixes on the
     // device and send only those (25 MB -> 0.4 MB at 256 queries x 8192 slots with 128 hits on average).
-    std::vector<int64_t> counts(nq);
-    HIP_TRY(h, hipMemcpyAsync(counts.data(), h->io_cnt.p, (size_t)nq * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, h->pin_out.ensure((size_t)nq * sizeof(int64_t)));
     HIP_TRY(h, hipStreamSynchronize(s));
+    HIP_TRY(h, hipMemcpyAsync(h->pin_out.p, h->io_cnt.p, (size_t)nq * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, hipStreamSynchronize(s));
+    std::vector<int64_t> counts(static_cast<const int64_t*>(h->pin_out.p), static_cast<const int64_t*>(h->pin_out.p) + nq);
     std::vector<int64_t> offsets((size_t)nq + 1, 0);
     for (int64_t i = 0; i < nq; ++i) offsets[(size_t)i + 1] = offsets[(size_t)i] + std::min<int64_t>(std::max<int64_t>(counts[i], 0), cap_eff);
     const int64_t total_hits = offsets[(size_t)nq];
     if (total_hits * 4 < nq * cap_eff) {
         if (total_hits > 0) {
             HIP_TRY(h, h->labels_in.ensure(((size_t)nq + 1) * sizeof(int64_t)));
-            HIP_TRY(h, h->seed_lab.ensure((size_t)total_hits * sizeof(int64_t)));
-            HIP_TRY(h, h->seed_dist.ensure((size_t)total_hits * sizeof(float)));
-            HIP_TRY(h, hipMemcpyAsync(h->labels_in.p, offsets.data(), ((size_t)nq + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            // packed outputs: one device buffer [labels | distances], one DMA into pinned memory
+            const size_t plab = (size_t)total_hits * sizeof(int64_t), pdst = (size_t)total_hits * sizeof(float);
+            HIP_TRY(h, h->seed_lab.ensure(plab + pdst));
+            HIP_TRY(h, h->pin_out.ensure(plab + pdst));
+            int64_t* d_pl = h->seed_lab.as<int64_t>();
+            float* d_pd = reinterpret_cast<float*>(h->seed_lab.as<char>() + plab);
+            std::memcpy(h->pin_in.p, offsets.data(), ((size_t)nq + 1) * sizeof(int64_t));
+            HIP_TRY(h, hipMemcpyAsync(h->labels_in.p, h->pin_in.p, ((size_t)nq + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
             range_pack_kernel<<<(unsigned)nq, 256, 0, s>>>(h->io_lab.as<int64_t>(), h->io_dist.as<float>(), h->labels_in.as<int64_t>(),
-                                                           cap_eff, h->seed_lab.as<int64_t>(), h->seed_dist.as<float>());
+                                                           cap_eff, d_pl, d_pd);
             HIP_TRY(h, hipGetLastError());
-            std::vector<int64_t> pl((size_t)total_hits);
-            std::vector<float> pd((size_t)total_hits);
-            HIP_TRY(h, hipMemcpyAsync(pl.data(), h->seed_lab.p, (size_t)total_hits * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(h, hipMemcpyAsync(pd.data(), h->seed_dist.p, (size_t)total_hits * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_TRY(h, hipMemcpyAsync(h->pin_out.p, d_pl, plab + pdst, hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
+            const int64_t* pl = static_cast<const int64_t*>(h->pin_out.p);
+            const float* pd = reinterpret_cast<const float*>(static_cast<const char*>(h->pin_out.p) + plab);
             for (int64_t i = 0; i < nq; ++i) {
                 const int64_t n = offsets[(size_t)i + 1] - offsets[(size_t)i];
-                std::memcpy(out_labels + (size_t)i * capacity, pl.data() + offsets[(size_t)i], (size_t)n * sizeof(int64_t));
-                std::memcpy(out_dist + (size_t)i * capacity, pd.data() + offsets[(size_t)i], (size_t)n * sizeof(float));
+                std::memcpy(out_labels + (size_t)i * capacity, pl + offsets[(size_t)i], (size_t)n * sizeof(int64_t));
+                std::memcpy(out_dist + (size_t)i * capacity, pd + offsets[(size_t)i], (size_t)n * sizeof(float));
             }
         }
     } else {

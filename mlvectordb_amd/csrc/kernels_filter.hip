@@ -1277,8 +1277,96 @@ __global__ __launch_bounds__(256) void range_score_kernel(const FilterArgs a, co
         if (base + i < (uint32_t)kCandCap) out[base + i] = found[i];  // beyond: counted only (the query is paged exactly)
 }
 
-__global__ __launch_bounds__(256) void range_sort_kernel(const FilterArgs a, const int32_t q0, const int64_t capacity,
-                                                         int64_t* out_labels, float* out_dist, int64_t* out_counts) {
+// Round 3: the same work as range_score_kernel, dealt out like the kNN rescoring (filter_rescore_score_kernel): the
+// 16-candidate groups of ALL queries form one flat list, group u goes to wave (u mod waves-of-the-grid), one block per CU --
+// every CU gathers the same number of rows whatever the spread of the list lengths (a query's hit count varies ~1000x with
+// |q|: the (query, chunk) grid launched 65,536 blocks of which ~1,000 had work, 820 us per 256-query wave).  A group's
+// hits (dist <= radius, live) are appended to the query's hit array behind one atomic per group.
+template <int SPACE>
+__global__ __launch_bounds__(kRescoreWaves * 64) void range_score_flat_kernel(const FilterArgs a, const float radius) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ uint32_t pre[kFilterQueries + 1];  // 16-candidate groups of the queries before q (overflowed queries: none)
+    const int ld = a.ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    double* qs = reinterpret_cast<double*>(smem) + (size_t)wave * ld;  // this wave's copy of its current query
+    if (wave == 0) {  // lane l: queries 4l .. 4l+3; inclusive scan over the lanes
+        uint32_t n[4], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = 4 * lane + i;
+            n[i] = q < a.nq && !a.overflow[q] ? (min(a.cnt[q], (uint32_t)a.cand_cap) + 15u) >> 4 : 0u;
+            sum += n[i];
+        }
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        uint32_t run = incl - sum;
+        if (lane == 0) pre[0] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            run += n[i];
+            pre[4 * lane + i + 1] = run;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = pre[kFilterQueries];
+    const int g = lane >> 4, r = lane & 15;
+    const double rad = (double)radius;
+    int cur = -1;
+    double qinv = 0.0;
+    for (uint32_t u = blockIdx.x + gridDim.x * wave; u < total; u += gridDim.x * nwaves) {
+        int lo = 0, hi = kFilterQueries;  // the query with pre[q] <= u < pre[q + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= u) lo = mid;
+            else hi = mid;
+        }
+        const int q = lo;
+        if (q != cur) {  // (wave-private LDS: no barrier; the wave's own earlier reads are done -- its loop is in order)
+            for (int c = lane; c < ld; c += 64) qs[c] = (double)a.Qpad[(int64_t)q * ld + c];
+            qinv = a.qaux[q];
+            cur = q;
+        }
+        const uint32_t cnt = min(a.cnt[q], (uint32_t)a.cand_cap);
+        const CandEntry* list = a.cand + (int64_t)q * a.cand_cap;
+        const uint32_t idx = (u - pre[q]) * 16 + r;
+        const bool have = idx < cnt;
+        const int32_t row = have ? list[idx].row : 0;
+        const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 16 + g * 4};
+        double acc[1][1], nx[1];
+        accumulate_rows<SPACE, 1, 1, kRescorePF>(base, qs, ld, g, acc, nx);
+        const double dist = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
+        bool hit = have && lane < 16 && dist <= rad;
+        if (hit) {
+            const float nrm = a.rn[row];
+            hit = nrm == nrm;
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (bal) {  // wave-uniform
+            uint32_t base_slot = 0;
+            if (lane == 0) base_slot = atomicAdd(&a.rhit_cnt[q], (uint32_t)__popcll(bal));
+            base_slot = __shfl(base_slot, 0);
+            if (hit) {
+                const uint32_t slot = base_slot + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                if (slot < (uint32_t)kCandCap) {  // beyond: counted only (the query is paged exactly)
+                    RangeHit h;
+                    h.d = dist;
+                    h.l = row;
+                    h.pad = 0;
+                    a.rhits[(int64_t)q * kCandCap + slot] = h;
+                }
+            }
+        }
+    }
+}
+
+constexpr int kSortThreads = 1024;  // the kernel is as slow as its longest list (one block per query; hit counts vary ~1000x between
+                                    // queries): 256 threads took 381 us per 256-query wave for a 6,554-hit list (profiles/r03)
+__global__ __launch_bounds__(kSortThreads) void range_sort_kernel(const FilterArgs a, const int32_t q0, const int64_t capacity,
+                                                                  int64_t* out_labels, float* out_dist, int64_t* out_counts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     RangeHit* hits = reinterpret_cast<RangeHit*>(smem);  // [np2 <= kCandCap]
     const int q = blockIdx.x;
@@ -1296,7 +1384,7 @@ __global__ __launch_bounds__(256) void range_sort_kernel(const FilterArgs a, con
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
     const RangeHit* src = a.rhits + (int64_t)q * kCandCap;
-    for (uint32_t i = threadIdx.x; i < np2; i += 256) {
+    for (uint32_t i = threadIdx.x; i < np2; i += kSortThreads) {
         RangeHit h;
         h.d = __builtin_inf();
         h.l = kNoLabel;
@@ -1306,7 +1394,7 @@ __global__ __launch_bounds__(256) void range_sort_kernel(const FilterArgs a, con
     __syncthreads();
     for (uint32_t size = 2; size <= np2; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (np2 >> 1); t += 256) {
+            for (uint32_t t = threadIdx.x; t < (np2 >> 1); t += kSortThreads) {
                 const uint32_t lo = 2 * t - (t & (stride - 1));
                 const uint32_t hi = lo + stride;
                 const bool up = (lo & size) == 0;
@@ -1321,7 +1409,7 @@ __global__ __launch_bounds__(256) void range_sort_kernel(const FilterArgs a, con
         }
     }
     const uint32_t emit = n < (uint64_t)capacity ? n : (uint32_t)capacity;
-    for (uint32_t i = threadIdx.x; i < emit; i += 256) {
+    for (uint32_t i = threadIdx.x; i < emit; i += kSortThreads) {
         out_labels[(int64_t)(q0 + q) * capacity + i] = hits[i].l;
         out_dist[(int64_t)(q0 + q) * capacity + i] = (float)hits[i].d;
     }
@@ -2322,18 +2410,24 @@ hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int
 
 hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, int64_t capacity, int64_t* out_labels,
                                 float* out_dist, int64_t* out_counts, hipStream_t s) {
-    const size_t lds_score = (size_t)a.ld * sizeof(double) + (size_t)kRangeChunk * sizeof(RangeHit) + 16;
     const size_t lds_sort = (size_t)kCandCap * sizeof(RangeHit);
-    const dim3 grid((unsigned)a.nq, (unsigned)((a.cand_cap + kRangeChunk - 1) / kRangeChunk));
     hipError_t e = hipMemsetAsync(a.rhit_cnt, 0, kFilterQueries * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
+    // MLVDB_RANGE_FLAT=0: round 2's (query, 256-candidate chunk) grid (A/B)
+    const bool flat = env_int("MLVDB_RANGE_FLAT", 1) != 0;
+    int waves = kRescoreWaves;
+    while (waves > 1 && (size_t)waves * a.ld * sizeof(double) > 144 * 1024) waves >>= 1;
+    const size_t lds_score = flat ? std::max((size_t)waves * a.ld * sizeof(double), (size_t)96 * 1024)
+                                  : (size_t)a.ld * sizeof(double) + (size_t)kRangeChunk * sizeof(RangeHit) + 16;
+    const dim3 grid = flat ? dim3(kRescoreGrid) : dim3((unsigned)a.nq, (unsigned)((a.cand_cap + kRangeChunk - 1) / kRangeChunk));
+    const int threads = flat ? waves * 64 : 256;
 #define MLVDB_LAUNCH_RANGE(SP)                                                                                        \
     do {                                                                                                              \
-        auto kern = range_score_kernel<SP>;                                                                           \
+        auto kern = flat ? range_score_flat_kernel<SP> : range_score_kernel<SP>;                                      \
         if (lds_score > 48 * 1024)                                                                                    \
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                     (int)lds_score);                                                                  \
-        if (e == hipSuccess) kern<<<grid, 256, lds_score, s>>>(a, radius);                                            \
+        if (e == hipSuccess) kern<<<grid, threads, lds_score, s>>>(a, radius);                                        \
     } while (0)
     switch (a.space) {
         case kSpaceL2: MLVDB_LAUNCH_RANGE(kSpaceL2); break;
@@ -2346,7 +2440,7 @@ hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, i
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(range_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_sort);
     if (e != hipSuccess) return e;
-    range_sort_kernel<<<a.nq, 256, lds_sort, s>>>(a, q0, capacity, out_labels, out_dist, out_counts);
+    range_sort_kernel<<<a.nq, kSortThreads, lds_sort, s>>>(a, q0, capacity, out_labels, out_dist, out_counts);
     return hipGetLastError();
 }
 
