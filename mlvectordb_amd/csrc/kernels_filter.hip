@@ -1222,9 +1222,8 @@ __global__ __launch_bounds__(kRankWaves * 64) void filter_rescore_rank_kernel(co
 // (query, chunk of kRangeChunk candidates) blocks instead of one block per query:
 //   range_score_kernel  exact fp64 distance of every candidate of its chunk; the hits (dist <= radius, live) are
 //                       collected in LDS and copied to the query's hit array behind one atomic reservation;
-//   range_sort_kernel   one block per query: bitonic sort of its hits by (distance, label) in LDS, emit the nearest
-//                       `capacity`, publish the exact count.  More than kCandCap hits: flagged, served by the paged
-//                       exact kNN (api.hip).
+//   range_rank_kernel   blocks over (query, 256 hits): rank of every hit by (distance, label), written to its place;
+//                       publishes the exact count.  More than kCandCap hits: flagged, served by the paged exact kNN (api.hip).
 template <int SPACE>
 __global__ __launch_bounds__(256) void range_score_kernel(const FilterArgs a, const float radius) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1363,57 +1362,106 @@ __global__ __launch_bounds__(kRescoreWaves * 64) void range_score_flat_kernel(co
     }
 }
 
-constexpr int kSortThreads = 1024;  // the kernel is as slow as its longest list (one block per query; hit counts vary ~1000x between
-                                    // queries): 256 threads took 381 us per 256-query wave for a 6,554-hit list (profiles/r03)
-__global__ __launch_bounds__(kSortThreads) void range_sort_kernel(const FilterArgs a, const int32_t q0, const int64_t capacity,
+// Ordering the hits of a query by (distance, label) -- by RANKING, not sorting: a hit's rank is the number of hits that
+// precede it, ranks are a permutation (labels are unique), so every hit is written straight to its place.  Blocks over
+// (query, chunk of 256 hits); every block holds the query's whole hit list in LDS as {d[], l[]} and each thread counts the
+// predecessors of one hit (all lanes read the same LDS word per step: a broadcast).  Round 2 sorted each list with one
+// bitonic network per query in LDS: 91 stages x 8192 x 16-byte records for the longest list of a wave (6,554 hits) are
+// 36 MB through one CU's LDS -- 300-380 us per 256-query wave with 255 CUs idle (profiles/r03/config4_l2_range_kernel_stats.csv).
+// Here the longest list is spread over 26 blocks of 6,554 steps each.  More than kCandCap hits: flagged, served by the
+// paged exact kNN (api.hip), as before.
+constexpr int kRankChunk = 256;
+constexpr int kRankGrid = 256;  // one block per CU; the (query, chunk) work items are dealt to the blocks in turn.  (A grid of
+                                // nq x 32 blocks, most of which exit at once, took 2.5 ms just to be dispatched: every block asks
+                                // for 98 KB of LDS.)
+__global__ __launch_bounds__(kRankChunk) void range_rank_kernel(const FilterArgs a, const int32_t q0, const int64_t capacity,
                                                                   int64_t* out_labels, float* out_dist, int64_t* out_counts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    RangeHit* hits = reinterpret_cast<RangeHit*>(smem);  // [np2 <= kCandCap]
-    const int q = blockIdx.x;
-    if (q >= a.nq || a.overflow[q]) return;
-    const uint32_t total = a.rhit_cnt[q];
-    if (total > (uint32_t)kCandCap) {  // more hits than one block sorts: the exact count is known, the hits come from the
-        if (threadIdx.x == 0) {        // paged exact kNN (api.hip reads the flag after the kernel; cnt = the exact count)
-            a.overflow[q] = 2u;
-            a.cnt[q] = total;
-            out_counts[q0 + q] = total;
+    __shared__ uint32_t pre[kFilterQueries + 1];  // chunks of the queries before q
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {  // lane l: queries 4l .. 4l+3; inclusive scan over the lanes
+        uint32_t c[4], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = 4 * lane + i;
+            uint32_t n = 0;
+            if (q < a.nq && !a.overflow[q]) {
+                n = a.rhit_cnt[q];
+                if (blockIdx.x == 0) {
+                    if (n > (uint32_t)kCandCap) {  // more hits than a list holds: the exact count is known, the hits come from
+                        a.overflow[q] = 2u;         // the paged exact kNN (api.hip reads the flag after the kernel)
+                        a.cnt[q] = n;
+                    }
+                    out_counts[q0 + q] = n;
+                }
+                if (n > (uint32_t)kCandCap) n = 0;
+            }
+            c[i] = (n + kRankChunk - 1) / kRankChunk;
+            sum += c[i];
         }
-        return;
-    }
-    const uint32_t n = total;
-    uint32_t np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    const RangeHit* src = a.rhits + (int64_t)q * kCandCap;
-    for (uint32_t i = threadIdx.x; i < np2; i += kSortThreads) {
-        RangeHit h;
-        h.d = __builtin_inf();
-        h.l = kNoLabel;
-        h.pad = 0;
-        hits[i] = i < n ? src[i] : h;
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        uint32_t run = incl - sum;
+        if (lane == 0) pre[0] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            run += c[i];
+            pre[4 * lane + i + 1] = run;
+        }
     }
     __syncthreads();
-    for (uint32_t size = 2; size <= np2; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = threadIdx.x; t < (np2 >> 1); t += kSortThreads) {
-                const uint32_t lo = 2 * t - (t & (stride - 1));
-                const uint32_t hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const RangeHit x = hits[lo], y = hits[hi];
-                const bool x_after_y = entry_less(y.d, y.l, x.d, x.l);
-                if (x_after_y == up) {
-                    hits[lo] = y;
-                    hits[hi] = x;
-                }
+    const uint32_t total = pre[kFilterQueries];
+    for (uint32_t u = blockIdx.x; u < total; u += gridDim.x) {  // block-uniform
+        int lo = 0, hi = kFilterQueries;  // the query with pre[q] <= u < pre[q + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (pre[mid] <= u) lo = mid;
+            else hi = mid;
+        }
+        const int q = lo;
+        const uint32_t n = a.rhit_cnt[q];  // (<= kCandCap: larger lists have no chunks)
+        const uint32_t n8 = (n + 7u) & ~7u;  // padded with (+inf, kNoLabel): precedes nothing
+        double* ed = reinterpret_cast<double*>(smem);       // [n8]
+        int32_t* el = reinterpret_cast<int32_t*>(ed + n8);  // [n8], 16-byte aligned
+        const RangeHit* src = a.rhits + (int64_t)q * kCandCap;
+        __syncthreads();  // the previous item's readers are done with the LDS copy
+        for (uint32_t i = threadIdx.x; i < n8; i += kRankChunk) {
+            RangeHit h;
+            h.d = __builtin_inf();
+            h.l = kNoLabel;
+            if (i < n) h = src[i];
+            ed[i] = h.d;
+            el[i] = h.l;
+        }
+        __syncthreads();
+        const uint32_t i = (u - pre[q]) * (uint32_t)kRankChunk + threadIdx.x;
+        if (i < n) {
+            const double di = ed[i];
+            const int32_t li = el[i];
+            // 8 list entries per step, read as 4 + 2 16-byte LDS words (every lane the same address: broadcasts) and compared
+            // without branches: with one entry per step and entry_less's short-circuit the loop was two exposed LDS round trips
+            // per entry (873 us for the 6,554-hit list of the benchmark wave)
+            const double2* e2 = reinterpret_cast<const double2*>(ed);
+            const int4* l4 = reinterpret_cast<const int4*>(el);
+            uint32_t rank = 0;
+            auto before = [&](double d, int32_t l) __attribute__((always_inline)) {
+                return (uint32_t)((d < di) | ((d == di) & (l < li)));
+            };
+            for (uint32_t j = 0; j < n8; j += 8) {
+                const double2 d0 = e2[j / 2], d1 = e2[j / 2 + 1], d2 = e2[j / 2 + 2], d3 = e2[j / 2 + 3];
+                const int4 la = l4[j / 4], lb = l4[j / 4 + 1];
+                rank += before(d0.x, la.x) + before(d0.y, la.y) + before(d1.x, la.z) + before(d1.y, la.w) +
+                        before(d2.x, lb.x) + before(d2.y, lb.y) + before(d3.x, lb.z) + before(d3.y, lb.w);
             }
-            __syncthreads();
+            if ((int64_t)rank < capacity) {
+                out_labels[(int64_t)(q0 + q) * capacity + rank] = li;
+                out_dist[(int64_t)(q0 + q) * capacity + rank] = (float)di;
+            }
         }
     }
-    const uint32_t emit = n < (uint64_t)capacity ? n : (uint32_t)capacity;
-    for (uint32_t i = threadIdx.x; i < emit; i += kSortThreads) {
-        out_labels[(int64_t)(q0 + q) * capacity + i] = hits[i].l;
-        out_dist[(int64_t)(q0 + q) * capacity + i] = (float)hits[i].d;
-    }
-    if (threadIdx.x == 0) out_counts[q0 + q] = n;
 }
 
 // ------------------------------------------------------------------ launchers
@@ -2410,7 +2458,7 @@ hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int
 
 hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, int64_t capacity, int64_t* out_labels,
                                 float* out_dist, int64_t* out_counts, hipStream_t s) {
-    const size_t lds_sort = (size_t)kCandCap * sizeof(RangeHit);
+    const size_t lds_sort = (size_t)kCandCap * (sizeof(double) + sizeof(int32_t));  // the ranking kernel's {d[], l[]} (kCandCap % 8 == 0)
     hipError_t e = hipMemsetAsync(a.rhit_cnt, 0, kFilterQueries * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     // MLVDB_RANGE_FLAT=0: round 2's (query, 256-candidate chunk) grid (A/B)
@@ -2437,10 +2485,10 @@ hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, i
 #undef MLVDB_LAUNCH_RANGE
     if (e != hipSuccess) return e;
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(range_sort_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(range_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_sort);
     if (e != hipSuccess) return e;
-    range_sort_kernel<<<a.nq, kSortThreads, lds_sort, s>>>(a, q0, capacity, out_labels, out_dist, out_counts);
+    range_rank_kernel<<<kRankGrid, kRankChunk, lds_sort, s>>>(a, q0, capacity, out_labels, out_dist, out_counts);
     return hipGetLastError();
 }
 
