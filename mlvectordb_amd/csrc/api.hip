@@ -77,9 +77,9 @@ struct mlvdb_index {
     float* X = nullptr;   // panels, capacity * ld floats
     void* Xb = nullptr;   // bf16 shadow of X for the filter scan (capacity * ld bf16), or nullptr
     bool shadow = false;  // keep the bf16 shadow (decided at creation: dim % 64 == 0 and not disabled)
-    bool i8_only = false; // MLVDB_SHADOW=int8 at creation (dim % 256 == 0): no bf16 shadow, the int8 one serves kNN and range
-                          // scans (1.25x instead of 1.75x the corpus in HBM); row-mask searches, the seeding pass and
-                          // indexes whose rows quantise too badly for int8 bounds convert the fp32 rows in registers
+    bool i8_only = false; // dim % 256 == 0 (default since round 3; MLVDB_SHADOW=bf16 at creation keeps both): no bf16 shadow, the
+                          // int8 one serves every pass (1.25x instead of 1.75x the corpus in HBM); only an index whose rows
+                          // quantise too badly for int8 bounds (l2 / ip, rmax8 > 0.03) converts the fp32 rows in registers
     float* rn = nullptr;  // row norms, NaN = tombstoned / not a row
     int64_t capacity = 0, total = 0, deleted = 0;
     hipStream_t stream = nullptr;
@@ -834,7 +834,10 @@ int mlvdb_index_create(int device, int32_t dim, int32_t space, int64_t capacity_
     {
         const char* ns = getenv("MLVDB_NO_SHADOW");
         const char* sm = getenv("MLVDB_SHADOW");
-        h->i8_only = sm && !strcmp(sm, "int8") && h->ld % 256 == 0 && !(ns && ns[0] == '1');
+        // Round 3: where the int8 shadow exists (dim % 256 == 0) it is the only one by default -- seeding pass, small
+        // batches of every space, scans, range and row-mask searches all run on it: 1.25x the corpus in HBM instead of
+        // 1.75x.  MLVDB_SHADOW=bf16 keeps the bf16 shadow as well (the bf16 bodies for A/B, MLVDB_I8=0).
+        h->i8_only = h->ld % 256 == 0 && !(ns && ns[0] == '1') && !(sm && !strcmp(sm, "bf16"));
         h->shadow = filter_supported(h->ld) && !(ns && ns[0] == '1') && !h->i8_only;
     }
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);

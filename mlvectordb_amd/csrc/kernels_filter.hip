@@ -165,7 +165,8 @@ template <int SPACE, int kMT, bool DENSE, int NQT = 16, bool I8 = false>
 __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (&acc)[kMT][NQT], const float4 (&rnv)[kMT],
                                               const float4 (&rbv)[kMT], const int32_t row0, const int32_t base_row,
                                               const float* thr_l, const float* sq_l, const float* ke_l, float* dump,
-                                              const int c16) {
+                                              const int c16, const int qbase = 0) {
+    // qbase: first query of the 16*NQT this call covers (thr_l / sq_l / ke_l are already offset by it; the lists are not)
     // ke = the query's error term (filter_prep_kernel).  Per-row constants:
     //   cosine  u = a*p0 + ke             (p0 = 1/(|x|+1e-30))
     //   ip      u = a + ke*p0             (p0 = |x|)
@@ -176,7 +177,8 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
         const float nr[4] = {rnv[m].x, rnv[m].y, rnv[m].z, rnv[m].w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (I8) {  // int8 shadow (cosine): acc = float(integer dot), rnv = sx/(|x|+1e-30), rbv = the row's error x K
+            if (I8) {  // int8 shadow: acc = float(integer dot).  cosine: rnv = sx/(|x|+1e-30), rbv = the row's error x K;
+                       // l2 / ip: rnv = the row's scale sx, rbv = |x| (p1 of l2 is derived from it below)
                 const float nb[4] = {rbv[m].x, rbv[m].y, rbv[m].z, rbv[m].w};
                 p0[m][i] = nr[i];
                 p1[m][i] = nb[i];
@@ -191,7 +193,16 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
     }
     auto bound = [&](int m, int i, int n, float sq, float ke) __attribute__((always_inline)) {
         const float av = acc[m][n][i];
-        if (I8) return __builtin_fmaf(__builtin_fmaf(av, p0[m][i], p1[m][i]), sq, ke);  // sq8 (w + b K) + ke8
+        if (I8 && SPACE == kSpaceCosine) return __builtin_fmaf(__builtin_fmaf(av, p0[m][i], p1[m][i]), sq, ke);  // sq8 (w + b K) + ke8
+        if (I8) {
+            // l2 / ip on the int8 shadow, the assembly body's arithmetic (filter_scan_asm_kernel's preamble): w = float(I) sx;
+            // ip  u = sq8 (w + ke' |x|),  l2  u = sq' (w + ke' |x|) - |x|^2 (1 - slack)  with ke' = ke / sq8 rounded up and
+            // sq = sq8 (ip) or 2 |q| sq8 (l2), both prepared per query by the kernel
+            const float w = av * p0[m][i];
+            const float t = __builtin_fmaf(ke, p1[m][i], w);
+            if (SPACE == kSpaceIp) return sq * t;
+            return __builtin_fmaf(sq, t, -(p1[m][i] * p1[m][i]) * (1.0f - kSlack));
+        }
         if (SPACE == kSpaceCosine) return __builtin_fmaf(av, p0[m][i], ke);
         if (SPACE == kSpaceIp) return __builtin_fmaf(ke, p0[m][i], av);
         return __builtin_fmaf(sq, __builtin_fmaf(ke, p0[m][i], av), p1[m][i]);
@@ -203,7 +214,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
         for (int n = 0; n < NQT; ++n) {
             const float sq = (SPACE == kSpaceL2 || I8) ? sq_l[16 * n + c16] : 1.0f;
             const float ke = ke_l[16 * n + c16];
-            CandEntry* dst = a.cand + (int64_t)(16 * n + c16) * kCandCap + (row0 - base_row);
+            CandEntry* dst = a.cand + (int64_t)(qbase + 16 * n + c16) * kCandCap + (row0 - base_row);
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
@@ -237,7 +248,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) mask |= bound(m, i, n, sq, ke) >= thr ? 1u << (4 * m + i) : 0u;
-            if (mask) slot = atomicAdd(&a.cnt[16 * n + c16], (uint32_t)__popc(mask));
+            if (mask) slot = atomicAdd(&a.cnt[qbase + 16 * n + c16], (uint32_t)__popc(mask));
         }
         packed[n] = mask | (min(slot, (uint32_t)a.cand_cap) << 12);
     }
@@ -251,7 +262,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) dump[(4 * m + i) * 64] = bound(m, i, n, sq, ke);
-            const int q = 16 * n + c16;
+            const int q = qbase + 16 * n + c16;
             uint32_t mask = packed[n] & 0xfffu;
             uint32_t slot = packed[n] >> 12;
             while (mask) {
@@ -483,17 +494,30 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
     const int64_t ntiles = tile_end - tile_begin;
     const int64_t my_tiles = ntiles > blockIdx.x ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     if (my_tiles == 0) return;
+    // blockIdx.y (dense seeding pass of a batch of more than 16*NQT queries): which group of 16*NQT queries this workgroup serves
+    const int qbase = blockIdx.y * (16 * NQT);
     if (threadIdx.x < kFilterQueries) {
         thr_l[threadIdx.x] = a.thr[threadIdx.x];
-        sq_l[threadIdx.x] = I8 ? a.sq8[threadIdx.x] : a.qscale[threadIdx.x];
-        ke_l[threadIdx.x] = I8 ? a.ke8[threadIdx.x] : a.ke[threadIdx.x];
+        float sqv = a.qscale[threadIdx.x], kev = a.ke[threadIdx.x];
+        if (I8) {
+            const float sq8 = a.sq8[threadIdx.x];
+            if (SPACE == kSpaceCosine) {
+                sqv = sq8;
+                kev = a.ke8[threadIdx.x];
+            } else {  // (scan_epilogue: u = sq (w + ke' |x|) [+ p1])
+                kev = float_above((double)kev / (double)sq8);
+                sqv = SPACE == kSpaceL2 ? sqv * sq8 : sq8;
+            }
+        }
+        sq_l[threadIdx.x] = sqv;
+        ke_l[threadIdx.x] = kev;
     }
     // query image (filter_prep_kernel's [kc][n][ks][lane] order) -> LDS [2kc+ks][n < NQT][lane]
     {
         const uint4* qimg = reinterpret_cast<const uint4*>(I8 ? a.qimg8 : a.qimg);
         for (int v = threadIdx.x; v < nsteps * NQT * 64; v += NW * 64) {
             const int l = v & 63, n = (v >> 6) % NQT, st = (v >> 6) / NQT;
-            qlds[v] = qimg[(((st >> 1) * 16 + n) * 2 + (st & 1)) * 64 + l];
+            qlds[v] = qimg[(((st >> 1) * 16 + (qbase >> 4) + n) * 2 + (st & 1)) * 64 + l];
         }
     }
     __syncthreads();
@@ -501,7 +525,7 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
     typename std::conditional<I8, i32x4, f32x4>::type acc[kMT][NQT];
     float4 xr[R][kMT];
     float4 rnv[kMT], rbv[kMT];
-    const float kq = I8 ? a.ke8[kFilterQueries] : 0.f;
+    const float kq = I8 ? (SPACE == kSpaceCosine ? a.ke8[kFilterQueries] : 1.0f) : 0.f;  // cosine: the factor of the rows' own errors
     const uint32_t panel_bytes = (uint32_t)ld * (I8 ? 16 : 32);  // 16 rows of int8 / bf16
     const uint32_t wave_bytes = kMT * panel_bytes;
     const uint64_t tile_stride_bytes = (uint64_t)gridDim.x * (NW * wave_bytes);
@@ -577,8 +601,8 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
                 else accf[m][n] = acc[m][n];
             }
         scan_epilogue<SPACE, kMT, DENSE, NQT, I8>(a, accf, rnv, rbv, (int32_t)(tile * kFilterTileRows) + wave * (16 * kMT) + g * 4,
-                                              (int32_t)(tile_begin * kFilterTileRows), thr_l, sq_l, ke_l,
-                                              hit_l + wave * (4 * kMT * 64) + lane, c16);
+                                              (int32_t)(tile_begin * kFilterTileRows), thr_l + qbase, sq_l + qbase, ke_l + qbase,
+                                              hit_l + wave * (4 * kMT * 64) + lane, c16, qbase);
     }
 }
 
@@ -2163,7 +2187,7 @@ static size_t narrow_lds(int32_t ld, int nqt, int nw, bool i8 = false) {
     return (size_t)(ld / (i8 ? 64 : 32)) * nqt * 1024 + 3 * kFilterQueries * sizeof(float) + (size_t)nw * 4 * 2 * 64 * sizeof(float);
 }
 bool filter_narrow_ok(const FilterArgs& a) {
-    if (!a.Xb || a.nq > kNarrowMaxQueries) return false;
+    if (!(a.Xb || a.X8) || a.nq > kNarrowMaxQueries) return false;  // streams the int8 shadow when the pass has one, else the bf16 one
     if (env_int("MLVDB_SCAN_NARROW", 1) == 0) return false;
     // int8 bounds admit ~7x more rows than bf16 ones and this kernel appends them one atomic at a time: beyond 8
     // queries the 256-query body (appends staged per wave) is faster (profiles/r01/small_batch_ab_10m_i8.txt)
@@ -2171,7 +2195,7 @@ bool filter_narrow_ok(const FilterArgs& a) {
     return narrow_lds(a.ld, narrow_nqt(a.nq), 8, a.X8 != nullptr) <= kNarrowLdsMax;
 }
 template <int SPACE, int NQT, bool DENSE, int R, int NW, bool I8 = false>
-static hipError_t launch_scan_narrow_n(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
+static hipError_t launch_scan_narrow_n(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, int qgroups = 1) {
     constexpr int tile_rows = NW * 32;
     const int64_t tile_begin = row_begin / tile_rows;
     const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
@@ -2188,16 +2212,14 @@ static hipError_t launch_scan_narrow_n(const FilterArgs& a, int64_t row_begin, i
     static std::atomic<uint64_t> configured{0};  // per instantiation
     if (hipError_t e = ensure_dynamic_lds(configured, reinterpret_cast<const void*>(kern), (int)kNarrowLdsMax); e != hipSuccess)
         return e;
-    kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end);
+    kern<<<dim3((unsigned)grid, (unsigned)qgroups), NW * 64, lds, s>>>(a, tile_begin, tile_end);
     return hipGetLastError();
 }
 template <int SPACE, int NQT, bool DENSE>
 static hipError_t launch_scan_narrow_q(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s) {
-    if constexpr (SPACE == kSpaceCosine) {
-        if (a.X8) {  // int8 shadow: k-steps of 64 columns; ld % 256 == 0, so their count is a multiple of 4
-            if constexpr (DENSE) return launch_scan_narrow_n<SPACE, NQT, true, 4, 4, true>(a, row_begin, row_end, s);
-            else return launch_scan_narrow_n<SPACE, NQT, false, 4, 8, true>(a, row_begin, row_end, s);
-        }
+    if (a.X8) {  // int8 shadow: k-steps of 64 columns; ld % 256 == 0, so their count is a multiple of 4
+        if constexpr (DENSE) return launch_scan_narrow_n<SPACE, NQT, true, 4, 4, true>(a, row_begin, row_end, s);
+        else return launch_scan_narrow_n<SPACE, NQT, false, 4, 8, true>(a, row_begin, row_end, s);
     }
     const bool r4 = (a.ld / 32) % 4 == 0;
     if constexpr (DENSE) {  // the seeding pass is a few tiles: one geometry
@@ -2370,8 +2392,7 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
     hipError_t e;
     const bool xb = a.Xb != nullptr;
     if (filter_narrow_ok(a)) {
-        FilterArgs b = a;
-        if (a.X8 && a.space != kSpaceCosine) b.ke = a.keb;  // l2 / ip: the narrow kernel is the bf16 one
+        FilterArgs b = a;  // (round 3: the narrow kernel runs on the int8 shadow for every space)
         e = a.space == kSpaceL2       ? launch_scan_narrow<kSpaceL2, true>(b, 0, rows, s)
             : a.space == kSpaceCosine ? launch_scan_narrow<kSpaceCosine, true>(b, 0, rows, s)
                                       : launch_scan_narrow<kSpaceIp, true>(b, 0, rows, s);
@@ -2380,6 +2401,21 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
             const bool fuse = filter_refine_can_fuse(a);
             if ((e = launch_filter_refine_thr(a, k, (int32_t)rows, fuse, s)) != hipSuccess || fuse) return e;
         }
+        return launch_update(a, k, (int32_t)rows, s);
+    }
+    if (a.X8 && env_int("MLVDB_SEED_I8", 1)) {
+        // Round 3: the dense pass of a 256-query batch on the int8 shadow too -- the narrow kernel (64 queries' image in LDS)
+        // once per group of 64 queries (grid.y): 30 row tiles x 4 groups = 120 workgroups instead of the 30 of the bf16
+        // kernel below, half the MFMAs, and no pass of the default path reads the bf16 shadow any more (so an index need
+        // not keep one: 1.25x instead of 1.75x the corpus in HBM).  Every bound goes into the lists either way; the refine
+        // that follows takes the threshold from exact scores.
+        const int groups = (a.nq + 63) / 64;
+        e = a.space == kSpaceL2       ? launch_scan_narrow_n<kSpaceL2, 4, true, 4, 4, true>(a, 0, rows, s, groups)
+            : a.space == kSpaceCosine ? launch_scan_narrow_n<kSpaceCosine, 4, true, 4, 4, true>(a, 0, rows, s, groups)
+                                      : launch_scan_narrow_n<kSpaceIp, 4, true, 4, 4, true>(a, 0, rows, s, groups);
+        if (e != hipSuccess) return e;
+        const bool fuse = filter_refine_can_fuse(a);
+        if ((e = launch_filter_refine_thr(a, k, (int32_t)rows, fuse, s)) != hipSuccess || fuse) return e;
         return launch_update(a, k, (int32_t)rows, s);
     }
     FilterArgs b = a;

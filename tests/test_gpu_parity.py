@@ -148,11 +148,16 @@ def test_filter_without_bf16_shadow_matches_oracle(space, monkeypatch):
         assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"noshadow/{space}/n{n}d{d}")
 
 
+@pytest.mark.parametrize("shadow", ["default", "bf16"])
 @pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
-def test_int8_only_shadow_matches_oracle(space, monkeypatch):
-    """MLVDB_SHADOW=int8 (dim % 256 == 0): no bf16 shadow in HBM (1.25x instead of 1.75x the corpus); kNN and range scans run
-    on the int8 shadow, the seeding pass / row masks / narrow batches convert the fp32 rows in registers.  Same answers."""
-    monkeypatch.setenv("MLVDB_SHADOW", "int8")
+def test_int8_only_shadow_matches_oracle(space, shadow, monkeypatch):
+    """dim % 256 == 0: by default (round 3) the index keeps NO bf16 shadow in HBM (1.25x instead of 1.75x the corpus): seeding
+    pass, small batches of every space, scans, range and row-mask searches all run on the int8 shadow.  MLVDB_SHADOW=bf16 keeps
+    both shadows (round 2's default).  Same answers."""
+    if shadow == "bf16":
+        monkeypatch.setenv("MLVDB_SHADOW", "bf16")
+    else:
+        monkeypatch.delenv("MLVDB_SHADOW", raising=False)
     for seed, n, d, nq, k in [(64, 40000, 256, 40, 10), (65, 9000, 768, 300, 5), (66, 36000, 512, 3, 10)]:
         rows, qs = make_case(seed, n, d, nq, dup=True)
         deleted = deleted_mask(seed, n, 0.1)
@@ -322,19 +327,21 @@ def test_range_capacity_overflow_is_reported_then_resolved():
 SCAN_VARIANTS = [
     {},                                              # defaults: int8 shadow body where dim % 256 == 0, else the bf16 body below
     {"MLVDB_SCAN_PRIO": "0"},                        # int8 body without the progress-based wave priorities
-    {"MLVDB_I8": "0"},                               # bf16 body: one 8-wave workgroup per CU, Q by LDS-DMA
-    {"MLVDB_I8": "0", "MLVDB_SCAN_DMA": "0"},        # Q staged through registers (global -> VGPR -> ds_write)
-    {"MLVDB_I8": "0", "MLVDB_SCAN_NW": "4"},         # two 4-wave workgroups per CU
-    {"MLVDB_I8": "0", "MLVDB_SCAN_MT": "4"},         # one wave per SIMD, 64 rows per wave
-    {"MLVDB_I8": "0", "MLVDB_SCAN_NT": "0"},         # (cosine only) temporal X loads
-    {"MLVDB_I8": "0", "MLVDB_SCAN_ASM": "0"},        # the hipcc-scheduled kernel (also serves corpora without shadow)
-    {"MLVDB_I8": "0", "MLVDB_SCAN_STAG": "1"},       # later half of the waves half a tile behind (rotated k origin)
+    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16"},                               # bf16 body: one 8-wave workgroup per CU, Q by LDS-DMA
+    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16", "MLVDB_SCAN_DMA": "0"},        # Q staged through registers (global -> VGPR -> ds_write)
+    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16", "MLVDB_SCAN_NW": "4"},         # two 4-wave workgroups per CU
+    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16", "MLVDB_SCAN_MT": "4"},         # one wave per SIMD, 64 rows per wave
+    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16", "MLVDB_SCAN_NT": "0"},         # (cosine only) temporal X loads
+    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16", "MLVDB_SCAN_ASM": "0"},        # the hipcc-scheduled kernel (also serves corpora without shadow)
+    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16", "MLVDB_SCAN_STAG": "1"},       # later half of the waves half a tile behind (rotated k origin)
     {"MLVDB_SCAN_VAR": "230"},                       # (cosine, int8) one wave per SIMD, 64 rows per wave, AccVGPR accumulators
     {"MLVDB_SCAN_VAR": "231"},                       # (cosine, int8) four Q buffers, B-fragment reads across the chunk barrier
     {"MLVDB_SCAN_VAR": "233"},                       # ... with the early-out hit stubs
     {"MLVDB_SCAN_VAR": "235"},                       # (cosine, int8) straight-line append routine
     {"MLVDB_SCAN_VAR": "236"},                       # ... with the early-out hit stubs
     {"MLVDB_SCAN_XCD": "1"},                         # every XCD scans one contiguous eighth of the tile range
+    {"MLVDB_SHADOW": "bf16"},                        # both shadows kept (round 2's default): int8 scans, bf16 seeding / narrow passes off
+    {"MLVDB_SEED_I8": "0"},                          # int8-only index, seeding pass by the compiler kernel on the fp32 rows
 ]
 
 NARROW_CASES = [

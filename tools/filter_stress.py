@@ -54,9 +54,9 @@ for case in range(args.cases):
     if rng.random() < 0.3:  # queries that are (noisy) copies of rows: exact and near matches
         src = rng.integers(0, n, nq)
         qs = (rows[src] * (1 + 0.001 * rng.standard_normal((nq, d)))).astype(np.float32)
-    i8only = d % 256 == 0 and rng.random() < 0.25     # no bf16 shadow (MLVDB_SHADOW=int8)
-    if i8only:
-        os.environ["MLVDB_SHADOW"] = "int8"
+    i8only = d % 256 == 0 and rng.random() < 0.75     # no bf16 shadow (the default since round 3; else MLVDB_SHADOW=bf16)
+    if d % 256 == 0 and not i8only:
+        os.environ["MLVDB_SHADOW"] = "bf16"
     eng = HipScanEngine(d, space, device=0, strategy="filter")
     os.environ.pop("MLVDB_SHADOW", None)
     eng.append(rows[: n // 2])
