@@ -133,8 +133,14 @@ def in_process_main(args, json_fd) -> None:
     t_start = time.perf_counter()
     for _ in range(args.steps):
         index.search_many(q_host, k, "bench", args.space)
+    unpipelined = time.perf_counter() - t_start
+    # throughput mode: Index.search_stream -- the shard scans of wave i+1 are queued before wave i is merged (round 3)
+    t_start = time.perf_counter()
+    n_waves = sum(1 for _ in index.search_stream((q_host for _ in range(args.steps)), k, "bench", args.space))
     elapsed = time.perf_counter() - t_start
+    assert n_waves == args.steps
     out.update({"value": round(g * batch * args.steps / elapsed, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+                "ms_per_step_unpipelined_search_many": round(unpipelined / args.steps * 1e3, 3),
                 "whole_corpus_qps": round(batch * args.steps / elapsed, 1),
                 "dtype": "i8 / bf16 (MFMA bounds) + f64 (exact rescoring of the f32 rows)"})
     index.close()

@@ -386,6 +386,57 @@ class Index:
 
     _MAX_TOP_K = 16384  # MLVDB_MAX_TOPK_PAGED: the most neighbours one call returns per query
 
+    def search_stream(self, batches, top_k: int, namespace: str, metric: str):
+        """Additive: ``search_many`` over an iterable of query batches, pipelined -- yields one ``BatchHits`` per batch, in
+        order, while the next batch is already being scanned.  On a row-sharded namespace (``Index(devices=[...])``) the
+        shard scans of wave i+1 are queued before wave i's per-shard candidates are merged
+        (``MultiDeviceEngine.search_stream``); on a single engine a worker thread runs the next ``search_many`` (the ctypes
+        call holds no GIL) while the caller consumes the current one.  The namespace must not be mutated meanwhile."""
+        ns = self._ns.get(namespace)
+        active = 0 if ns is None else ns.total - ns.deleted
+        if ns is None or active <= 0 or top_k <= 0:
+            for q in batches:
+                yield BatchHits.empty(self._coerce_queries(q).shape[0])
+            return
+        k = min(int(top_k), active, self._MAX_TOP_K)
+        stream = getattr(ns.engine, "search_stream", None)
+        if stream is not None:
+            ok = []  # per batch: the query count if it could not be scanned (wrong dimensionality), else None
+
+            def feed():
+                for q in batches:
+                    q = self._coerce_queries(q)
+                    if q.shape[1] != ns.dim or q.shape[0] == 0:
+                        ok.append(q.shape[0])
+                        continue
+                    ok.append(None)
+                    yield q
+
+            results = stream(feed(), k)
+            done = 0
+            for labels, dist, counts, _ in results:
+                while done < len(ok) and ok[done] is not None:  # batches skipped before this one
+                    yield BatchHits.empty(ok[done])
+                    done += 1
+                done += 1
+                yield BatchHits(labels, self._scores(dist, metric), counts, ns.ids)
+            while done < len(ok):
+                if ok[done] is not None:
+                    yield BatchHits.empty(ok[done])
+                done += 1
+            return
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pending = None
+            for q in batches:
+                nxt = pool.submit(self.search_many, q, top_k, namespace, metric)
+                if pending is not None:
+                    yield pending.result()
+                pending = nxt
+            if pending is not None:
+                yield pending.result()
+
     def range_search(self, query: VectorDTO, radius: float, namespace: str, metric: str,
                      max_results: int = 1024) -> List[SearchResult]:
         values = np.asarray(query.values, dtype=np.float32)

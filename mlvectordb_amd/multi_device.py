@@ -15,6 +15,7 @@ algorithm, for ``torch.distributed`` launches, is sharded.py / bench.py.)
 * ``search`` runs every shard's scan concurrently -- one host thread per shard; the ctypes calls hold no GIL and each
   blocks only on its own device's stream -- and merges the per-shard ``[nq, k]`` candidates by (fp64 distance, global
   label) (``sharded.merge_topk``), the same order a single index ranks by, so ids equal a one-index search;
+  ``search_stream`` pipelines consecutive query waves: wave i+1 is scanning while wave i is merged (round 3);
 * no collective: the only exchange is the ``G x nq x k x 20 B`` of candidates that come back over PCIe anyway.
 """
 from __future__ import annotations
@@ -38,7 +39,10 @@ class MultiDeviceEngine:
         make = shard_factory or (lambda dev: HipScanEngine(dim, space, device=dev, strategy=strategy,
                                                            capacity_hint=capacity_hint))
         self.shards: List[ScanEngine] = [make(dev) for dev in self.devices]
-        self._pool = ThreadPoolExecutor(max_workers=len(self.shards), thread_name_prefix="mlvdb-shard")
+        # one host thread PER SHARD: calls on a shard run in submission order, one at a time (a handle serves one
+        # stream at a time), so the scans of the next query wave can be queued while this wave's are still running
+        self._pools = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"mlvdb-shard{i}") for i in range(len(self.shards))]
+        self._merge_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mlvdb-merge")
         g = len(self.shards)
         self._l2g: List[np.ndarray] = [np.zeros(0, dtype=np.int64) for _ in range(g)]  # local -> global, ascending
         self._g2s = np.zeros(0, dtype=np.int16)   # global -> shard
@@ -49,8 +53,11 @@ class MultiDeviceEngine:
     # ------------------------------------------------------------------ helpers
     def _each(self, fn, args_per_shard):
         """Run ``fn(shard, *args)`` for every shard whose args are not None, concurrently; results by shard index."""
-        futures = [None if a is None else self._pool.submit(fn, s, *a) for s, a in zip(self.shards, args_per_shard)]
-        return [None if f is None else f.result() for f in futures]
+        return [None if f is None else f.result() for f in self._submit(fn, args_per_shard)]
+
+    def _submit(self, fn, args_per_shard):
+        return [None if a is None else pool.submit(fn, s, *a)
+                for pool, s, a in zip(self._pools, self.shards, args_per_shard)]
 
     def _split(self, n: int) -> List[int]:
         """Rows of an ``n``-row batch per shard: contiguous pieces that level the shards' fill."""
@@ -170,8 +177,8 @@ class MultiDeviceEngine:
             raise RuntimeError("row range out of bounds")
         return self.get_rows_at(np.arange(first, first + n, dtype=np.int64))
 
-    def search64(self, queries: np.ndarray, k: int, mask: Optional[np.ndarray] = None):
-        """(labels int64 [nq, k] global, dist float32, counts int32, dist64 float64): the merged answer."""
+    def _submit_scans(self, queries: np.ndarray, k: int, mask: Optional[np.ndarray]):
+        """Queue one wave's scan on every non-empty shard; returns the futures by shard index (None: empty shard)."""
         queries = np.ascontiguousarray(queries, dtype=np.float32)
         if queries.ndim != 2 or queries.shape[1] != self.dim:
             raise RuntimeError(f"Wrong dimensionality of the vectors: got {queries.shape}, index dim {self.dim}")
@@ -185,19 +192,45 @@ class MultiDeviceEngine:
                 args.append(None)
             else:
                 args.append((queries, k, None if mask is None else np.ascontiguousarray(mask[self._l2g[s]])))
-        res = self._each(lambda sh, q, kk, m: sh.search64(q, kk, m), args)
+        return self._submit(lambda sh, q, kk, m: sh.search64(q, kk, m), args), queries.shape[0]
+
+    def _merge(self, futures, nq: int, k: int):
+        """Wait for one wave's shard scans and merge them by (fp64 distance, global label)."""
         labs, d64s = [], []
-        for s, r in enumerate(res):
-            if r is None:
+        for s, f in enumerate(futures):
+            if f is None:
                 continue
+            r = f.result()
             lab = r[0]
             labs.append(np.where(lab >= 0, self._l2g[s][np.maximum(lab, 0)], -1))
             d64s.append(r[3])
-        nq = queries.shape[0]
         if not labs:
             return (np.full((nq, k), -1, dtype=np.int64), np.full((nq, k), np.inf, dtype=np.float32),
                     np.zeros(nq, dtype=np.int32), np.full((nq, k), np.inf))
         return merge_topk(labs, d64s, k, return_dist64=True)
+
+    def search64(self, queries: np.ndarray, k: int, mask: Optional[np.ndarray] = None):
+        """(labels int64 [nq, k] global, dist float32, counts int32, dist64 float64): the merged answer."""
+        futures, nq = self._submit_scans(queries, k, mask)
+        return self._merge(futures, nq, k)
+
+    def search_stream(self, batches, k: int, depth: int = 2):
+        """``search64`` over an iterable of query batches, pipelined ("overlaps the next query wave"): the shard
+        scans of wave i+1 are queued on the shards' threads BEFORE wave i's candidates are merged, and the merge runs on
+        a thread of its own, so a wave costs max(scan, merge) instead of their sum and the GPUs never wait for the host
+        merge (3 ms in NumPy for 8 x 1024 x 10 candidates against an ~8 ms wave).  Yields the merged
+        ``(labels, dist, counts, dist64)`` per batch, in order; at most ``depth`` waves are in flight.  The index must not
+        be mutated while a stream is being consumed."""
+        from collections import deque
+
+        inflight = deque()
+        for q in batches:
+            futures, nq = self._submit_scans(q, k, None)
+            inflight.append(self._merge_pool.submit(self._merge, futures, nq, k))
+            while len(inflight) >= max(1, depth):
+                yield inflight.popleft().result()
+        while inflight:
+            yield inflight.popleft().result()
 
     def search(self, queries: np.ndarray, k: int, mask: Optional[np.ndarray] = None):
         lab, dist, cnt, _ = self.search64(queries, k, mask)
@@ -260,9 +293,10 @@ class MultiDeviceEngine:
         return [sh.last_stats() for sh in self.shards]
 
     def close(self) -> None:
+        for pool in self._pools + [self._merge_pool]:
+            pool.shutdown(wait=True)  # nothing may still be running on a shard that is about to be destroyed
         for sh in self.shards:
             sh.close()
-        self._pool.shutdown(wait=False)
         self._l2g = [np.zeros(0, dtype=np.int64) for _ in self.shards]
         self._g2s, self._g2l = np.zeros(0, dtype=np.int16), np.zeros(0, dtype=np.int64)
         self._total = self._deleted = 0

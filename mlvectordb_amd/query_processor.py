@@ -120,6 +120,11 @@ class QueryProcessor:
         """Additive: ``find_similar_many`` over an iterable of query batches, pipelined -- while the GPU scans batch
         i+1 (a worker thread inside the ctypes call, which holds no GIL) this thread enriches batch i.  Yields one
         ``List[List[dict]]`` per batch, in order."""
+        stream = getattr(self._index, "search_stream", None)
+        if stream is not None:  # this package's Index: one engine -> a prefetching worker; row shards -> scan / merge pipeline
+            for hits in stream(batches, top_k, namespace, metric):
+                yield self._enrich_many(hits, namespace)
+            return
         from concurrent.futures import ThreadPoolExecutor
 
         with ThreadPoolExecutor(max_workers=1) as pool:

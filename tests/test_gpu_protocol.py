@@ -72,6 +72,27 @@ def test_find_similar_many_object_storage_and_deletes_on_hip():
     hip._index.close()
 
 
+def test_search_stream_over_four_logical_shards_equals_search_many_and_oracle():
+    """MultiDeviceEngine.search_stream on devices=[0, 0, 0, 0] -- shard scans of wave i+1 queued before
+    wave i is merged -- returns, wave for wave, what search_many returns and what the oracle says; QueryProcessor.
+    find_similar_stream rides on it."""
+    n, d, k = 60_000, 256, 10
+    rows, _ = make_case(211, n, d, 1, dup=True)
+    many = Index(space="cosine", devices=[0, 0, 0, 0], strategy="filter")
+    many.add_arrays(rows, "ns")
+    rng = np.random.default_rng(5)
+    waves = [rng.standard_normal((nq, d)).astype(np.float32) for nq in (40, 3, 256, 17)]
+    try:
+        streamed = list(many.search_stream(iter(waves), k, "ns", "cosine"))
+        for q, got in zip(waves, streamed):
+            want = exact_scan.knn(q, rows, k, "cosine")
+            assert np.array_equal(got.labels, want[0]) and np.abs((1 - got.scores) - want[1]).max() <= 1e-5
+            assert got == many.search_many(q, k, "ns", "cosine")
+        assert all(st["strategy_used"] == 2 for st in many._ns["ns"].engine.last_stats())
+    finally:
+        many.close()
+
+
 @pytest.mark.parametrize("space,n,d,nq", [("cosine", 50000, 256, 64), ("l2", 9000, 64, 20), ("ip", 40000, 128, 5)])
 def test_multi_device_index_as_four_logical_shards_on_device_0(space, n, d, nq):
     rows, qs = make_case(103, n, d, nq, dup=True)       # rows 1, n//2, n-1 identical: they land in different shards

@@ -287,3 +287,55 @@ def test_multi_device_save_load_and_query_processor(tmp_path):
     qp.upsert_arrays(rows, "ns", keep_host_copy=False)    # values come back from the shards
     hits = qp.find_similar_many(rows[:3], top_k=2, namespace="ns")
     assert all(np.array_equal(h[0]["values"], rows[j]) and abs(h[0]["score"] - 1.0) < 1e-6 for j, h in enumerate(hits))
+
+
+@pytest.mark.parametrize("space", ["l2", "cosine"])
+def test_search_stream_pipelines_shard_scans_and_merges_without_changing_results(space):
+    """Index.search_stream (round 3, SURVEY 8e "overlaps the next query wave"): on a row-sharded namespace the shard scans of
+    wave i+1 are queued before wave i is merged; results, wave for wave, are those of search_many -- also for batches that
+    cannot be scanned (wrong dimensionality, empty) in the middle of the stream, and on a single engine."""
+    import threading
+
+    many, one, rows, ids, rng = _sharded_and_single(space)
+    metric = "cosine" if space == "cosine" else "l2"
+    d = rows.shape[1]
+    batches = [rng.standard_normal((n, d)).astype(np.float32) for n in (5, 1, 12, 7, 3)]
+    batches.insert(2, np.zeros((4, d + 1), np.float32))   # wrong dimensionality: [] per query, the stream goes on
+    batches.insert(4, np.zeros((0, d), np.float32))        # an empty batch
+    want = [one.search_many(q, 6, "ns", metric) for q in batches]
+    for index in (many, one):
+        got = list(index.search_stream(iter(batches), 6, "ns", metric))
+        assert len(got) == len(batches)
+        for g, w, q in zip(got, want, batches):
+            assert len(g) == q.shape[0] and g == w
+    assert [len(h) for h in many.search_stream([batches[0]], 6, "nope", metric)] == [5]   # unknown namespace: empty hit lists
+    # the pipeline really runs ahead: while the consumer holds wave 0, wave 1's scans have been issued
+    eng = many._ns["ns"].engine
+    issued, real = [], eng.shards[0].search64
+
+    def spy(q, k, m=None):
+        issued.append(q.shape[0])
+        return real(q, k, m)
+
+    eng.shards[0].search64 = spy
+    stream = many.search_stream(iter([batches[0], batches[1], batches[3]]), 6, "ns", metric)
+    first = next(stream)
+    deadline = threading.Event()
+    for _ in range(200):  # (the shard's thread runs the queued call on its own)
+        if len(issued) >= 2:
+            break
+        deadline.wait(0.01)
+    assert first == want[0] and len(issued) >= 2, issued
+    assert [h == w for h, w in zip(stream, (want[1], want[3]))] == [True, True]
+    eng.shards[0].search64 = real
+    # QueryProcessor.find_similar_stream rides on it
+    from mlvectordb_amd import ArrayStorage, QueryProcessor
+    from oracle.engine import OracleScanEngine
+
+    qp = QueryProcessor(ArrayStorage(), Index(space=space, devices=[0, 0, 0], engine_factory=OracleScanEngine))
+    qp.upsert_arrays(rows, "ns")
+    a = list(qp.find_similar_stream(iter(batches[:2]), 4, "ns", metric))
+    b = [qp.find_similar_many(q, 4, "ns", metric) for q in batches[:2]]
+    assert [[h["id"] for h in hs] for wave in a for hs in wave] == [[h["id"] for h in hs] for wave in b for hs in wave]
+    many.close()
+    one.close()
