@@ -41,3 +41,43 @@ class BlasScanIndex:
         order = np.lexsort((part, pd), axis=1) if False else np.argsort(pd, axis=1, kind="stable")
         labels = np.take_along_axis(part, order, axis=1).astype(np.int64)
         return labels, np.take_along_axis(pd, order, axis=1).astype(np.float32)
+
+
+class BlasScanEngine:
+    """``BlasScanIndex`` behind the engine interface of ``mlvectordb_amd.Index`` (append / search / get_rows_at / counts),
+    so that the CPU baseline is timed through the same ``QueryProcessor.find_similar_many -> Index.search_many`` surface as
+    the GPU path -- UUID tables, score post-processing and enrichment included.  No tombstones, masks or ranges:
+    a baseline, not an engine."""
+
+    def __init__(self, dim: int, space: str) -> None:
+        self.dim, self.space = int(dim), space
+        self._chunks, self._index, self._n = [], None, 0
+
+    def append(self, rows: np.ndarray) -> int:
+        first = self._n
+        self._chunks.append(np.ascontiguousarray(rows, dtype=np.float32))
+        self._n += rows.shape[0]
+        self._index = None
+        return first
+
+    def _built(self) -> BlasScanIndex:
+        if self._index is None:
+            self._rows = self._chunks[0] if len(self._chunks) == 1 else np.concatenate(self._chunks)
+            self._chunks = [self._rows]
+            self._index = BlasScanIndex(self._rows, self.space)
+        return self._index
+
+    def counts(self):
+        return self._n, 0
+
+    def search(self, queries: np.ndarray, k: int, mask=None):
+        assert mask is None
+        labels, dist = self._built().search(queries, k)
+        return labels, dist, np.full(labels.shape[0], labels.shape[1], dtype=np.int32)
+
+    def get_rows_at(self, labels: np.ndarray) -> np.ndarray:
+        self._built()
+        return self._rows[np.asarray(labels, dtype=np.int64).ravel()]
+
+    def close(self) -> None:
+        self._chunks, self._index, self._n = [], None, 0

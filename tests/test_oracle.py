@@ -72,3 +72,23 @@ def test_oracle_reproduces_committed_golden_vectors(name):
     assert np.array_equal(labels, g["labels"])
     assert np.array_equal(counts, g["counts"])
     assert np.array_equal(dist, g["dist"])
+
+
+def test_blas_baseline_engine_through_the_protocol_surface_agrees_with_the_oracle():
+    """bench.py's cpu_baseline leg: QueryProcessor.find_similar_many -> Index.search_many -> BlasScanEngine (fp32 sgemm).
+    A speed baseline, ranked on fp32 scores -- on well-separated data its ids are the oracle's."""
+    import uuid
+
+    from mlvectordb_amd import ArrayStorage, Index, QueryProcessor
+    from oracle.blas_scan import BlasScanEngine
+
+    rng = np.random.default_rng(0)
+    rows = rng.standard_normal((5000, 48), dtype=np.float32)
+    q = rng.standard_normal((9, 48), dtype=np.float32)
+    for space in ("cosine", "l2"):
+        qp = QueryProcessor(ArrayStorage(), Index(space=space, engine_factory=BlasScanEngine))
+        ids = qp.upsert_arrays(rows, "cpu")
+        hits = qp.find_similar_many(q, top_k=5, namespace="cpu", metric=space)
+        want = exact_scan.knn(q, rows, 5, space)
+        assert all([h["id"] for h in hits[i]] == [uuid.UUID(bytes=ids[l].tobytes()) for l in want[0][i]] for i in range(9))
+        assert all(np.array_equal(h["values"], rows[l]) for h, l in zip(hits[3], want[0][3]))
