@@ -553,6 +553,9 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
         // int8 bounds are loose: thresholds from exact scores of the k best bounds; the same kernel prunes the lists
         // (the update kernel's bound-derived threshold could only be lower) unless the query does not fit beside them
         const bool fuse = fa.X8 && filter_refine_can_fuse(fa);
+        // (Tried in round 3 for batches of <= 8 queries: no refine after the LAST round -- the rescoring takes the unpruned
+        // lists.  Slower: 0.257 vs 0.226 ms at batch 1 on 1M x 768, the ranking kernel pays more for the ~800-entry list
+        // than the refine's launch costs; profiles/r03/small_batch_last_refine_1m.txt.)
         if (fa.X8) HIP_TRY(h, launch_filter_refine_thr(fa, k, -1, fuse, s));
 #ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: where the refine kernel's time goes (its blocks stamp their phases)
         if (fa.X8 && fa.wgbuf && getenv("MLVDB_DEBUG_REFINE")) {

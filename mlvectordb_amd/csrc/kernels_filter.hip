@@ -1679,17 +1679,9 @@ __global__ __launch_bounds__(256) void filter_prep8_kernel(const FilterArgs a) {
 //   keb     the bf16 term (filter_prep_kernel's ke): what the bf16 seeding pass adds to its bounds
 //   ke      covers both kinds of entry (the update kernel's lower bounds u - 2 eps): the larger of the two, with the
 //           int8 row term at its index-wide maximum
-__global__ __launch_bounds__(256) void filter_prep8_fin_kernel(const FilterArgs a, const int reset) {
-    const int q = threadIdx.x;
-    const float sqmin = __uint_as_float(a.sqmin[0]);
-    const double eqmax = (double)__uint_as_float(a.sqmin[1]);
-    if (reset) {  // fused prep: nobody re-initialises the two scalars before the next pass's atomics -- this kernel does, once
-        __syncthreads();  // every thread of this (only) block has read them
-        if (q == 0) {
-            a.sqmin[0] = 0x7f7f7f7fu;
-            a.sqmin[1] = 0u;
-        }
-    }
+// (device function: also called by filter_prep_fused_kernel for one-query passes; needs a.ke8[q] = eq8 and a.ke[q] = the bf16 term)
+__device__ __forceinline__ void prep8_fin_query(const FilterArgs& a, const int q, const float sqmin, const float eqmax_f) {
+    const double eqmax = (double)eqmax_f;
     const double eq8 = (double)a.ke8[q];
     const double ratio = a.space == kSpaceCosine && q < a.nq ? (double)a.sq8[q] / (double)sqmin * 1.000001 : 1.0;
     const double rnd = 4.0 * 5.9604644775390625e-08;  // float(I) * rp8 (+ b K) * sq8: roundings of a value <= ~1
@@ -1701,6 +1693,20 @@ __global__ __launch_bounds__(256) void filter_prep8_fin_kernel(const FilterArgs 
     a.ke[q] = float_above(big);
     a.ke8[q] = float_above((eq8 + rnd) * 1.000001 + slack);
     if (q == 0) a.ke8[kFilterQueries] = float_above((1.0 + eqmax) / (double)sqmin * 1.000001);
+}
+
+__global__ __launch_bounds__(256) void filter_prep8_fin_kernel(const FilterArgs a, const int reset) {
+    const int q = threadIdx.x;
+    const float sqmin = __uint_as_float(a.sqmin[0]);
+    const float eqmax = __uint_as_float(a.sqmin[1]);
+    if (reset) {  // fused prep: nobody re-initialises the two scalars before the next pass's atomics -- this kernel does, once
+        __syncthreads();  // every thread of this (only) block has read them
+        if (q == 0) {
+            a.sqmin[0] = 0x7f7f7f7fu;
+            a.sqmin[1] = 0u;
+        }
+    }
+    prep8_fin_query(a, q, sqmin, eqmax);
 }
 
 // ------------------------------------------------------------------ one launch for everything a pass needs of its queries
@@ -1812,11 +1818,17 @@ __global__ __launch_bounds__(256) void filter_prep_fused_kernel(const FilterArgs
         const double eq8 = __builtin_sqrt(dred[0] + dred[1] + dred[2] + dred[3]) * 1.000001 + 1e-12;
         a.sq8[q] = sq;
         a.ke8[q] = real ? float_above(eq8) : 0.f;  // finished by filter_prep8_fin_kernel
-        if (real) {
+        if (real && a.nq > 1) {
             atomicMin(a.sqmin, __float_as_uint(sq));
             atomicMax(a.sqmin + 1, __float_as_uint(float_above(eq8)));
         }
+        if (real && a.nq == 1) {
+            // a one-query pass (BASELINE configs[1]): the smallest scale / largest error "of the pass" are this query's own,
+            // so the fin kernel's arithmetic for it runs here and its launch is saved (prep8_fin_query: one formula, two callers)
+            prep8_fin_query(a, 0, sq, float_above(eq8));
+        }
     }
+    if (want_i8 && a.nq == 1 && q > 0 && threadIdx.x == 0) prep8_fin_query(a, q, 1.0f, 0.0f);  // padded slots (never admitted)
 }
 
 hipError_t launch_filter_prep_fused(const FilterArgs& a, const float* queries, int32_t dim, float* Qpad, double* qaux, float* qerr,
@@ -1824,7 +1836,7 @@ hipError_t launch_filter_prep_fused(const FilterArgs& a, const float* queries, i
     if (a.ld / kFilterChunkK <= 0) return hipErrorInvalidValue;
     const int want_i8 = a.X8 != nullptr;
     filter_prep_fused_kernel<<<kFilterQueries, 256, 0, s>>>(a, queries, dim, Qpad, qaux, qerr, want_i8);
-    if (want_i8) filter_prep8_fin_kernel<<<1, kFilterQueries, 0, s>>>(a, 1);
+    if (want_i8 && a.nq > 1) filter_prep8_fin_kernel<<<1, kFilterQueries, 0, s>>>(a, 1);  // (one query: done inside the kernel above)
     return hipGetLastError();
 }
 
