@@ -2345,6 +2345,7 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                     if (var == 233) return launch_scan_asm<SPACE, 4, 8, true, 233, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 235) return launch_scan_asm<SPACE, 4, 8, true, 235, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 236) return launch_scan_asm<SPACE, 4, 8, true, 236, true, 2, true>(a, row_begin, row_end, s, info);
+                    if (var == 237) return launch_scan_asm<SPACE, 4, 8, true, 237, true, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 217) return launch_scan_asm<SPACE, 4, 4, true, 217, false, 2, true>(a, row_begin, row_end, s, info);
                     if (var == 218) return launch_scan_asm<SPACE, 4, 4, true, 218, true, 2, true>(a, row_begin, row_end, s, info);
                 }

@@ -338,7 +338,8 @@ SCAN_VARIANTS = [
     {"MLVDB_SCAN_VAR": "231"},                       # (cosine, int8) four Q buffers, B-fragment reads across the chunk barrier
     {"MLVDB_SCAN_VAR": "233"},                       # ... with the early-out hit stubs
     {"MLVDB_SCAN_VAR": "235"},                       # (cosine, int8) straight-line append routine
-    {"MLVDB_SCAN_VAR": "236"},                       # ... with the early-out hit stubs
+    {"MLVDB_SCAN_VAR": "236"},                       # ... with the early-out hit stubs (= the default body since round 3)
+    {"MLVDB_SCAN_VAR": "237"},                       # round 2's default body
     {"MLVDB_SCAN_XCD": "1"},                         # every XCD scans one contiguous eighth of the tile range
     {"MLVDB_SHADOW": "bf16"},                        # both shadows kept (round 2's default): int8 scans, bf16 seeding / narrow passes off
     {"MLVDB_SEED_I8": "0"},                          # int8-only index, seeding pass by the compiler kernel on the fp32 rows

@@ -1107,7 +1107,8 @@ def inc_name(space, nw, r, nt, qd, prio, mt, dma, stag=False):
 def default_i8_body(space):
     """The int8 body the library runs by default for `space` (ArchVGPR accumulators, wave priorities): scan_asm_<space>_i8_va.inc."""
     DBG.clear()
-    return generate(space, 4, 4, 8, True, True, 2, True, False, True, True)
+    # round 3: straight-line append routine (all spaces) and early-out hit stubs (cosine): gen_slow_fast / gen_hit_stubs
+    return generate(space, 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True)
 
 
 def main():
@@ -1115,7 +1116,7 @@ def main():
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_diag223.inc", "scan_asm_diag224.inc", "scan_asm_diag225.inc", "scan_asm_diag226.inc", "scan_asm_diag227.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc", "scan_asm_cosine_i8_va_r6b3.inc", "scan_asm_cosine_i8_va_q3d.inc", "scan_asm_cosine_i8_mt4.inc", "scan_asm_cosine_i8_va_qa.inc", "scan_asm_cosine_i8_va_eo.inc", "scan_asm_cosine_i8_va_qa_eo.inc", "scan_asm_cosine_i8_va_fs.inc", "scan_asm_cosine_i8_va_eo_fs.inc", "scan_asm_diag234.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_diag223.inc", "scan_asm_diag224.inc", "scan_asm_diag225.inc", "scan_asm_diag226.inc", "scan_asm_diag227.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc", "scan_asm_cosine_i8_va_r6b3.inc", "scan_asm_cosine_i8_va_q3d.inc", "scan_asm_cosine_i8_mt4.inc", "scan_asm_cosine_i8_va_qa.inc", "scan_asm_cosine_i8_va_eo.inc", "scan_asm_cosine_i8_va_qa_eo.inc", "scan_asm_cosine_i8_va_fs.inc", "scan_asm_cosine_i8_va_eo_fs.inc", "scan_asm_cosine_i8_va_r2.inc", "scan_asm_diag234.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
@@ -1174,10 +1175,12 @@ def main():
     # straight-line append routine (235), with the early-out stubs (236)
     (Path(args.outdir) / "scan_asm_cosine_i8_va_fs.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, fs=True))
     (Path(args.outdir) / "scan_asm_cosine_i8_va_eo_fs.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True))
+    # 237: round 2's default body (append routine with eight skipped row blocks, stubs without the early out), for A/B
+    (Path(args.outdir) / "scan_asm_cosine_i8_va_r2.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
     # 234: the default body; the C++ wrapper stamps its phases around it (correct results; DIAG builds only).  Stamps INSIDE
     # the statement were tried: two more live SGPR outputs do not fit (the "s" inputs then come out as VGPRs and the
     # assembler refuses them), two more VGPR outputs make hipcc's register allocator hang (> 40 minutes, killed)
-    (Path(args.outdir) / "scan_asm_diag234.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
+    (Path(args.outdir) / "scan_asm_diag234.inc").write_text(default_i8_body("cosine"))
     DBG.update({"noadm"})   # 213: ArchVGPR accumulators, no admission test at all
     (Path(args.outdir) / "scan_asm_diag213.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
     DBG.clear()
@@ -1218,7 +1221,7 @@ def main():
     disp.append('#include "scan_asm_cosine_i8_mt4.inc"')
     disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 219 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
     disp.append('#include "scan_asm_cosine_i8_va_q4.inc"')
-    for code, nm in ((231, "qa"), (232, "eo"), (233, "qa_eo"), (235, "fs"), (236, "eo_fs")):
+    for code, nm in ((231, "qa"), (232, "eo"), (233, "qa_eo"), (235, "fs"), (236, "eo_fs"), (237, "r2")):
         disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
         disp.append(f'#include "scan_asm_cosine_i8_va_{nm}.inc"')
     disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
