@@ -481,9 +481,11 @@ def main() -> None:
     eng.set_profiling(True)  # HIP events on the launch stream around every scan-kernel launch
     barrier()
     t_start = time.perf_counter()
+    host_enqueue_s = None
     if world == 1:
         for _ in range(args.steps):
             step()  # waves are enqueued back to back, the host never waits inside the timed region
+        host_enqueue_s = time.perf_counter() - t_start  # how long the host took to enqueue the K waves (it must stay ahead of the GPU)
     else:
         last = None
         enqueue(0)
@@ -544,14 +546,14 @@ def main() -> None:
         # measured HBM traffic: rocprofv3 PMC passes of this same command (separate runs; counters cannot be read from
         # inside the process).  The file records the hash of the kernel sources it was measured on: stale = ignored.
         traffic, tsrc = None, None
-        tfile = ROOT / "profiles" / "r02" / ("pmc_traffic_i8.json" if i8 else "pmc_traffic.json")
+        tfile = ROOT / "profiles" / "r03" / ("pmc_traffic_i8.json" if i8 else "pmc_traffic.json")
         if filt and n_local == 10_000_000 and d == 768 and tfile.exists():
             tj = json.loads(tfile.read_text())
             if tj.get("kernel_source_sha16") == kernel_source_sha16():
                 traffic = tj["traffic_bytes_per_launch_avg"]
-                tsrc = f"profiles/r02/{tfile.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same kernel sources)"
+                tsrc = f"profiles/r03/{tfile.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same kernel sources)"
             else:
-                tsrc = f"profiles/r02/{tfile.name} is stale (kernel sources changed since it was measured): not reported"
+                tsrc = f"profiles/r03/{tfile.name} is stale (kernel sources changed since it was measured): not reported"
         if bound == "mfma":
             achieved, peak, unit = flops / scan_s / 1e12, mfma_peak / 1e12, "TFLOP/s"
         else:
@@ -596,6 +598,7 @@ def main() -> None:
                    "strategy": {1: "exact", 2: "filter"}.get(stats0["strategy_used"], "?"),
                    "sharding": f"row-wise over {world} ranks, host merge of per-shard top-k"},
         "whole_corpus_qps": round(batch * args.steps / elapsed, 1),
+        "host_enqueue_ms_per_wave": round(host_enqueue_s / args.steps * 1e3, 3) if host_enqueue_s is not None else None,
         "p50_ms_per_wave": round(float(np.median(per_step)) * 1e3, 3),
         "p50_ms_per_wave_host_io": round(float(np.median(per_step_io)) * 1e3, 3) if per_step_io else None,
         "roofline": roofline,

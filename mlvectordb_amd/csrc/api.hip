@@ -470,8 +470,12 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
     // seed: a dense pass of the filter kernel over the first rows puts every bound into the lists,
     // the update kernel turns them into thresholds; the remaining rows follow in rounds of growing
     // size so that thresholds tighten early
-    const int64_t n_seed = std::min<int64_t>(h->total, kSeedRows);
-    int64_t first_row = kSeedRows;
+    // rows of the dense seeding pass: a multiple of kFilterTile (the first scan round starts there), at most kSeedRows
+    // (MLVDB_SEED_ROWS, in units of kFilterTile = 768 rows: tuning, read per call)
+    int64_t seed_rows = kSeedRows;
+    if (const char* v = getenv("MLVDB_SEED_ROWS")) seed_rows = std::min<int64_t>(kSeedRows, std::max<int64_t>(1, atoll(v)) * kFilterTile);
+    const int64_t n_seed = std::min<int64_t>(h->total, seed_rows);
+    int64_t first_row = seed_rows;
     {
         // Tried in round 2 (MLVDB_SEED_EXACT=1): thresholds seeded from the EXACT k-th best score among the first
         // kSeedRows rows (exact fp64 scan of that prefix + merge + one tiny kernel) instead of the dense bf16 pass that

@@ -39,10 +39,10 @@ def test_final_bench_record_has_the_contract_keys_and_consistent_values():
 def test_pmc_traffic_file_matches_the_kernel_sources_in_the_tree():
     import pytest
 
-    pmc = json.loads((ROOT / "profiles" / "r02" / "pmc_traffic_i8.json").read_text())
+    pmc = json.loads((ROOT / "profiles" / "r03" / "pmc_traffic_i8.json").read_text())
     if pmc["kernel_source_sha16"] != bench.kernel_source_sha16():
         # not a failure of the code under test: bench.py then reports "traffic": null.  Shown as xfail so that it is seen.
-        pytest.xfail("the scan kernel sources changed after profiles/r02/pmc_traffic_i8.json was measured: re-run the two "
+        pytest.xfail("the scan kernel sources changed after profiles/r03/pmc_traffic_i8.json was measured: re-run the two "
                      "rocprofv3 --pmc passes and tools/pmc_traffic.py")
     assert pmc["traffic_bytes_per_launch_avg"] > 0
 

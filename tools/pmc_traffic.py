@@ -9,17 +9,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 
 
-def kernel_source_sha16():
-    """Same hash as bench.py: ties the measurement to the kernel sources it was taken on (a stale file is ignored)."""
-    h = hashlib.sha256()
-    csrc = ROOT / "mlvectordb_amd" / "csrc"
-    for rel in ("scan_asm_cosine_i8_va.inc", "scan_asm_l2_i8_va.inc", "scan_asm_ip_i8_va.inc", "scan_common.h"):
-        h.update((csrc / rel).read_bytes())
-    src = (csrc / "kernels_filter.hip").read_text()
-    a = src.index("void filter_scan_asm_kernel(")
-    b = src.index("// ------------------------------------------------------------------ threshold update + compaction")
-    h.update(src[a:b].encode())
-    return h.hexdigest()[:16]
+sys.path.insert(0, str(ROOT))
+from bench import kernel_source_sha16  # noqa: E402  (one definition: ties the measurement to the kernel sources it was taken on)
 
 
 def launches(path, counter):
