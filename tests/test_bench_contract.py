@@ -10,7 +10,7 @@ ROOT = Path(__file__).resolve().parents[1]
 
 
 def _line(name):
-    text = (ROOT / "profiles" / "r02" / name).read_text().strip().splitlines()[-1]
+    text = (ROOT / "profiles" / "r03" / name).read_text().strip().splitlines()[-1]
     return json.loads(text)
 
 
