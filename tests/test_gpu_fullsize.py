@@ -118,6 +118,13 @@ def test_config3_10m_cosine_all_256_queries_equal_the_exact_scan(engine_10m_cosi
     assert (cf == K).all() and (lf >= 0).all() and (lf < N10).all()
     assert (np.diff(df, axis=1) >= 0).all()
     assert lf[:len(PLANT), 0].tolist() == PLANT
+    # BASELINE configs[4]'s per-GPU shape: a 1024-query wave = four 256-query passes over the 10M-row shard (what every rank of
+    # the 8-GPU job runs; the cross-shard merge is covered by tests/test_sharded.py and bench.py's sharded gate)
+    big = np.concatenate([qs, np.random.default_rng(1024).standard_normal((1024 - qs.shape[0], qs.shape[1])).astype(np.float32)])
+    got4, want4, st4 = _both_strategies(eng, big, K)
+    assert st4["strategy_used"] == 2 and st4["scan_launches"] == 12 and st4["fallback_queries"] == 0, st4
+    _assert_identical(got4, want4, "10M/cosine/batch1024")
+    assert np.array_equal(got4[0][:qs.shape[0]], lf)  # a query's answer does not depend on the pass it rides in
     # SURVEY 8d's secondary run: 10 % random tombstones
     dead = np.nonzero(np.random.default_rng(99).random(N10) < 0.1)[0].astype(np.int64)
     assert eng.tombstone(dead) == dead.size
@@ -133,7 +140,7 @@ def test_config3_10m_cosine_all_256_queries_equal_the_exact_scan(engine_10m_cosi
 
 @pytest.fixture(scope="module")
 def engine_10m_l2(engine_10m_cosine):
-    engine_10m_cosine.close()  # 54 GB each: one at a time
+    engine_10m_cosine.close()  # 38 GB each (54 with MLVDB_SHADOW=bf16): one at a time
     eng = _load_10m("l2")
     yield eng
     eng.close()
