@@ -414,6 +414,17 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
 int finish_filter_pass(mlvdb_index* h, hipStream_t s, FilterArgs& fa, int32_t q0, int32_t nq, int32_t k, int64_t* out_labels,
                        float* out_dist, int32_t* out_counts, double* out_d64, bool defer_fallback);
 
+// Everything a filter pass needs of its queries, in one fused launch (+ the one-block fin for int8 passes of several queries).
+int prep_pass(mlvdb_index* h, hipStream_t s, const FilterArgs& fa, const float* queries_raw, float* Qpad, double* qaux, float* qerr) {
+    if (h->sqmin_fresh) {  // what the fused prep's atomicMin / atomicMax start from; afterwards every fin kernel restores it
+        HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fa.sqmin), 0x7f7f7f7f, 1, s));
+        HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fa.sqmin + 1), 0, 1, s));
+        h->sqmin_fresh = false;
+    }
+    HIP_TRY(h, launch_filter_prep_fused(fa, queries_raw, h->dim, Qpad, qaux, qerr, s));
+    return MLVDB_OK;
+}
+
 // `queries_raw`: the pass's queries [nq][dim] as the caller gave them (device); this pass prepares them itself (padded copy,
 // norms, images: one fused launch) into Qpad / qaux / qerr at q0.
 int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, float* Qpad, double* qaux, int32_t q0, int32_t nq,
@@ -424,13 +435,8 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
     if (rc) return rc;
     rc = attach_i8(h, s, fa);
     if (rc) return rc;
-    if (h->sqmin_fresh) {  // what the fused prep's atomicMin / atomicMax start from; afterwards every fin kernel restores it
-        HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fa.sqmin), 0x7f7f7f7f, 1, s));
-        HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fa.sqmin + 1), 0, 1, s));
-        h->sqmin_fresh = false;
-    }
-    HIP_TRY(h, launch_filter_prep_fused(fa, queries_raw + (size_t)q0 * h->dim, h->dim, Qpad + (size_t)q0 * h->ld, qaux + q0,
-                                        h->qerr.as<float>() + q0, s));
+    rc = prep_pass(h, s, fa, queries_raw + (size_t)q0 * h->dim, Qpad + (size_t)q0 * h->ld, qaux + q0, h->qerr.as<float>() + q0);
+    if (rc) return rc;
     h->stats.bound_dtype = fa.X8 ? 2 : 1;
     // ---- tried in round 3 for small batches on small corpora (BASELINE configs[1]: 1M x 768, batch 1), OFF by default
     // (MLVDB_SMALL_BATCH=1): exact k-th best of a prefix of the fp32 rows (fp64 scan) -> ONE int8 scan of everything ->
@@ -1329,9 +1335,10 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
     std::memcpy(h->pin_in.p, queries, (size_t)nq * h->dim * sizeof(float));  // pinned staging: one DMA (search_host)
     HIP_TRY(h, hipMemcpyAsync(h->io_q.p, h->pin_in.p, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(h, h->qerr.ensure((size_t)nq * sizeof(float)));
-    HIP_TRY(h, launch_query_prep(h->io_q.as<float>(), (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
-                                 h->qaux.as<double>(), h->qerr.as<float>(), s));
     const bool filt = use_filter(h, nq);
+    if (!filt)  // (the filter passes prepare their own queries: one fused launch each)
+        HIP_TRY(h, launch_query_prep(h->io_q.as<float>(), (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
+                                     h->qaux.as<double>(), h->qerr.as<float>(), s));
     h->stats.strategy_used = filt ? MLVDB_STRATEGY_FILTER : MLVDB_STRATEGY_EXACT;
     for (int64_t q0 = 0; q0 < nq; q0 += kFilterQueries) {
         const int32_t n = (int32_t)std::min<int64_t>(kFilterQueries, nq - q0);
@@ -1357,8 +1364,13 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
                 if (rc) return rc;
             }
         }
-        HIP_TRY(h, launch_filter_prep(fa, s));  // also clears the candidate counters
-        if (fa.X8) HIP_TRY(h, launch_filter_prep8(fa, s));
+        if (filt) {  // (also clears the candidate counters)
+            rc = prep_pass(h, s, fa, h->io_q.as<float>() + (size_t)q0 * h->dim, h->qpad.as<float>() + (size_t)q0 * h->ld,
+                           h->qaux.as<double>() + q0, h->qerr.as<float>() + q0);
+            if (rc) return rc;
+        } else {
+            HIP_TRY(h, launch_filter_prep(fa, s));  // per-query state only (no image: the exact range scan reads Qpad)
+        }
         h->stats.bound_dtype = fa.X8 ? 2 : (filt ? 1 : 0);
         rc = scan_event(h, s, true);
         if (rc) return rc;

@@ -4,8 +4,9 @@
   oracle itself (32 queries).
 * configs[2] (10M x 768 cosine, batch 256, the headline): every one of the 256 queries, int8 body, three scan
   rounds (the third only exists beyond 1,572,864 rows), ids and fp32 distances equal to the exact fp64 scan
-  (itself pinned against the oracle at small sizes in test_gpu_parity.py and at 1M rows here); planted
-  near-copies; again after tombstoning 10 % of the rows with default_rng(99).
+  (itself pinned against the oracle at small sizes in test_gpu_parity.py and at 1M rows here) AND, for 8 of the queries, to
+  the NumPy fp64 oracle over the whole 10M rows (chunk-wise scan + merge); planted near-copies; a 1024-query (four-pass) wave;
+  again after tombstoning 10 % of the rows with default_rng(99).
 * configs[3] (10M x 768 squared-l2): kNN the same way, and the range query at the mean 10th-neighbour radius
   against the exact range scan for every query, including the ones with more hits than a candidate list holds.
 
@@ -118,6 +119,24 @@ def test_config3_10m_cosine_all_256_queries_equal_the_exact_scan(engine_10m_cosi
     assert (cf == K).all() and (lf >= 0).all() and (lf < N10).all()
     assert (np.diff(df, axis=1) >= 0).all()
     assert lf[:len(PLANT), 0].tolist() == PLANT
+    # ... and against the NumPy ORACLE itself at the full 10M rows, for 8 of the queries (the planted ones + one plain): the fp64
+    # oracle scans the regenerated 1M-row chunks one by one and the per-chunk top-k are merged by (fp64 distance, label), so the
+    # headline-size answer is oracle-pinned too, not only pinned through the GPU's exact scan (about a minute of host NumPy)
+    from oracle import exact_scan
+
+    sub = np.concatenate([np.arange(len(PLANT)), [200]])
+    parts_l, parts_d = [], []
+    for off, rows in synth.iter_corpus(0, N10, D, threads=16):
+        d64 = exact_scan.exact_distances(qs[sub], rows, "cosine")
+        part = np.argpartition(d64, K - 1, axis=1)[:, :K]
+        parts_l.append(part + off)
+        parts_d.append(np.take_along_axis(d64, part, axis=1))
+        del d64, rows
+    from mlvectordb_amd.sharded import merge_topk
+
+    ol, od, _ = merge_topk(parts_l, parts_d, K)
+    assert np.array_equal(lf[sub], ol), "10M rows: ids differ from the NumPy oracle"
+    assert np.abs(df[sub] - od).max() <= 1e-5
     # BASELINE configs[4]'s per-GPU shape: a 1024-query wave = four 256-query passes over the 10M-row shard (what every rank of
     # the 8-GPU job runs; the cross-shard merge is covered by tests/test_sharded.py and bench.py's sharded gate)
     big = np.concatenate([qs, np.random.default_rng(1024).standard_normal((1024 - qs.shape[0], qs.shape[1])).astype(np.float32)])
