@@ -1394,14 +1394,16 @@ __global__ __launch_bounds__(kRescoreWaves * 64) void range_score_flat_kernel(co
 // 36 MB through one CU's LDS -- 300-380 us per 256-query wave with 255 CUs idle (profiles/r03/config4_l2_range_kernel_stats.csv).
 // Here the longest list is spread over 26 blocks of 6,554 steps each.  More than kCandCap hits: flagged, served by the
 // paged exact kNN (api.hip), as before.
-constexpr int kRankChunk = 256;
-constexpr int kRankGrid = 256;  // one block per CU; the (query, chunk) work items are dealt to the blocks in turn.  (A grid of
+constexpr int kRankThreads = 256;
+constexpr int kRankTargets = 32;   // hits ranked per work item: 32 targets x 8 list segments = 256 threads
+constexpr int kRankSegs = kRankThreads / kRankTargets;
+constexpr int kRankGrid = 256;  // one block per CU; the (query, 32-hit chunk) work items are dealt to the blocks in turn.  (A grid of
                                 // nq x 32 blocks, most of which exit at once, took 2.5 ms just to be dispatched: every block asks
                                 // for 98 KB of LDS.)
-__global__ __launch_bounds__(kRankChunk) void range_rank_kernel(const FilterArgs a, const int32_t q0, const int64_t capacity,
-                                                                  int64_t* out_labels, float* out_dist, int64_t* out_counts) {
+__global__ __launch_bounds__(kRankThreads) void range_rank_kernel(const FilterArgs a, const int32_t q0, const int64_t capacity,
+                                                                    int64_t* out_labels, float* out_dist, int64_t* out_counts) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ uint32_t pre[kFilterQueries + 1];  // chunks of the queries before q
+    __shared__ uint32_t pre[kFilterQueries + 1];  // work items of the queries before q
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave == 0) {  // lane l: queries 4l .. 4l+3; inclusive scan over the lanes
         uint32_t c[4], sum = 0;
@@ -1420,7 +1422,7 @@ __global__ __launch_bounds__(kRankChunk) void range_rank_kernel(const FilterArgs
                 }
                 if (n > (uint32_t)kCandCap) n = 0;
             }
-            c[i] = (n + kRankChunk - 1) / kRankChunk;
+            c[i] = (n + kRankTargets - 1) / kRankTargets;
             sum += c[i];
         }
         uint32_t incl = sum;
@@ -1438,6 +1440,9 @@ __global__ __launch_bounds__(kRankChunk) void range_rank_kernel(const FilterArgs
     }
     __syncthreads();
     const uint32_t total = pre[kFilterQueries];
+    const int tgt = threadIdx.x / kRankSegs, seg = threadIdx.x % kRankSegs;  // the 8 segment threads of a target are neighbours
+    int cur = -1;
+    uint32_t n = 0, n8 = 0;
     for (uint32_t u = blockIdx.x; u < total; u += gridDim.x) {  // block-uniform
         int lo = 0, hi = kFilterQueries;  // the query with pre[q] <= u < pre[q + 1]
         while (hi - lo > 1) {
@@ -1446,44 +1451,53 @@ __global__ __launch_bounds__(kRankChunk) void range_rank_kernel(const FilterArgs
             else hi = mid;
         }
         const int q = lo;
-        const uint32_t n = a.rhit_cnt[q];  // (<= kCandCap: larger lists have no chunks)
-        const uint32_t n8 = (n + 7u) & ~7u;  // padded with (+inf, kNoLabel): precedes nothing
-        double* ed = reinterpret_cast<double*>(smem);       // [n8]
-        int32_t* el = reinterpret_cast<int32_t*>(ed + n8);  // [n8], 16-byte aligned
-        const RangeHit* src = a.rhits + (int64_t)q * kCandCap;
-        __syncthreads();  // the previous item's readers are done with the LDS copy
-        for (uint32_t i = threadIdx.x; i < n8; i += kRankChunk) {
-            RangeHit h;
-            h.d = __builtin_inf();
-            h.l = kNoLabel;
-            if (i < n) h = src[i];
-            ed[i] = h.d;
-            el[i] = h.l;
+        double* ed = reinterpret_cast<double*>(smem);  // [n8]
+        if (q != cur) {  // (consecutive items of a block usually belong to different queries; the longest list's to many blocks)
+            n = a.rhit_cnt[q];  // (<= kCandCap: larger lists have no items)
+            n8 = (n + 63u) & ~63u;  // padded with (+inf, kNoLabel), which precedes nothing: every segment a whole number of 8-entry steps
+            int32_t* el_w = reinterpret_cast<int32_t*>(ed + n8);
+            const RangeHit* src = a.rhits + (int64_t)q * kCandCap;
+            __syncthreads();  // the previous item's readers are done with the LDS copy
+            for (uint32_t i = threadIdx.x; i < n8; i += kRankThreads) {
+                RangeHit h;
+                h.d = __builtin_inf();
+                h.l = kNoLabel;
+                if (i < n) h = src[i];
+                ed[i] = h.d;
+                el_w[i] = h.l;
+            }
+            __syncthreads();
+            cur = q;
         }
-        __syncthreads();
-        const uint32_t i = (u - pre[q]) * (uint32_t)kRankChunk + threadIdx.x;
-        if (i < n) {
-            const double di = ed[i];
-            const int32_t li = el[i];
-            // 8 list entries per step, read as 4 + 2 16-byte LDS words (every lane the same address: broadcasts) and compared
-            // without branches: with one entry per step and entry_less's short-circuit the loop was two exposed LDS round trips
-            // per entry (873 us for the 6,554-hit list of the benchmark wave)
-            const double2* e2 = reinterpret_cast<const double2*>(ed);
-            const int4* l4 = reinterpret_cast<const int4*>(el);
-            uint32_t rank = 0;
-            auto before = [&](double d, int32_t l) __attribute__((always_inline)) {
-                return (uint32_t)((d < di) | ((d == di) & (l < li)));
-            };
-            for (uint32_t j = 0; j < n8; j += 8) {
-                const double2 d0 = e2[j / 2], d1 = e2[j / 2 + 1], d2 = e2[j / 2 + 2], d3 = e2[j / 2 + 3];
-                const int4 la = l4[j / 4], lb = l4[j / 4 + 1];
-                rank += before(d0.x, la.x) + before(d0.y, la.y) + before(d1.x, la.z) + before(d1.y, la.w) +
-                        before(d2.x, lb.x) + before(d2.y, lb.y) + before(d3.x, lb.z) + before(d3.y, lb.w);
-            }
-            if ((int64_t)rank < capacity) {
-                out_labels[(int64_t)(q0 + q) * capacity + rank] = li;
-                out_dist[(int64_t)(q0 + q) * capacity + rank] = (float)di;
-            }
+        const int32_t* el = reinterpret_cast<const int32_t*>(ed + n8);  // [n8], 16-byte aligned
+        const uint32_t i = (u - pre[q]) * (uint32_t)kRankTargets + tgt;
+        // Rank of hit i = how many list entries precede it by (distance, label).  The list is cut into 8 segments, one per
+        // thread of the target; 8 entries per step, read as 4 + 2 16-byte LDS words and compared without branches (with one
+        // entry per step and entry_less's short-circuit the loop was two exposed LDS round trips per entry: 873 us for the
+        // 6,554-hit list of the benchmark wave; one thread per target over the whole list, 8 entries per step: 268 us -- the
+        // loop is bound by its ~64 compare / select instructions per step, so the longest list is spread over 8x more threads)
+        const bool have = i < n;
+        const double di = have ? ed[i] : 0.0;
+        const int32_t li = have ? el[i] : 0;
+        const double2* e2 = reinterpret_cast<const double2*>(ed);
+        const int4* l4 = reinterpret_cast<const int4*>(el);
+        uint32_t rank = 0;
+        auto before = [&](double d, int32_t l) __attribute__((always_inline)) {
+            return (uint32_t)((d < di) | ((d == di) & (l < li)));
+        };
+        const uint32_t per = n8 / kRankSegs;  // entries per segment: a multiple of 8
+        for (uint32_t j = seg * per; j < (seg + 1) * per; j += 8) {
+            const double2 d0 = e2[j / 2], d1 = e2[j / 2 + 1], d2 = e2[j / 2 + 2], d3 = e2[j / 2 + 3];
+            const int4 la = l4[j / 4], lb = l4[j / 4 + 1];
+            rank += before(d0.x, la.x) + before(d0.y, la.y) + before(d1.x, la.z) + before(d1.y, la.w) +
+                    before(d2.x, lb.x) + before(d2.y, lb.y) + before(d3.x, lb.z) + before(d3.y, lb.w);
+        }
+        rank += __shfl_xor(rank, 1);  // the 8 partial ranks of a target
+        rank += __shfl_xor(rank, 2);
+        rank += __shfl_xor(rank, 4);
+        if (have && seg == 0 && (int64_t)rank < capacity) {
+            out_labels[(int64_t)(q0 + q) * capacity + rank] = li;
+            out_dist[(int64_t)(q0 + q) * capacity + rank] = (float)di;
         }
     }
 }
@@ -2507,7 +2521,7 @@ hipError_t launch_filter_rescore(const FilterArgs& a, int32_t k, int32_t q0, int
 
 hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, int64_t capacity, int64_t* out_labels,
                                 float* out_dist, int64_t* out_counts, hipStream_t s) {
-    const size_t lds_sort = (size_t)kCandCap * (sizeof(double) + sizeof(int32_t));  // the ranking kernel's {d[], l[]} (kCandCap % 8 == 0)
+    const size_t lds_sort = (size_t)kCandCap * (sizeof(double) + sizeof(int32_t));  // the ranking kernel's {d[], l[]} (kCandCap % 64 == 0)
     hipError_t e = hipMemsetAsync(a.rhit_cnt, 0, kFilterQueries * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     // MLVDB_RANGE_FLAT=0: round 2's (query, 256-candidate chunk) grid (A/B)
@@ -2537,7 +2551,7 @@ hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, i
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(range_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_sort);
     if (e != hipSuccess) return e;
-    range_rank_kernel<<<kRankGrid, kRankChunk, lds_sort, s>>>(a, q0, capacity, out_labels, out_dist, out_counts);
+    range_rank_kernel<<<kRankGrid, kRankThreads, lds_sort, s>>>(a, q0, capacity, out_labels, out_dist, out_counts);
     return hipGetLastError();
 }
 
