@@ -2436,10 +2436,15 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
         // kernel below, half the MFMAs, and no pass of the default path reads the bf16 shadow any more (so an index need
         // not keep one: 1.25x instead of 1.75x the corpus in HBM).  Every bound goes into the lists either way; the refine
         // that follows takes the threshold from exact scores.
-        const int groups = (a.nq + 63) / 64;
-        e = a.space == kSpaceL2       ? launch_scan_narrow_n<kSpaceL2, 4, true, 4, 4, true>(a, 0, rows, s, groups)
-            : a.space == kSpaceCosine ? launch_scan_narrow_n<kSpaceCosine, 4, true, 4, 4, true>(a, 0, rows, s, groups)
-                                      : launch_scan_narrow_n<kSpaceIp, 4, true, 4, 4, true>(a, 0, rows, s, groups);
+        // queries per group: as many as the image leaves room for in LDS (64 up to ld = 2304, 32 up to 4736, else 16)
+        const int nqt = narrow_lds(a.ld, 4, 4, true) <= kNarrowLdsMax ? 4 : (narrow_lds(a.ld, 2, 4, true) <= kNarrowLdsMax ? 2 : 1);
+        const int groups = (a.nq + 16 * nqt - 1) / (16 * nqt);
+#define MLVDB_SEED_I8(SP)                                                                                              \
+    (nqt == 4 ? launch_scan_narrow_n<SP, 4, true, 4, 4, true>(a, 0, rows, s, groups)                                  \
+              : nqt == 2 ? launch_scan_narrow_n<SP, 2, true, 4, 4, true>(a, 0, rows, s, groups)                       \
+                         : launch_scan_narrow_n<SP, 1, true, 4, 4, true>(a, 0, rows, s, groups))
+        e = a.space == kSpaceL2 ? MLVDB_SEED_I8(kSpaceL2) : a.space == kSpaceCosine ? MLVDB_SEED_I8(kSpaceCosine) : MLVDB_SEED_I8(kSpaceIp);
+#undef MLVDB_SEED_I8
         if (e != hipSuccess) return e;
         const bool fuse = filter_refine_can_fuse(a);
         if ((e = launch_filter_refine_thr(a, k, (int32_t)rows, fuse, s)) != hipSuccess || fuse) return e;

@@ -367,6 +367,18 @@ def test_small_batches_through_the_filter_agree_with_oracle(space, d, nq, n, nar
     assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"narrow={narrow}/{space}/d{d}/nq{nq}")
 
 
+@pytest.mark.parametrize("space,d,nq", [("cosine", 4096, 40), ("l2", 2560, 70), ("ip", 8192, 20), ("cosine", 8192, 3)])
+def test_wide_rows_through_the_filter_agree_with_oracle(space, d, nq):
+    """dim up to the 8192 limit on the int8 path: the dense seeding pass groups fewer queries per workgroup when their int8 image
+    no longer fits LDS at 64 (32 beyond ld = 2304, 16 beyond 4736), the refine cannot fuse the pruning beyond ld = 2048."""
+    n = 33_000 if d <= 4096 else 17_000
+    rows, qs = make_case(900 + d, n, d, nq, dup=True)
+    deleted = deleted_mask(5, n, 0.05)
+    got, stats = run_hip(rows, qs, 10, space, "filter", deleted, append_chunks=2)
+    assert stats["strategy_used"] == 2 and stats["bound_dtype"] == 2 and stats["fallback_queries"] == 0
+    assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"wide/{space}/d{d}/nq{nq}")
+
+
 @pytest.mark.parametrize("variant", SCAN_VARIANTS, ids=lambda v: ",".join(f"{k[6:]}={x}" for k, x in v.items()) or "default")
 @pytest.mark.parametrize("space,d", [("cosine", 128), ("l2", 192), ("ip", 64), ("cosine", 768), ("l2", 1536), ("ip", 768), ("l2", 256)])
 def test_scan_kernel_variants_agree_with_oracle(variant, space, d, monkeypatch):
