@@ -412,7 +412,7 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
 
 // One pass of <= 256 queries through the filter path; outputs at query index q0.. of the batch.
 int finish_filter_pass(mlvdb_index* h, hipStream_t s, FilterArgs& fa, int32_t q0, int32_t nq, int32_t k, int64_t* out_labels,
-                       float* out_dist, int32_t* out_counts, double* out_d64, bool defer_fallback);
+                       float* out_dist, int32_t* out_counts, double* out_d64, bool defer_fallback, bool ranked = false);
 
 // Everything a filter pass needs of its queries, in one fused launch (+ the one-block fin for int8 passes of several queries).
 int prep_pass(mlvdb_index* h, hipStream_t s, const FilterArgs& fa, const float* queries_raw, float* Qpad, double* qaux, float* qerr) {
@@ -487,7 +487,20 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
         // then belong to the first scan round.  Slower: 2.16 vs 2.04 ms per 256-query wave, 0.303 vs 0.288 ms at batch 1
         // (3840 x 768 x 256 fp64 multiply-adds are not free); the dense pass stays the default.
         const char* env = getenv("MLVDB_SEED_EXACT");
-        if (env && env[0] == '1') {
+        // Batches of 1-2 queries (round 3): the exact k-th best of the prefix by a kernel made for it (one 16-row group per
+        // wave all over the chip + a one-block selection of the k-th: 8 + 10 us) instead of the dense int8 pass + exact-threshold refine (7 + 15.5 us
+        // of latency chains at batch 1); the prefix rows then belong to the first scan round.  MLVDB_SMALL_SEED=0: the dense pass.
+        const char* sm = getenv("MLVDB_SMALL_SEED");
+        int small_nq = 2;  // (4-8 queries: no gain from either step; profiles/r03/small_batch_fused_finish_and_prefix_seed_1m.txt)
+        if (const char* v = getenv("MLVDB_SMALL_NQ")) small_nq = std::max(0, std::min(8, atoi(v)));
+        if (fa.X8 && nq <= small_nq && k <= 64 && !h->mask_active && filter_narrow_ok(fa) && !(env && env[0] == '1') &&
+            !(sm && sm[0] == '0')) {
+            HIP_TRY(h, h->seed_d64.ensure(((size_t)kFilterQueries * 64 + (size_t)8 * kSeedRows) * sizeof(double)));
+            double* d64 = h->seed_d64.as<double>();
+            HIP_TRY(h, launch_prefix_exact(h->X, fa.rn, fa.Qpad, fa.qaux, nq, (int32_t)n_seed, h->ld, h->space, d64, s));
+            HIP_TRY(h, launch_filter_prefix_thr(fa, d64, (int32_t)n_seed, k, s));
+            first_row = 0;
+        } else if (env && env[0] == '1') {
             HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * k * sizeof(int64_t)));
             HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * k * sizeof(float)));
             HIP_TRY(h, h->seed_cnt.ensure(kFilterQueries * sizeof(int32_t)));
@@ -509,6 +522,14 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
     if (const char* v = getenv("MLVDB_ROUND1")) r1 = std::max<int64_t>(6, atoll(v));
     if (const char* v = getenv("MLVDB_ROUND2")) r2 = std::max<int64_t>(r1, atoll(v));
     const int64_t bounds[] = {first_row, (int64_t)kFilterTile * r1, (int64_t)kFilterTile * r2, h->total};
+    // Batches of 1-2 queries: the refine after the LAST round also rescores and ranks (one launch instead of three:
+    // launch_filter_finish_small); MLVDB_SMALL_FINISH=0: the three kernels
+    // (one block per query: at 4-8 queries the rescoring kernel's spread over the whole chip wins again -- 0.261 vs 0.247 ms at 4)
+    int small_nq = 2;
+    if (const char* v = getenv("MLVDB_SMALL_NQ")) small_nq = std::max(0, std::min(8, atoi(v)));
+    bool small_finish = fa.X8 && nq <= small_nq && k <= 64 && filter_refine_can_fuse(fa);
+    if (const char* v = getenv("MLVDB_SMALL_FINISH")) small_finish = small_finish && v[0] != '0';
+    bool ranked = false;
     for (int r = 0; r < 3; ++r) {
         const int64_t b = std::min(bounds[r], h->total), e = std::min(bounds[r + 1], h->total);
         if (e <= b) continue;
@@ -564,6 +585,15 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
         // (Tried in round 3 for batches of <= 8 queries: no refine after the LAST round -- the rescoring takes the unpruned
         // lists.  Slower: 0.257 vs 0.226 ms at batch 1 on 1M x 768, the ranking kernel pays more for the ~800-entry list
         // than the refine's launch costs; profiles/r03/small_batch_last_refine_1m.txt.)
+        if (small_finish && e == h->total) {  // the last round of a small batch
+            HIP_TRY(h, h->qsel.ensure(kFilterQueries * sizeof(int32_t)));
+            unsigned long long* stats = h->counters.as<unsigned long long>();
+            HIP_TRY(h, launch_filter_finish_small(fa, k, q0, out_labels, out_dist, out_counts, out_d64, stats,
+                                                  defer_fallback ? nullptr : h->qsel.as<int32_t>(),
+                                                  reinterpret_cast<int32_t*>(stats + 2), s));
+            ranked = true;
+            break;
+        }
         if (fa.X8) HIP_TRY(h, launch_filter_refine_thr(fa, k, -1, fuse, s));
 #ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: where the refine kernel's time goes (its blocks stamp their phases)
         if (fa.X8 && fa.wgbuf && getenv("MLVDB_DEBUG_REFINE")) {
@@ -584,12 +614,13 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
 #endif
         if (!fuse) HIP_TRY(h, launch_filter_update(fa, k, s));
     }
-    return finish_filter_pass(h, s, fa, q0, nq, k, out_labels, out_dist, out_counts, out_d64, defer_fallback);
+    return finish_filter_pass(h, s, fa, q0, nq, k, out_labels, out_dist, out_counts, out_d64, defer_fallback, ranked);
 }
 
-// The end of a kNN pass: exact fp64 rescoring of the candidate lists, then the exact fallback for overflowed queries.
+// The end of a kNN pass: exact fp64 rescoring of the candidate lists (unless the last refine did it: ranked), then the exact
+// fallback for overflowed queries.
 int finish_filter_pass(mlvdb_index* h, hipStream_t s, FilterArgs& fa, int32_t q0, int32_t nq, int32_t k, int64_t* out_labels,
-                       float* out_dist, int32_t* out_counts, double* out_d64, bool defer_fallback) {
+                       float* out_dist, int32_t* out_counts, double* out_d64, bool defer_fallback, bool ranked) {
     int rc = MLVDB_OK;
     // counters: [0] rescored pairs, [1] fallback queries (accumulated over the passes of a call), [2] flag count
     unsigned long long* stats = h->counters.as<unsigned long long>();
@@ -599,10 +630,11 @@ int finish_filter_pass(mlvdb_index* h, hipStream_t s, FilterArgs& fa, int32_t q0
     // (its ranking kernel also compacts the overflowed queries for the device-decided fallback below: qsel, nflag)
     HIP_TRY(h, h->qsel.ensure(kFilterQueries * sizeof(int32_t)));
     int32_t* nflag = reinterpret_cast<int32_t*>(stats + 2);
-    HIP_TRY(h, launch_filter_rescore(fa, k, q0, out_labels, out_dist, out_counts, out_d64, stats,
-                                     defer_fallback ? nullptr : h->qsel.as<int32_t>(), nflag, s));
+    if (!ranked)
+        HIP_TRY(h, launch_filter_rescore(fa, k, q0, out_labels, out_dist, out_counts, out_d64, stats,
+                                         defer_fallback ? nullptr : h->qsel.as<int32_t>(), nflag, s));
 #ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: where the ranking kernel's time goes (its blocks stamp their phases)
-    if (fa.wgbuf && getenv("MLVDB_DEBUG_REFINE")) {
+    if (!ranked && fa.wgbuf && getenv("MLVDB_DEBUG_REFINE")) {
         std::vector<unsigned long long> st(16384 + 1024, 0ull);
         HIP_TRY(h, hipMemcpyAsync(st.data(), fa.wgbuf, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));

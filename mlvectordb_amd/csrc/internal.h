@@ -96,6 +96,9 @@ hipError_t launch_exact_merge(const TopEntry* partial, int32_t nq_sel, const int
                               int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_d64,
                               hipStream_t s);
 
+// exact fp64 distances of rows 0..m-1 to every query (tombstoned rows: +inf): d64 = [nq][m]
+hipError_t launch_prefix_exact(const float* X, const float* rn, const float* Qpad, const double* qaux, int32_t nq, int32_t m,
+                               int32_t ld, int32_t space, double* d64, hipStream_t s);
 // exact fp64 distances of given pairs: out[q][j] = d(query q, row labels[q][j]) (labels on the device, each < total or < 0 = +inf)
 hipError_t launch_pair_distances(const float* X, const float* Qpad, const double* qaux, const int64_t* labels, int32_t nq,
                                  int32_t m, int32_t ld, int32_t space, double* out64, float* out32, hipStream_t s);
@@ -177,6 +180,8 @@ hipError_t launch_filter_prep(const FilterArgs& a, hipStream_t s);
 hipError_t launch_filter_prep_fused(const FilterArgs& a, const float* queries, int32_t dim, float* Qpad, double* qaux, float* qerr,
                                     hipStream_t s);
 // seed thresholds from exact kNN distances of a prefix of the corpus: seed_d64[q][k]
+// thr[q] from the k-th smallest of d64[q][0..m) (m <= kSeedRows; fewer than k finite values: thr stays as it is)
+hipError_t launch_filter_prefix_thr(const FilterArgs& a, const double* d64, int32_t m, int32_t k, hipStream_t s);
 hipError_t launch_filter_seed_thr(const FilterArgs& a, const double* seed_d64, int32_t k, hipStream_t s);
 // What a scan launch reports back (tuning aids).  The assembly scan stages its hits per wave in LDS and its own tail
 // moves them into the per-query candidate lists (round 1 had a separate scatter launch for that).
@@ -193,6 +198,10 @@ hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s);
 bool filter_refine_can_fuse(const FilterArgs& a);
 bool filter_narrow_ok(const FilterArgs& a);  // the pass's scans run on the narrow kernel (<= 64 queries, image resident in LDS)
 hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, bool fuse, hipStream_t s);
+// batches of <= 8 queries: the last refine + exact rescoring + ranking + output in one launch (needs filter_refine_can_fuse)
+hipError_t launch_filter_finish_small(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
+                                      int32_t* out_counts, double* out_d64, unsigned long long* rescored, int32_t* qsel,
+                                      int32_t* nflag, hipStream_t s);
 hipError_t launch_filter_scan(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info);
 // dense seeding pass over rows [0,row_end), row_end <= kSeedRows: all bounds -> candidate lists -> thresholds (update)
 constexpr int kSeedRows = 3840;  // a multiple of every scan tile (128, 192) and <= kCandCap

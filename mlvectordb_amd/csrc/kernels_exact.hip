@@ -290,6 +290,69 @@ __global__ __launch_bounds__(256) void pair_distance_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------ exact k-th best of a PREFIX of the rows (small batches)
+// The seed of a filter pass of <= 8 queries: exact fp64 distances of rows 0..m-1 (accumulate_rows: the scores every other
+// exact path gives them), tombstoned rows +inf, one 16-row group per wave so the few thousand rows spread over the chip as
+// m/64 blocks per query; filter_prefix_thr_kernel (kernels_filter.hip) then takes the k-th best per query by a radix select
+// on order keys (per-wave sorted top-k lists with fp64 lane shuffles took 34 us for 3840 rows: profiles/r03).
+// Replaces the dense int8 seeding pass + exact-threshold refine (two latency chains, 23 us at batch 1) where the fp64
+// arithmetic of m x nq rows costs nothing.
+template <int SPACE, int PF>
+__global__ __launch_bounds__(256) void prefix_exact_kernel(const float* __restrict__ X, const float* __restrict__ rn,
+                                                           const float* __restrict__ Qpad, const double* __restrict__ qaux,
+                                                           int32_t m, int32_t ld, double* __restrict__ out64) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* qs = reinterpret_cast<double*>(smem);  // [ld]
+    const int q = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, r = lane & 15;
+    const int nw = blockDim.x >> 6;
+    for (int c = threadIdx.x; c < ld; c += blockDim.x) qs[c] = (double)Qpad[(int64_t)q * ld + c];
+    __syncthreads();
+    const double qinv = qaux[q];
+    for (int j0 = (blockIdx.y * nw + wave) * 16; j0 < m; j0 += gridDim.y * nw * 16) {
+        const int j = j0 + r;
+        const bool have = j < m;
+        const int64_t rr = have ? j : 0;
+        const float* base[1] = {X + (rr >> 4) * (int64_t)(kPanelRows * ld) + (rr & 15) * 16 + g * 4};
+        double acc[1][1], nx[1];
+        accumulate_rows<SPACE, 1, 1, PF>(base, qs, ld, g, acc, nx);
+        if (have && lane < 16) {
+            const float nrm = rn[rr];
+            const double d = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
+            out64[(int64_t)q * m + j] = nrm == nrm && d == d ? d : __builtin_inf();
+        }
+    }
+}
+
+hipError_t launch_prefix_exact(const float* X, const float* rn, const float* Qpad, const double* qaux, int32_t nq, int32_t m,
+                               int32_t ld, int32_t space, double* d64, hipStream_t s) {
+    if (nq <= 0 || m <= 0) return hipErrorInvalidValue;
+    const size_t lds = (size_t)ld * sizeof(double);
+    // a whole 768-column row in flight per lane (24 groups x two banks) when the row is a whole number of such halves:
+    // one round trip per row instead of three (the kernel is one latency chain per wave); MLVDB_PREFIX_PF=8: tuning
+    bool pf24 = (ld / 16) % 24 == 0;
+    if (const char* v = getenv("MLVDB_PREFIX_PF")) pf24 = pf24 && atoi(v) == 24;
+    int nw = 4;  // waves per block, 16 rows each (MLVDB_PREFIX_WAVES: tuning)
+    if (const char* v = getenv("MLVDB_PREFIX_WAVES")) nw = std::max(1, std::min(4, atoi(v)));
+    const dim3 grid((unsigned)nq, (unsigned)(((int64_t)m + 16 * nw - 1) / (16 * nw)));
+    hipError_t e = hipSuccess;
+#define MLVDB_LAUNCH_PREFIX(SP)                                                                                        \
+    do {                                                                                                               \
+        auto kern = pf24 ? prefix_exact_kernel<SP, 24> : prefix_exact_kernel<SP, 8>;                                   \
+        if (lds > 48 * 1024)                                                                                           \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) kern<<<grid, nw * 64, lds, s>>>(X, rn, Qpad, qaux, m, ld, d64);                               \
+    } while (0)
+    switch (space) {
+        case kSpaceL2: MLVDB_LAUNCH_PREFIX(kSpaceL2); break;
+        case kSpaceCosine: MLVDB_LAUNCH_PREFIX(kSpaceCosine); break;
+        default: MLVDB_LAUNCH_PREFIX(kSpaceIp); break;
+    }
+#undef MLVDB_LAUNCH_PREFIX
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
 hipError_t launch_pair_distances(const float* X, const float* Qpad, const double* qaux, const int64_t* labels, int32_t nq,
                                  int32_t m, int32_t ld, int32_t space, double* out64, float* out32, hipStream_t s) {
     if (nq <= 0 || m <= 0) return hipSuccess;

@@ -1931,6 +1931,94 @@ __device__ __forceinline__ uint32_t radix_select_atleast256(const uint32_t* keys
     return prefix;
 }
 
+// thr[q] from the exact distances of a prefix of the rows (small batches: api.hip, launch_prefix_exact): the threshold the
+// k-th nearest of them gives, exactly as filter_seed_thr_kernel forms it -- t(d) = float_below(s(d) - 1e-9 mag) is monotone
+// in d, so the k-th largest t is t(k-th smallest d).  Selection without histograms (a radix select run to the last bit
+// took 14 us here, per-wave sorted lists with fp64 shuffles 34): every thread keeps its <= 15 keys in registers; L = the
+// k-th largest of the 256 per-thread maxima is at most the k-th largest key (k keys are >= L), the few keys >= L (about k,
+// unless many are equal) are collected and ranked by counting.
+__global__ __launch_bounds__(256) void filter_prefix_thr_kernel(const FilterArgs a, const double* __restrict__ d64, const int32_t m,
+                                                                const int32_t k) {
+    constexpr int kPer = kSeedRows / 256;  // 15
+    __shared__ __attribute__((aligned(16))) uint32_t tmax[256];
+    __shared__ uint32_t sel[256];
+    __shared__ uint32_t s_n[4];
+    const int q = blockIdx.x;
+    const double aux = a.qaux[q];
+    if (a.space == kSpaceIp && !(aux > 0.0)) return;  // |q| = 0: every distance is 1 (block-uniform)
+    uint32_t key[kPer], best = 0;
+    double dk[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = j * 256 + threadIdx.x;
+        dk[j] = i < m ? d64[(int64_t)q * m + i] : __builtin_inf();
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        key[j] = 0;
+        if (dk[j] < 1.0e300) {
+            double s;
+            if (a.space == kSpaceCosine) s = 1.0 - dk[j];
+            else if (a.space == kSpaceIp) s = (1.0 - dk[j]) / aux;
+            else s = aux * aux - dk[j];
+            const double mag = a.space == kSpaceL2 ? aux * aux + __builtin_fabs(dk[j]) : __builtin_fabs(s) + 1.0;
+            key[j] = float_order_key(float_below(s - 1e-9 * mag));
+            if (key[j] == 0) key[j] = 1;
+            best = max(best, key[j]);
+        }
+    }
+    tmax[threadIdx.x] = best;
+    if (threadIdx.x < 4) s_n[threadIdx.x] = 0;
+    __syncthreads();
+    // rank of this thread's maximum among the 256 (ties by thread index: a permutation); the k-th largest is L
+    if (k <= 256) {  // (four maxima per LDS read, eight reads in flight: one read per step made this loop most of the kernel)
+        uint32_t rank = 0;
+        const uint4* t4 = reinterpret_cast<const uint4*>(tmax);
+        const uint32_t me = threadIdx.x;
+#pragma unroll 8
+        for (uint32_t j = 0; j < 64; ++j) {
+            const uint4 o = t4[j];
+            rank += (o.x > best || (o.x == best && 4 * j < me)) ? 1u : 0u;
+            rank += (o.y > best || (o.y == best && 4 * j + 1 < me)) ? 1u : 0u;
+            rank += (o.z > best || (o.z == best && 4 * j + 2 < me)) ? 1u : 0u;
+            rank += (o.w > best || (o.w == best && 4 * j + 3 < me)) ? 1u : 0u;
+        }
+        if (rank == (uint32_t)k - 1u) s_n[1] = best;
+    }
+    __syncthreads();
+    const uint32_t L = s_n[1];
+    if (L == 0) return;  // fewer than k threads hold a live row: leave the threshold open (rare: the rounds' refines set it)
+#pragma unroll
+    for (int j = 0; j < kPer; ++j)
+        if (key[j] >= L) {
+            const uint32_t pos = atomicAdd(&s_n[0], 1u);
+            if (pos < 256u) sel[pos] = key[j];
+        }
+    __syncthreads();
+    const uint32_t n = s_n[0];
+    uint32_t tkey = L;  // more than 256 keys at or above L (masses of equal rows): L itself is a valid threshold
+    if (n <= 256u) {
+        if (threadIdx.x < n) {
+            const uint32_t mine = sel[threadIdx.x];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; ++j) {
+                const uint32_t o = sel[j];
+                rank += (o > mine || (o == mine && j < threadIdx.x)) ? 1u : 0u;
+            }
+            if (rank == (uint32_t)k - 1u) s_n[2] = mine;
+        }
+        __syncthreads();
+        tkey = s_n[2];
+    }
+    if (threadIdx.x == 0) a.thr[q] = float_from_order_key(tkey);
+}
+
+hipError_t launch_filter_prefix_thr(const FilterArgs& a, const double* d64, int32_t m, int32_t k, hipStream_t s) {
+    if (m < 1 || m > kSeedRows || k < 1 || k > 256) return hipErrorInvalidValue;
+    filter_prefix_thr_kernel<<<a.nq, 256, 0, s>>>(a, d64, m, k);
+    return hipGetLastError();
+}
+
 // Exact thresholds: the entries with the largest bounds -- at least `picks` (>= k), at most max(picks, 32) of them -- are
 // scored exactly (fp64); the k-th largest of those exact scores is a lower bound of the final k-th best score, however
 // loose the bounds are (k rows are known to score at least that).  With int8 bounds (error ~ one sigma of the score
@@ -1939,9 +2027,26 @@ __device__ __forceinline__ uint32_t radix_select_atleast256(const uint32_t* keys
 // passes find a bound with 16..32 entries at or above it, all of which are taken (the set is deterministic, no ties are
 // split); gather: 8 lanes per row, all of a row's pieces in flight at once (a row is one page walk: latency, not bytes).
 // The sums here are only compared against bounds (1e-9 relative slack below), so their order is free.
-template <int SPACE>
+//
+// FINISH (batches of <= 8 queries, after the last scan round; fuse must be set): the block goes on to do what the rescoring
+// kernels do for its query -- exact distances of the surviving rows by accumulate_rows (the arithmetic of every other exact
+// path), ranking by (distance, label), the answer written out -- and block 0 compacts the overflow flags for the device-
+// decided fallback, as the ranking kernel does.  Three dependent launches (refine 13 + score 12 + rank 5 us at batch 1, of
+// which ~4.5 us each are the launch itself) become one.
+struct FinishOut {
+    int32_t q0;
+    int64_t* labels;
+    float* dist;
+    int32_t* counts;
+    double* d64;
+    unsigned long long* rescored;
+    int32_t* qsel;
+    int32_t* nflag;
+};
+
+template <int SPACE, bool FINISH = false>
 __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs a, const int32_t k, const int32_t forced_cnt,
-                                                                const bool fuse, const int32_t picks) {
+                                                                const bool fuse, const int32_t picks, const FinishOut fo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* qs = reinterpret_cast<double*>(smem);                                   // [ld]
     double* sc = qs + a.ld;                                                         // [64] exact scores of the picks
@@ -1959,6 +2064,23 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
 #define REFINE_STAMP(i) do { } while (0)
 #endif
     REFINE_STAMP(0);
+    if (FINISH && blockIdx.x == 0 && fo.qsel) {  // block-uniform; 256 threads = kFilterQueries
+        uint32_t* s_flagged = s_scan + 18;  // [4] (no static LDS here: the dynamic allocation is sized to the CU's limit)
+        const int t = threadIdx.x;
+        // (a list longer than its capacity without the flag cannot happen; the block of that query would set the flag below)
+        const bool flagged = t < a.nq && (a.overflow[t] != 0 || a.cnt[t] > (uint32_t)kCandCap);
+        const unsigned long long bal = __ballot(flagged);
+        if ((t & 63) == 0) s_flagged[t >> 6] = __popcll(bal);
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (t >> 6); ++w) base += (int)s_flagged[w];
+        if (flagged) fo.qsel[base + __popcll(bal & ((1ull << (t & 63)) - 1ull))] = t;
+        if (t == 0) {
+            const int n = (int)(s_flagged[0] + s_flagged[1] + s_flagged[2] + s_flagged[3]);
+            *fo.nflag = n;
+            if (fo.rescored) fo.rescored[1] += (unsigned long long)n;
+        }
+    }
     if (q >= a.nq || a.overflow[q]) return;
     const uint32_t cnt = forced_cnt >= 0 ? (uint32_t)forced_cnt : a.cnt[q];
     if (cnt > (uint32_t)kCandCap) {  // cannot happen without the flag, but never index past the list
@@ -2139,12 +2261,17 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
     uint32_t pos = 0;
     for (int w = 0; w < wave; ++w) pos += s_scan[w];
     const uint32_t new_cnt = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
-    if (new_cnt != cnt) {
+    uint32_t* surv = keys;  // FINISH: rows of the survivors, in list order (the keys are done with)
+    if (FINISH || new_cnt != cnt) {
         for (uint32_t base = wb; base < we; base += 64) {
             const uint32_t idx = base + lane;
             const bool kept = idx < we && stage[idx].u >= thr;
             const unsigned long long bal = __ballot(kept);
-            if (kept) list[pos + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = stage[idx];
+            const uint32_t at = pos + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (kept) {
+                if (FINISH) surv[at] = (uint32_t)stage[idx].row;
+                else list[at] = stage[idx];
+            }
             pos += (uint32_t)__popcll(bal);
         }
     }
@@ -2154,6 +2281,113 @@ __global__ __launch_bounds__(256) void filter_refine_thr_kernel(const FilterArgs
     }
     REFINE_STAMP(5);
 #undef REFINE_STAMP
+    if (!FINISH) return;
+    __syncthreads();  // surv[] complete; stage[] is free from here on
+    // ---- exact distances of the survivors: 16 rows per wave and step (filter_rescore_score_kernel's inner step)
+    constexpr int kFinWaves = 4;
+    double* ed = reinterpret_cast<double*>(stage);                    // [kRescoreRankMax] short lists: ranked in LDS
+    int32_t* el = reinterpret_cast<int32_t*>(ed + kRescoreRankMax);   // [kRescoreRankMax]
+    RangeHit* rs = a.rs + (int64_t)q * kCandCap;                      // long lists: through global memory
+    const bool in_lds = new_cnt <= (uint32_t)kRescoreRankMax;
+    {
+        // (two rows per lane group -- 128 rows per block and step, the ~70 survivors in one round of gathers -- was slower:
+        // 25.0 vs 22.6 us for the kernel)
+        const int g = lane >> 4, r = lane & 15;
+        for (uint32_t base = (uint32_t)wave * 16; base < new_cnt; base += kFinWaves * 16) {
+            const uint32_t idx = base + r;
+            const bool have = idx < new_cnt;
+            const int32_t row = (int32_t)surv[have ? idx : base];
+            const float* rbase[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 16 + g * 4};
+            double acc[1][1], nx[1];
+            accumulate_rows<SPACE, 1, 1, kRescorePF>(rbase, qs, ld, g, acc, nx);
+            const double dist = finish_distance<SPACE>(acc[0][0], nx[0], qinv);
+            if (have && lane < 16) {
+                const float nrm = a.rn[row];
+                const bool live = nrm == nrm;
+                if (in_lds) {
+                    ed[idx] = live ? dist : __builtin_inf();
+                    el[idx] = live ? row : kNoLabel;
+                } else {
+                    RangeHit hit;
+                    hit.d = live ? dist : __builtin_inf();
+                    hit.l = live ? row : kNoLabel;
+                    hit.pad = 0;
+                    rs[idx] = hit;
+                }
+            }
+        }
+    }
+    if (threadIdx.x == 0) s_scan[17] = 0;
+    __syncthreads();
+    // ---- ranking + output (filter_rescore_rank_kernel's two cases, four waves)
+    const int64_t o = (int64_t)(fo.q0 + q) * k;
+    if (in_lds) {
+        int mine = 0;
+        for (uint32_t i = wave; i < new_cnt; i += kFinWaves) {
+            const double di = ed[i];
+            const int32_t li = el[i];
+            if (li == kNoLabel) continue;  // wave-uniform
+            ++mine;
+            int rank = 0;
+            for (uint32_t j0 = 0; j0 < new_cnt && rank < k; j0 += 128) {
+                const uint32_t j = j0 + lane, j2 = j + 64;
+                const bool l0 = j < new_cnt && entry_less(ed[j], el[j], di, li);
+                const bool l1 = j2 < new_cnt && entry_less(ed[j2], el[j2], di, li);
+                rank += __popcll(__ballot(l0)) + __popcll(__ballot(l1));
+            }
+            if (lane == 0 && rank < k) {
+                fo.labels[o + rank] = (int64_t)li;
+                fo.dist[o + rank] = (float)di;
+                if (fo.d64) fo.d64[o + rank] = di;
+            }
+        }
+        if (lane == 0 && mine) atomicAdd(&s_scan[17], (uint32_t)mine);
+        __syncthreads();
+        const int n_out = min((int)s_scan[17], k);
+        for (int i = n_out + threadIdx.x; i < k; i += 256) {
+            fo.labels[o + i] = -1;
+            fo.dist[o + i] = __builtin_inff();
+            if (fo.d64) fo.d64[o + i] = __builtin_inf();
+        }
+        if (threadIdx.x == 0) {
+            fo.counts[fo.q0 + q] = n_out;
+            if (fo.rescored) atomicAdd(fo.rescored, (unsigned long long)new_cnt);
+        }
+        return;
+    }
+    // long lists (masses of near-equal rows): per-wave sorted top-k lists, merged by wave 0
+    double* sd = reinterpret_cast<double*>(stage);                  // [kFinWaves][64]
+    int32_t* sl = reinterpret_cast<int32_t*>(sd + kFinWaves * 64);  // [kFinWaves][64]
+    WaveTopK top;
+    top.init();
+    for (uint32_t b = 0; b < new_cnt; b += kFinWaves * 64) {
+        const uint32_t i = b + wave * 64 + lane;
+        RangeHit hh;
+        hh.d = __builtin_inf();
+        hh.l = kNoLabel;
+        if (i < new_cnt) hh = rs[i];
+        top.offer(hh.l != kNoLabel, hh.d, hh.l, k, lane);
+    }
+    sd[wave * 64 + lane] = top.d;
+    sl[wave * 64 + lane] = top.l;
+    __syncthreads();
+    if (wave != 0) return;
+    WaveTopK f;
+    f.init();
+#pragma unroll
+    for (int w2 = 0; w2 < kFinWaves; ++w2)
+        f.offer(lane < k && sl[w2 * 64 + lane] != kNoLabel, sd[w2 * 64 + lane], sl[w2 * 64 + lane], k, lane);
+    const bool valid = lane < k && f.l != kNoLabel;
+    if (lane < k) {
+        fo.labels[o + lane] = valid ? (int64_t)f.l : -1;
+        fo.dist[o + lane] = valid ? (float)f.d : __builtin_inff();
+        if (fo.d64) fo.d64[o + lane] = valid ? f.d : __builtin_inf();
+    }
+    const int n_valid_out = __popcll(__ballot(valid));
+    if (lane == 0) {
+        fo.counts[fo.q0 + q] = n_valid_out;
+        if (fo.rescored) atomicAdd(fo.rescored, (unsigned long long)new_cnt);
+    }
 }
 
 // fuse: also do the threshold update's pruning (then filter_update_kernel is not needed for the round); possible while
@@ -2175,7 +2409,28 @@ hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forc
     int picks = pv ? atoi(pv) : k + k / 2;
     if (!pv && picks < 16) picks = 16;
     picks = picks < k ? k : (picks > 64 ? 64 : picks);
-    kern<<<a.nq, 256, lds, s>>>(a, k, forced_cnt, fuse, picks);
+    kern<<<a.nq, 256, lds, s>>>(a, k, forced_cnt, fuse, picks, FinishOut{});
+    return hipGetLastError();
+}
+
+// The last refine of a pass of <= 8 queries + rescoring + ranking in one launch (filter_refine_can_fuse(a) must hold, k <= 64).
+hipError_t launch_filter_finish_small(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
+                                      int32_t* out_counts, double* out_d64, unsigned long long* rescored, int32_t* qsel,
+                                      int32_t* nflag, hipStream_t s) {
+    if (!filter_refine_can_fuse(a) || k < 1 || k > 64) return hipErrorInvalidValue;
+    const size_t lds = (size_t)a.ld * sizeof(double) + 65 * sizeof(double) + 64 * 4 + 256 * 4 + 24 * 4 + (size_t)kCandCap * 4 +
+                       (size_t)kCandCap * sizeof(CandEntry);
+    auto kern = a.space == kSpaceL2 ? filter_refine_thr_kernel<kSpaceL2, true>
+                : a.space == kSpaceCosine ? filter_refine_thr_kernel<kSpaceCosine, true> : filter_refine_thr_kernel<kSpaceIp, true>;
+    static std::atomic<uint64_t> configured[3];
+    if (hipError_t e = ensure_dynamic_lds(configured[a.space], reinterpret_cast<const void*>(kern), 160 * 1024); e != hipSuccess)
+        return e;
+    const char* pv = getenv("MLVDB_REFINE_PICKS");
+    int picks = pv ? atoi(pv) : k + k / 2;
+    if (!pv && picks < 16) picks = 16;
+    picks = picks < k ? k : (picks > 64 ? 64 : picks);
+    FinishOut fo{q0, out_labels, out_dist, out_counts, out_d64, rescored, qsel, nflag};
+    kern<<<a.nq, 256, lds, s>>>(a, k, -1, true, picks, fo);
     return hipGetLastError();
 }
 
