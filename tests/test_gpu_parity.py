@@ -379,6 +379,55 @@ def test_wide_rows_through_the_filter_agree_with_oracle(space, d, nq):
     assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"wide/{space}/d{d}/nq{nq}")
 
 
+SMALL_KNOBS = [
+    {},                                 # round 3's default for 1-2 queries: exact prefix seed + fused last refine / rescoring / ranking
+    {"MLVDB_SMALL_SEED": "0"},          # dense int8 seeding pass + refine, fused finish
+    {"MLVDB_SMALL_FINISH": "0"},        # prefix seed, the three finishing kernels
+    {"MLVDB_SMALL_NQ": "0"},            # round 2's structure
+    {"MLVDB_SMALL_NQ": "8"},            # both steps for up to 8 queries
+]
+SMALL_CASES = [
+    # space, d, nq, n, k, deleted_frac  (d % 256 == 0: the int8 shadow, which the small-batch steps need)
+    ("cosine", 768, 1, 70_003, 10, 0.05), ("cosine", 768, 2, 70_003, 10, 0.05), ("l2", 768, 1, 40_001, 10, 0.3),
+    ("ip", 256, 2, 150_001, 1, 0.0), ("l2", 1536, 1, 33_001, 64, 0.05), ("cosine", 256, 1, 150_001, 33, 0.9),
+    ("ip", 768, 1, 3_000, 10, 0.05),     # fewer rows than the seed prefix
+    ("l2", 256, 2, 9_000, 64, 0.995),    # fewer than k live rows in the prefix (and 45 in all)
+    ("cosine", 768, 5, 70_003, 10, 0.05), ("l2", 768, 8, 40_001, 10, 0.05),  # 3-8 queries: default structure unless SMALL_NQ=8
+]
+
+
+@pytest.mark.parametrize("knobs", SMALL_KNOBS, ids=lambda v: ",".join(f"{k[6:]}={x}" for k, x in v.items()) or "default")
+@pytest.mark.parametrize("space,d,nq,n,k,frac", SMALL_CASES)
+def test_batches_of_one_or_two_queries_agree_with_oracle(space, d, nq, n, k, frac, knobs, monkeypatch):
+    """The small-batch steps of the filter path (api.hip run_filter_pass: prefix_exact_kernel + filter_prefix_thr_kernel seed,
+    launch_filter_finish_small) against the oracle, each switched off in turn: ragged tiles, tombstones up to 99.5 %, duplicates,
+    k = 1 / 33 / 64, corpora smaller than the prefix."""
+    for key, val in knobs.items():
+        monkeypatch.setenv(key, val)
+    rows, qs = make_case(900 + d + nq + k, n, d, nq, dup=True)
+    deleted = deleted_mask(13, n, frac)
+    got, stats = run_hip(rows, qs, k, space, "filter", deleted, append_chunks=3)
+    assert stats["strategy_used"] == 2 and stats["fallback_queries"] == 0 and stats["bound_dtype"] == 2
+    assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"small {knobs}/{space}/d{d}/nq{nq}/k{k}")
+
+
+@pytest.mark.parametrize("copies,expect_fallback", [(3_000, False), (12_000, True)])
+def test_one_query_among_thousands_of_equal_rows(copies, expect_fallback):
+    """A corpus holding `copies` identical rows next to the query: 3,000 of them survive every bound (the fused finish ranks a
+    list longer than its LDS table: the per-wave top-k path), 12,000 overflow the candidate list (the query goes to the exact
+    scan, decided on the device).  Either way the answer is the oracle's: the lowest labels among the equal rows."""
+    n, d, k = 60_000, 256, 10
+    rows, qs = make_case(4242, n, d, 1)
+    near = qs[0] + 0.01 * np.random.default_rng(5).standard_normal(d).astype(np.float32)
+    where = np.random.default_rng(6).choice(np.arange(5_000, n), size=copies, replace=False)
+    rows[where] = near
+    got, stats = run_hip(rows, qs, k, "cosine", "filter", None, append_chunks=2)
+    assert stats["strategy_used"] == 2 and (stats["fallback_queries"] > 0) == expect_fallback, stats
+    want = oracle_knn(qs, rows, k, "cosine")
+    assert_knn_matches(got, want, f"equal rows x{copies}")
+    assert np.array_equal(got[0][0], np.sort(where)[:k])
+
+
 @pytest.mark.parametrize("variant", SCAN_VARIANTS, ids=lambda v: ",".join(f"{k[6:]}={x}" for k, x in v.items()) or "default")
 @pytest.mark.parametrize("space,d", [("cosine", 128), ("l2", 192), ("ip", 64), ("cosine", 768), ("l2", 1536), ("ip", 768), ("l2", 256)])
 def test_scan_kernel_variants_agree_with_oracle(variant, space, d, monkeypatch):
