@@ -479,7 +479,8 @@ def test_device_compaction_equals_a_fresh_index_of_the_survivors(space, d, strat
 
 
 @pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
-@pytest.mark.parametrize("strategy,n,d,nq", [("filter", 60_000, 128, 40), ("exact", 3000, 20, 5), ("filter", 9000, 768, 300)])
+@pytest.mark.parametrize("strategy,n,d,nq", [("filter", 60_000, 128, 40), ("exact", 3000, 20, 5), ("filter", 9000, 768, 300),
+                                             ("filter", 30_000, 256, 1), ("filter", 30_000, 768, 2)])  # (1-2 queries: the fused finish under a mask)
 def test_row_mask_search_matches_oracle(space, strategy, n, d, nq):
     """mlvdb_search_batch_filtered: the exact top-k among the allowed, live rows (mask of a metadata filter),
     including masks that allow fewer than k rows and masks that allow nothing; the index itself is unchanged."""
