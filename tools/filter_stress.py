@@ -14,6 +14,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=60)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--max-rows", type=int, default=200_000)
+ap.add_argument("--batches", default="1,3,8,9,40,256,300", help="batch sizes drawn from")
+ap.add_argument("--dims", default="256,512,768,1024,320,128", help="dimensions drawn from")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 
@@ -44,9 +46,9 @@ bad = 0
 t0 = time.time()
 for case in range(args.cases):
     kind, qkind = KINDS[rng.integers(len(KINDS))], KINDS[rng.integers(len(KINDS))]
-    d = int(rng.choice([256, 512, 768, 1024, 320, 128]))
+    d = int(rng.choice([int(x) for x in args.dims.split(",")]))
     n = int(rng.integers(20_000, args.max_rows))
-    nq = int(rng.choice([1, 3, 8, 9, 40, 256, 300]))
+    nq = int(rng.choice([int(x) for x in args.batches.split(",")]))
     k = int(rng.choice([1, 5, 10, 64]))
     space = str(rng.choice(["cosine", "l2", "ip"]))
     rows = draw(kind, n, d)
