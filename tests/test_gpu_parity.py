@@ -367,7 +367,9 @@ def test_small_batches_through_the_filter_agree_with_oracle(space, d, nq, n, nar
     assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"narrow={narrow}/{space}/d{d}/nq{nq}")
 
 
-@pytest.mark.parametrize("space,d,nq", [("cosine", 4096, 40), ("l2", 2560, 70), ("ip", 8192, 20), ("cosine", 8192, 3)])
+@pytest.mark.parametrize("space,d,nq", [("cosine", 4096, 40), ("l2", 2560, 70), ("ip", 8192, 20), ("cosine", 8192, 3),
+                                        # 1-2 queries: the prefix seed with a 64 KB query in LDS; the fused finish at and beyond its ld = 2048 limit
+                                        ("l2", 8192, 1), ("cosine", 4096, 2), ("ip", 2048, 1), ("cosine", 2304, 2)])
 def test_wide_rows_through_the_filter_agree_with_oracle(space, d, nq):
     """dim up to the 8192 limit on the int8 path: the dense seeding pass groups fewer queries per workgroup when their int8 image
     no longer fits LDS at 64 (32 beyond ld = 2304, 16 beyond 4736), the refine cannot fuse the pruning beyond ld = 2048."""
