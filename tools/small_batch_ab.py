@@ -17,6 +17,7 @@ ap.add_argument("--space", default="cosine")
 ap.add_argument("--batches", default="1,2,4,8,12,16,32,64")
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--modes", default="exact,narrow,pass256,auto")
+ap.add_argument("--spin", action="store_true", help="wait for the call by polling the stream (hipStreamQuery) instead of hipStreamSynchronize")
 args = ap.parse_args()
 N, D, K = args.rows, args.dim, 10
 eng = HipScanEngine(D, args.space, device=0, capacity_hint=N)
@@ -40,7 +41,13 @@ for nq in batches:
         for i in range(args.iters + 5):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             eng.search_device(q.data_ptr(), nq, K, lab.data_ptr(), dst.data_ptr(), cnt.data_ptr(), 0, 0)
-            torch.cuda.synchronize(); lat.append(time.perf_counter() - t0)
+            if args.spin:
+                st = torch.cuda.current_stream()
+                while not st.query():
+                    pass
+            else:
+                torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
         ids = lab[:nq].cpu().numpy().copy()
         if ref is None:
             ref = ids
