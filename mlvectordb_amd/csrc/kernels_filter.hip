@@ -2472,7 +2472,7 @@ bool filter_narrow_ok(const FilterArgs& a) {
     if (env_int("MLVDB_SCAN_NARROW", 1) == 0) return false;
     // int8 bounds admit ~7x more rows than bf16 ones and this kernel appends them one atomic at a time: beyond 8
     // queries the 256-query body (appends staged per wave) is faster (profiles/r01/small_batch_ab_10m_i8.txt)
-    if (a.X8 && a.nq > 8) return false;
+    if (a.X8 && a.nq > env_int("MLVDB_NARROW_I8_MAX", 8)) return false;  // (tuning: the largest batch the int8 narrow kernel takes)
     return narrow_lds(a.ld, narrow_nqt(a.nq), 8, a.X8 != nullptr) <= kNarrowLdsMax;
 }
 template <int SPACE, int NQT, bool DENSE, int R, int NW, bool I8 = false>
