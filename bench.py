@@ -78,6 +78,8 @@ def parse_args():
     ap.add_argument("--tombstones", type=float, default=0.0,
                     help="secondary run (SURVEY 8d): tombstone this fraction of every shard's rows, default_rng(99), before searching")
     ap.add_argument("--gen-threads", type=int, default=0)
+    ap.add_argument("--wave-mode", choices=["synchronised", "back_to_back"], default="synchronised",
+                    help="N=1: what the timed K steps do between waves (both are measured; this one is `ms_per_step` / `value`)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (gloo for single-device rehearsals)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--in-process", action="store_true",
@@ -480,13 +482,43 @@ def main() -> None:
     eng.last_stats()  # start a fresh statistics window
     eng.set_profiling(os.environ.get("MLVDB_BENCH_NO_EVENTS") != "1")  # HIP events on the launch stream around every scan-kernel launch
     #                                                                     (=1: tuning only -- what the events themselves cost; no roofline then)
+    # N = 1 times the K steps twice, each region bracketed by barrier + synchronize: once with the waves enqueued back to back
+    # (the host never waits inside the region) and once with the host synchronising after every wave, as a caller that consumes
+    # each wave's answer does.  The synchronised loop is the FASTER one on this hardware -- the ~30 us the GPU idles between waves
+    # let its clock recover, the MFMA-heavy scan then runs 5-6 % shorter -- and it is the line's `ms_per_step` /
+    # `value` (--wave-mode back_to_back swaps the two); the other region's figure stays beside it, scan-kernel events included.
+    host_enqueue_s = None
+    other = None
+    if world == 1:
+        def region(synchronised):
+            eng.last_stats()  # fresh statistics window
+            barrier()
+            t0 = time.perf_counter()
+            enq = None
+            for _ in range(args.steps):
+                step()
+                if synchronised:
+                    torch.cuda.current_stream().synchronize()
+            if not synchronised:
+                enq = time.perf_counter() - t0  # how long the host took to enqueue the K waves (it must stay ahead of the GPU)
+            barrier()
+            return time.perf_counter() - t0, enq, eng.last_stats()
+
+        primary_sync = args.wave_mode == "synchronised"
+        el_o, enq_o, st_o = region(not primary_sync)
+        host_enqueue_s = enq_o
+        other = {"wave_mode": "back_to_back" if primary_sync else "synchronised", "ms_per_step": round(el_o / args.steps * 1e3, 3),
+                 "value": round(batch * args.steps / el_o, 1),
+                 "scan_avg_launch_ms": round(st_o["scan_ms"] / max(1, st_o["scan_launches"]), 4)}
     barrier()
     t_start = time.perf_counter()
-    host_enqueue_s = None
     if world == 1:
         for _ in range(args.steps):
-            step()  # waves are enqueued back to back, the host never waits inside the timed region
-        host_enqueue_s = time.perf_counter() - t_start  # how long the host took to enqueue the K waves (it must stay ahead of the GPU)
+            step()
+            if primary_sync:
+                torch.cuda.current_stream().synchronize()  # the caller has this wave's answer before it sends the next
+        if not primary_sync:
+            host_enqueue_s = time.perf_counter() - t_start
     else:
         last = None
         enqueue(0)
@@ -600,6 +632,8 @@ def main() -> None:
                    "sharding": f"row-wise over {world} ranks, host merge of per-shard top-k"},
         "whole_corpus_qps": round(batch * args.steps / elapsed, 1),
         "host_enqueue_ms_per_wave": round(host_enqueue_s / args.steps * 1e3, 3) if host_enqueue_s is not None else None,
+        "wave_mode": (args.wave_mode if world == 1 else "pipelined (wave i+1 enqueued before wave i is gathered and merged)"),
+        "other_wave_mode": other,
         "p50_ms_per_wave": round(float(np.median(per_step)) * 1e3, 3),
         "p50_ms_per_wave_host_io": round(float(np.median(per_step_io)) * 1e3, 3) if per_step_io else None,
         "roofline": roofline,

@@ -189,6 +189,15 @@ int reserve_rows(mlvdb_index* h, int64_t rows) {
 // ---- profiling helpers
 // Statistics accumulate over calls until mlvdb_index_last_stats reads (and resets) them, so a
 // caller can enqueue many query waves without synchronising and still get per-kernel times.
+// Timing-only events (profiling): created without the system-scope fence an event record otherwise carries -- the cache
+// write-back / invalidate it costs sits between the kernels of the pass being measured (hip_runtime_api.h,
+// hipEventDisableSystemFence: "events that are only being used to measure timing").  Nothing synchronises-with these events:
+// results are read after a stream synchronisation.  MLVDB_EVENT_FENCE=1: default events (A/B).
+static hipError_t create_timing_event(hipEvent_t* ev) {
+    static const bool fence = [] { const char* e = getenv("MLVDB_EVENT_FENCE"); return e && e[0] == '1'; }();
+    return fence ? hipEventCreate(ev) : hipEventCreateWithFlags(ev, hipEventDisableSystemFence);
+}
+
 int begin_call(mlvdb_index* h, hipStream_t s) {
     if (h->scan_events_used > 8192) {  // nobody is reading them: start over rather than grow forever
         h->scan_events_used = 0;
@@ -197,7 +206,7 @@ int begin_call(mlvdb_index* h, hipStream_t s) {
     }
     if (h->profiling && !h->stats_pending) {
         for (auto& ev : h->total_events)
-            if (!ev) HIP_TRY(h, hipEventCreate(&ev));
+            if (!ev) HIP_TRY(h, create_timing_event(&ev));
         HIP_TRY(h, hipEventRecord(h->total_events[0], s));
     }
     return MLVDB_OK;
@@ -216,8 +225,8 @@ int scan_event(mlvdb_index* h, hipStream_t s, bool start) {
     if (start) {
         if (h->scan_events_used == h->scan_events.size()) {
             hipEvent_t a = nullptr, b = nullptr;
-            HIP_TRY(h, hipEventCreate(&a));
-            HIP_TRY(h, hipEventCreate(&b));
+            HIP_TRY(h, create_timing_event(&a));
+            HIP_TRY(h, create_timing_event(&b));
             h->scan_events.emplace_back(a, b);
         }
         HIP_TRY(h, hipEventRecord(h->scan_events[h->scan_events_used].first, s));

@@ -42,3 +42,7 @@ def test_one_gpu_line_has_the_contract_keys_on_a_small_shard():
     assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] <= 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and "find_similar_many" in d["cpu_baseline"]["sample"]
     assert d["parity_gate"]["filter_equals_exact_scan_ids"] and d["parity_gate"]["oracle_ids_equal"]
+    # the K steps are timed twice at N = 1: synchronised wave by wave (the line's figure) and enqueued back to back (beside it)
+    other = d["other_wave_mode"]
+    assert d["wave_mode"] == "synchronised" and other["wave_mode"] == "back_to_back" and other["ms_per_step"] > 0
+    assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
