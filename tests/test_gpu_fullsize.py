@@ -119,6 +119,14 @@ def test_config3_10m_cosine_all_256_queries_equal_the_exact_scan(engine_10m_cosi
     assert (cf == K).all() and (lf >= 0).all() and (lf < N10).all()
     assert (np.diff(df, axis=1) >= 0).all()
     assert lf[:len(PLANT), 0].tolist() == PLANT
+    # batches of 1 and 2 queries on the same 10M rows (round 3: exact prefix seed, three narrow scan rounds, fused finish):
+    # a query's answer does not depend on the batch it rides in
+    eng.set_strategy("auto")
+    for lo, hi in ((200, 201), (3, 5), (0, 1)):
+        l1, d1, c1 = eng.search(qs[lo:hi], K)
+        st1 = eng.last_stats()
+        assert st1["strategy_used"] == 2 and st1["bound_dtype"] == 2 and st1["fallback_queries"] == 0, st1
+        assert np.array_equal(l1, lf[lo:hi]) and np.array_equal(d1, df[lo:hi]) and (c1 == K).all()
     # ... and against the NumPy ORACLE itself at the full 10M rows, for 8 of the queries (the planted ones + one plain): the fp64
     # oracle scans the regenerated 1M-row chunks one by one and the per-chunk top-k are merged by (fp64 distance, label), so the
     # headline-size answer is oracle-pinned too, not only pinned through the GPU's exact scan (about a minute of host NumPy)
@@ -172,6 +180,10 @@ def test_config4_10m_l2_knn_and_range_equal_the_exact_scans(engine_10m_l2):
     assert st["strategy_used"] == 2 and st["scan_launches"] == 3 and st["fallback_queries"] == 0
     _assert_identical(got, want, "10M/l2")
     assert got[0][:len(PLANT), 0].tolist() == PLANT
+    for lo, hi in ((200, 201), (5, 7)):  # batches of 1 and 2 queries (the small-batch steps on the l2 arithmetic)
+        l1, d1, c1 = eng.search(qs[lo:hi], K)
+        assert eng.last_stats()["strategy_used"] == 2 and eng.last_stats()["fallback_queries"] == 0
+        assert np.array_equal(l1, got[0][lo:hi]) and np.array_equal(d1, got[1][lo:hi])
     # range query at the mean 10th-neighbour distance: filter path vs the exact range scan
     radius = float(got[1][len(PLANT):, K - 1].mean())
     eng.set_strategy("auto")
