@@ -46,3 +46,9 @@ def test_one_gpu_line_has_the_contract_keys_on_a_small_shard():
     other = d["other_wave_mode"]
     assert d["wave_mode"] == "synchronised" and other["wave_mode"] == "back_to_back" and other["ms_per_step"] > 0
     assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+
+
+def test_back_to_back_wave_mode_swaps_the_two_timed_regions():
+    d = _run(["--rows-per-gpu", "300000", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline", "--wave-mode", "back_to_back"])
+    assert d["wave_mode"] == "back_to_back" and d["other_wave_mode"]["wave_mode"] == "synchronised"
+    assert d["host_enqueue_ms_per_wave"] > 0 and d["parity_gate"]["filter_equals_exact_scan_ids"]
