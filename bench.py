@@ -80,6 +80,10 @@ def parse_args():
     ap.add_argument("--gen-threads", type=int, default=0)
     ap.add_argument("--wave-mode", choices=["synchronised", "back_to_back"], default="synchronised",
                     help="N=1: what the timed K steps do between waves (both are measured; this one is `ms_per_step` / `value`)")
+    ap.add_argument("--query-batches", type=int, default=8,
+                    help="distinct seeded query batches the timed loops rotate through (each gated once, untimed)")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="N=1: also time >= this many seconds (and >= 1000 waves) in both wave modes (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (gloo for single-device rehearsals)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--in-process", action="store_true",
@@ -350,20 +354,29 @@ def main() -> None:
     load_s = time.perf_counter() - t0
     log(f"shard rows [{row0}, {row0 + n_local}) resident after {load_s:.1f} s ({threads} generator threads)")
 
-    q_host = synth.queries(batch, d)
-    q_dev = torch.from_numpy(q_host).to(dev)
+    # Query batches: batch 0 is SURVEY 8d's default_rng(4321); every timed loop rotates through all of them, so thresholds,
+    # candidate counts and branch behaviour are not those of one draw.  Each batch passes the parity gate once, untimed.
+    nqb = max(1, args.query_batches)
+    q_hosts = [synth.queries(batch, d, i) for i in range(nqb)]
+    q_devs = [torch.from_numpy(q).to(dev) for q in q_hosts]
+    q_host, q_dev = q_hosts[0], q_devs[0]
     lab = torch.empty((batch, k), dtype=torch.int64, device=dev)
     dst = torch.empty((batch, k), dtype=torch.float32, device=dev)
     cnt = torch.empty(batch, dtype=torch.int32, device=dev)
     d64 = torch.empty((batch, k), dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def local_wave():
-        eng.search_device(q_dev.data_ptr(), batch, k, lab.data_ptr(), dst.data_ptr(), cnt.data_ptr(),
+    wave_no = [0]
+
+    def local_wave(qi=None):
+        if qi is None:  # the timed loops: the next batch in rotation
+            qi = wave_no[0] % nqb
+            wave_no[0] += 1
+        eng.search_device(q_devs[qi].data_ptr(), batch, k, lab.data_ptr(), dst.data_ptr(), cnt.data_ptr(),
                           d64.data_ptr(), stream)
 
-    def step():
-        local_wave()
+    def step(qi=None):
+        local_wave(qi)
         if world == 1:
             return None
         torch.cuda.current_stream().synchronize()
@@ -392,7 +405,7 @@ def main() -> None:
 
         def enqueue(i):
             b = slots[i % 2]
-            eng.search_device(q_dev.data_ptr(), batch, k, b["lab"].data_ptr(), b["dst"].data_ptr(), b["cnt"].data_ptr(),
+            eng.search_device(q_devs[i % nqb].data_ptr(), batch, k, b["lab"].data_ptr(), b["dst"].data_ptr(), b["cnt"].data_ptr(),
                               b["d64"].data_ptr(), stream)
             b["ev"].record()
 
@@ -416,18 +429,20 @@ def main() -> None:
             return None
 
     # ---- parity gate (untimed): ids must equal the exact fp64 GPU scan, and the oracle on a sample
-    verify = {}
-    local_wave()
-    torch.cuda.synchronize()
-    stats0 = eng.last_stats()
-    fast_ids = lab.cpu().numpy().copy()
-    fast_dist = dst.cpu().numpy().copy()
-    eng.set_strategy("exact")
-    ex_l, ex_d, _ = eng.search(q_host, k)  # every query of the wave against the exact fp64 scan of the whole shard
-    eng.set_strategy(args.strategy)
-    verify["queries_compared"] = int(batch)
-    verify["filter_equals_exact_scan_ids"] = bool(np.array_equal(fast_ids, ex_l))
-    verify["filter_equals_exact_scan_max_abs_err"] = float(np.abs(fast_dist - ex_d).max())
+    verify = {"query_batches": nqb, "filter_equals_exact_scan_ids": True, "filter_equals_exact_scan_max_abs_err": 0.0}
+    for qi in range(nqb - 1, -1, -1):  # (batch 0 last: its answer stays in fast_ids for the protocol-level check below)
+        local_wave(qi)
+        torch.cuda.synchronize()
+        stats0 = eng.last_stats()
+        fast_ids = lab.cpu().numpy().copy()
+        fast_dist = dst.cpu().numpy().copy()
+        eng.set_strategy("exact")
+        ex_l, ex_d, _ = eng.search(q_hosts[qi], k)  # every query of the wave against the exact fp64 scan of the whole shard
+        eng.set_strategy(args.strategy)
+        verify["filter_equals_exact_scan_ids"] &= bool(np.array_equal(fast_ids, ex_l))
+        verify["filter_equals_exact_scan_max_abs_err"] = max(verify["filter_equals_exact_scan_max_abs_err"],
+                                                             float(np.abs(fast_dist - ex_d).max()))
+    verify["queries_compared"] = int(batch) * nqb
     if rank == 0 and sample_rows is not None:
         from oracle import exact_scan
 
@@ -444,9 +459,9 @@ def main() -> None:
         verify["oracle_max_abs_err"] = float(np.abs(sd - od).max())
     if world > 1:
         # sharded path: the host-merged answer of the filter strategy must equal the merged exact scans
-        merged_fast = step()
+        merged_fast = step(0)
         eng.set_strategy("exact")
-        merged_exact = step()
+        merged_exact = step(0)
         eng.set_strategy(args.strategy)
         if rank == 0:
             verify["sharded_merge_equals_exact_ids"] = bool(np.array_equal(merged_fast[0], merged_exact[0]))
@@ -531,6 +546,30 @@ def main() -> None:
     st = eng.last_stats()  # accumulated over the K steps (HIP events of every scan launch)
     scan_ms, scan_launches, rows_scanned = st["scan_ms"], st["scan_launches"], st["rows_scanned"]
     rescored, fallbacks = st["candidates_rescored"], st["fallback_queries"]
+    # ---- sustained rate (N = 1): the K timed steps above are a 40 ms burst on a power-limited kernel; a server gets the
+    # rate the chip holds for seconds.  Both wave modes again, >= --sustained-seconds and >= 1000 waves each, same rotation of
+    # query batches, scan-kernel events on (what the first seconds of load cost in clock shows in scan_avg_launch_ms).
+    sustained = None
+    if world == 1 and args.sustained_seconds > 0:
+        n_sus = max(1000, int(args.sustained_seconds * 1.1 / max(elapsed / args.steps, 1e-4)) + 1)
+        sustained = {"waves_per_mode": n_sus, "query_batches": nqb,
+                     "effective_clock_ghz": None,
+                     "effective_clock_note": "GRBM_GUI_ACTIVE is a rocprofv3 PMC counter: not readable in-process; "
+                                             "profiles/r04/ holds the counter passes of this command"}
+        for mode in ("synchronised", "back_to_back"):
+            eng.last_stats()
+            barrier()
+            ts = time.perf_counter()
+            for _ in range(n_sus):
+                step()
+                if mode == "synchronised":
+                    torch.cuda.current_stream().synchronize()
+            barrier()
+            el = time.perf_counter() - ts
+            ss = eng.last_stats()
+            sustained[mode] = {"ms_per_step": round(el / n_sus * 1e3, 3), "value": round(batch * n_sus / el, 1),
+                               "seconds": round(el, 2),
+                               "scan_avg_launch_ms": round(ss["scan_ms"] / max(1, ss["scan_launches"]), 4)}
     eng.set_profiling(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
@@ -579,20 +618,26 @@ def main() -> None:
         # measured HBM traffic: rocprofv3 PMC passes of this same command (separate runs; counters cannot be read from
         # inside the process).  The file records the hash of the kernel sources it was measured on: stale = ignored.
         traffic, tsrc = None, None
-        tfile = ROOT / "profiles" / "r03" / ("pmc_traffic_i8.json" if i8 else "pmc_traffic.json")
+        tfile = ROOT / "profiles" / "r04" / ("pmc_traffic_i8.json" if i8 else "pmc_traffic.json")
         if filt and n_local == 10_000_000 and d == 768 and tfile.exists():
             tj = json.loads(tfile.read_text())
             if tj.get("kernel_source_sha16") == kernel_source_sha16():
                 traffic = tj["traffic_bytes_per_launch_avg"]
-                tsrc = f"profiles/r03/{tfile.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same kernel sources)"
+                tsrc = f"profiles/r04/{tfile.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same kernel sources)"
             else:
-                tsrc = f"profiles/r03/{tfile.name} is stale (kernel sources changed since it was measured): not reported"
+                tsrc = f"profiles/r04/{tfile.name} is stale (kernel sources changed since it was measured): not reported"
         if bound == "mfma":
             achieved, peak, unit = flops / scan_s / 1e12, mfma_peak / 1e12, "TFLOP/s"
         else:
             achieved, peak, unit = min_bytes / scan_s / 1e9, HBM_PEAK_GBS, "GB/s"
         roofline = {"bound": bound, "achieved": round(achieved, 1), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": tsrc,
+                    "frac": round(achieved / peak, 4),
+                    # what `frac` counts: the bytes this kernel streams -- the int8 / bf16 shadow + row constants
+                    # + query image -- not SURVEY 8(d)'s fp32 corpus bytes, whose fraction is `alg_frac` beside it
+                    "frac_basis": (("int8" if i8 else "bf16") + " shadow bytes") if filt else "fp32 corpus bytes (= SURVEY 8d)",
+                    "alg_frac": round(alg_bytes_scan / scan_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "alg_frac_basis": "SURVEY 8(d): rows x (d x 4 + 4) B of the fp32 corpus per scan launch (> 1: a narrower shadow is streamed)",
+                    "traffic": traffic, "traffic_source": tsrc,
                     "kernel": "filter_scan_asm_kernel" if filt else "exact_scan_kernel",
                     "operand_dtype": ("i8" if i8 else "bf16") if filt else "f32->f64",
                     "avg_launch_ms": round(scan_ms / max(1, scan_launches), 4), "launches": scan_launches,
@@ -634,6 +679,11 @@ def main() -> None:
         "host_enqueue_ms_per_wave": round(host_enqueue_s / args.steps * 1e3, 3) if host_enqueue_s is not None else None,
         "wave_mode": (args.wave_mode if world == 1 else "pipelined (wave i+1 enqueued before wave i is gathered and merged)"),
         "other_wave_mode": other,
+        # stable keys: the same two definitions every round, whichever of them `value` is.  `value` was the
+        # back-to-back figure until round 2 and is the synchronised one since the end of round 3.
+        "value_back_to_back": (round(shard_queries_per_s, 1) if args.wave_mode == "back_to_back" else other["value"]) if world == 1 else None,
+        "value_synchronised": (round(shard_queries_per_s, 1) if args.wave_mode == "synchronised" else other["value"]) if world == 1 else None,
+        "sustained": sustained,
         "p50_ms_per_wave": round(float(np.median(per_step)) * 1e3, 3),
         "p50_ms_per_wave_host_io": round(float(np.median(per_step_io)) * 1e3, 3) if per_step_io else None,
         "roofline": roofline,
@@ -731,6 +781,41 @@ def main() -> None:
             out["config2_1Mx768_batch1"] = side
         if not args.no_extras:
             out["config1_10kx128_find_similar"] = config1_side(local_rank)
+    # ---- top_k = 100 (top_k 65..1024 stays on the filter path): one wave of the same batch, gated against
+    # the exact scan for every query, timed device-resident like p50_ms_per_wave
+    if world == 1 and not args.no_extras and args.tombstones == 0.0:
+        k2 = 100
+        lab2 = torch.empty((batch, k2), dtype=torch.int64, device=dev)
+        dst2 = torch.empty((batch, k2), dtype=torch.float32, device=dev)
+        eng.last_stats()
+        t100 = []
+        for i in range(8):
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            eng.search_device(q_devs[i % nqb].data_ptr(), batch, k2, lab2.data_ptr(), dst2.data_ptr(), cnt.data_ptr(), 0, stream)
+            torch.cuda.current_stream().synchronize()
+            t100.append(time.perf_counter() - ts)
+        st100 = eng.last_stats()
+        eng.search_device(q_dev.data_ptr(), batch, k2, lab2.data_ptr(), dst2.data_ptr(), cnt.data_ptr(), 0, stream)
+        torch.cuda.current_stream().synchronize()
+        l100, d100 = lab2.cpu().numpy(), dst2.cpu().numpy()
+        eng.set_strategy("exact")
+        xl, xd, _ = eng.search(q_host, k2)
+        eng.set_strategy(args.strategy)
+        ms100 = float(np.median(t100[2:])) * 1e3
+        out["topk100_ms_per_wave"] = round(ms100, 3)
+        out["topk100"] = {"over_k10_p50": round(ms100 / out["p50_ms_per_wave"], 3),
+                          "strategy": {1: "exact (paged)", 2: "filter"}.get(st100["strategy_used"], "?"),
+                          "candidates_rescored_per_query": round(st100["candidates_rescored"] / (8 * batch), 1),
+                          "fallback_queries": int(st100["fallback_queries"]),
+                          "ids_equal_exact_scan_all_queries": bool(np.array_equal(l100, xl)),
+                          "max_abs_err": float(np.abs(d100 - xd).max())}
+        if not out["topk100"]["ids_equal_exact_scan_all_queries"] or out["topk100"]["max_abs_err"] > 1e-5:
+            log(f"PARITY GATE FAILED (top_k = 100): {out['topk100']}")
+            out["value"] = None
+            out["error"] = "top_k = 100 results differ from the exact scan"
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+            sys.exit(1)
     # ---- the same workload through the Protocol surface: QueryProcessor.find_similar_many over Index.search_many
     # (reference query_processor.py:26-49 batched).  Every hit comes back as {"id": UUID, "values": float32[d],
     # "metadata", "score"}; values are gathered from the index's rows in HBM.  "stream" = find_similar_stream: the scan

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLVDB_ABI_VERSION 4
+#define MLVDB_ABI_VERSION 5
 
 /* status codes */
 #define MLVDB_OK 0
@@ -194,6 +194,17 @@ int mlvdb_pair_distances(mlvdb_index* h, const float* queries, int64_t nq, const
 
 /* Strategy override (testing / benchmarking); default MLVDB_STRATEGY_AUTO. */
 int mlvdb_index_set_strategy(mlvdb_index* h, int32_t strategy);
+
+/*
+ * Tuning state of the handle (A/B runs and tests; every setting returns the same ids).  The MLVDB_<KEY> environment
+ * variables are read ONCE, by mlvdb_index_create; afterwards the library never consults the environment -- a caller
+ * that wants another setting on a live handle says so here: `assignment` = "KEY=VALUE" (integer value; the
+ * "MLVDB_" prefix is optional), keys as in DESIGN.md ("Tuning knobs").  Creation-time knobs (NO_SHADOW, SHADOW_BF16,
+ * I8_PAD) are refused with MLVDB_ERR_UNSUPPORTED, unknown keys with MLVDB_ERR_INVALID_ARG.
+ * No reference counterpart (hnswlib's only run-time knob is set_ef, index.py:38, which an exhaustive scan has no use for).
+ */
+int mlvdb_index_set_tuning(mlvdb_index* h, const char* assignment);
+int mlvdb_index_get_tuning(const mlvdb_index* h, const char* key, int32_t* value);
 
 /* Turn HIP-event timing of the scan kernels on/off (off by default: events add launch overhead). */
 int mlvdb_index_set_profiling(mlvdb_index* h, int32_t enabled);

@@ -18,7 +18,7 @@ SPACE_CODES = {"l2": 0, "cosine": 1, "ip": 2}
 STRATEGY_CODES = {"auto": 0, "exact": 1, "filter": 2}
 MAX_TOPK = 64
 MAX_TOPK_PAGED = 16384
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Stats(C.Structure):
@@ -59,6 +59,8 @@ SIGNATURES = {
     "mlvdb_range_batch": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int64, _P, _P, _P]),
     "mlvdb_pair_distances": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P]),
     "mlvdb_index_set_strategy": (C.c_int, [_P, C.c_int32]),
+    "mlvdb_index_set_tuning": (C.c_int, [_P, C.c_char_p]),
+    "mlvdb_index_get_tuning": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int32)]),
     "mlvdb_index_set_profiling": (C.c_int, [_P, C.c_int32]),
     "mlvdb_index_last_stats": (C.c_int, [_P, C.POINTER(Stats)]),
     "mlvdb_layout_offset": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),

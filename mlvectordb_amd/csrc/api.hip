@@ -72,12 +72,14 @@ struct PinBuf {
 struct mlvdb_index {
     int device = 0;
     int32_t dim = 0, ld = 0, space = 0;
+    int32_t ld8 = 0;      // width of the int8 shadow: round_up(ld, 256), zero padded; 0 = this index keeps none
     int32_t strategy = MLVDB_STRATEGY_AUTO;
+    Tuning tn;            // tuning state: from the environment at creation, mlvdb_index_set_tuning afterwards; never getenv later
     bool profiling = false;
     float* X = nullptr;   // panels, capacity * ld floats
     void* Xb = nullptr;   // bf16 shadow of X for the filter scan (capacity * ld bf16), or nullptr
     bool shadow = false;  // keep the bf16 shadow (decided at creation: dim % 64 == 0 and not disabled)
-    bool i8_only = false; // dim % 256 == 0 (default since round 3; MLVDB_SHADOW=bf16 at creation keeps both): no bf16 shadow, the
+    bool i8_only = false; // ld8 > 0 (default; SHADOW_BF16 at creation keeps both): no bf16 shadow, the
                           // int8 one serves every pass (1.25x instead of 1.75x the corpus in HBM); only an index whose rows
                           // quantise too badly for int8 bounds (l2 / ip, rmax8 > 0.03) converts the fp32 rows in registers
     float* rn = nullptr;  // row norms, NaN = tombstoned / not a row
@@ -142,6 +144,41 @@ int fail(mlvdb_index* h, int code, const char* what, hipError_t e = hipSuccess) 
             return fail(h, e__ == hipErrorOutOfMemory ? MLVDB_ERR_OUT_OF_MEMORY : MLVDB_ERR_HIP, #call, e__); \
     } while (0)
 
+// ---- tuning state: name table, the one environment read, KEY=VAL parsing
+struct TuningField {
+    const char* name;
+    int Tuning::*field;
+};
+const TuningField kTuningFields[] = {
+#define X(field, name, dflt) {name, &Tuning::field},
+    MLVDB_TUNING_FIELDS(X)
+#undef X
+};
+
+// mlvdb_index_create only: MLVDB_<NAME> for every field of the table (internal.h); MLVDB_SHADOW=bf16 is the historical
+// spelling of MLVDB_SHADOW_BF16=1.  Nothing else in the library reads the environment.
+Tuning tuning_from_env() {
+    Tuning t;
+    char key[80];
+    for (const TuningField& f : kTuningFields) {
+        snprintf(key, sizeof key, "MLVDB_%s", f.name);
+        if (const char* v = getenv(key)) t.*(f.field) = atoi(v);
+        if (!strcmp(f.name, "SHADOW_BF16"))
+            if (const char* v = getenv("MLVDB_SHADOW")) t.shadow_bf16 = !strcmp(v, "bf16") ? 1 : t.shadow_bf16;
+    }
+    return t;
+}
+
+const TuningField* find_tuning_field(const char* key, size_t len) {
+    if (len > 6 && !strncmp(key, "MLVDB_", 6)) {
+        key += 6;
+        len -= 6;
+    }
+    for (const TuningField& f : kTuningFields)
+        if (strlen(f.name) == len && !strncmp(f.name, key, len)) return &f;
+    return nullptr;
+}
+
 int reserve_rows(mlvdb_index* h, int64_t rows) {
     if (!h->rowerr.p) {  // largest relative bf16 rounding error of any row appended so far (0 = no rows)
         HIP_TRY(h, h->rowerr.ensure(sizeof(unsigned int)));
@@ -192,9 +229,8 @@ int reserve_rows(mlvdb_index* h, int64_t rows) {
 // Timing-only events (profiling): created without the system-scope fence an event record otherwise carries -- the cache
 // write-back / invalidate it costs sits between the kernels of the pass being measured (hip_runtime_api.h,
 // hipEventDisableSystemFence: "events that are only being used to measure timing").  Nothing synchronises-with these events:
-// results are read after a stream synchronisation.  MLVDB_EVENT_FENCE=1: default events (A/B).
-static hipError_t create_timing_event(hipEvent_t* ev) {
-    static const bool fence = [] { const char* e = getenv("MLVDB_EVENT_FENCE"); return e && e[0] == '1'; }();
+// results are read after a stream synchronisation.  Tuning EVENT_FENCE=1: default events (A/B).
+static hipError_t create_timing_event(hipEvent_t* ev, bool fence) {
     return fence ? hipEventCreate(ev) : hipEventCreateWithFlags(ev, hipEventDisableSystemFence);
 }
 
@@ -206,7 +242,7 @@ int begin_call(mlvdb_index* h, hipStream_t s) {
     }
     if (h->profiling && !h->stats_pending) {
         for (auto& ev : h->total_events)
-            if (!ev) HIP_TRY(h, create_timing_event(&ev));
+            if (!ev) HIP_TRY(h, create_timing_event(&ev, h->tn.event_fence != 0));
         HIP_TRY(h, hipEventRecord(h->total_events[0], s));
     }
     return MLVDB_OK;
@@ -225,8 +261,8 @@ int scan_event(mlvdb_index* h, hipStream_t s, bool start) {
     if (start) {
         if (h->scan_events_used == h->scan_events.size()) {
             hipEvent_t a = nullptr, b = nullptr;
-            HIP_TRY(h, create_timing_event(&a));
-            HIP_TRY(h, create_timing_event(&b));
+            HIP_TRY(h, create_timing_event(&a, h->tn.event_fence != 0));
+            HIP_TRY(h, create_timing_event(&b, h->tn.event_fence != 0));
             h->scan_events.emplace_back(a, b);
         }
         HIP_TRY(h, hipEventRecord(h->scan_events[h->scan_events_used].first, s));
@@ -245,7 +281,7 @@ int run_exact(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qa
               const int32_t* nq_sel_dev = nullptr, const double* cursor_d = nullptr,
               const int32_t* cursor_l = nullptr) {
     if (nq_sel <= 0) return MLVDB_OK;
-    ExactPlan plan = plan_exact(row_end - row_begin, h->ld, nq_sel, k);
+    ExactPlan plan = plan_exact(row_end - row_begin, h->ld, nq_sel, k, h->tn);
     if (nq_sel_dev) {
         // device-decided fallback: usually zero or a few queries are selected, so spread each query
         // tile over many blocks; blocks of unselected tiles exit at once
@@ -269,6 +305,7 @@ int run_exact(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qa
     a.cursor_d = cursor_d;
     a.cursor_l = cursor_l;
     a.partial = h->partial.as<TopEntry>();
+    a.tn = &h->tn;
     if (is_main_scan) {
         int rc = scan_event(h, s, true);
         if (rc) return rc;
@@ -298,7 +335,7 @@ __global__ void fill_empty_kernel(int64_t* labels, float* dist, int32_t* counts,
 __global__ void copy_words_kernel(const uint32_t* src, uint32_t* dst) { dst[threadIdx.x] = src[threadIdx.x]; }
 
 int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const double* qaux, const float* qerr, int32_t nq) {
-    HIP_TRY(h, h->qimg.ensure(filter_qimg_bytes(h->ld)));
+    HIP_TRY(h, h->qimg.ensure(filter_qimg_bytes((h->ld + 63) / 64 * 64)));
     {
         const void* before = h->fmisc.p;
         HIP_TRY(h, h->fmisc.ensure(8 * kFilterQueries * sizeof(uint32_t)));
@@ -312,11 +349,13 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     }
     if (!h->host_flags)
         HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&h->host_flags), kFilterQueries * sizeof(uint32_t), 0));
+    fa.tn = &h->tn;
     fa.X = h->X;
     fa.Xb = h->Xb;
     fa.rn = h->rn;
     fa.total = h->total;
     fa.ld = h->ld;
+    fa.ld8 = h->ld8;
     fa.space = h->space;
     fa.Qpad = Qpad;
     fa.qaux = qaux;
@@ -367,15 +406,16 @@ __global__ void tombstone_rp8_kernel(const int64_t* labels, int64_t n, float* rp
     if (i < n && labels[i] >= 0 && labels[i] < rows) rp8[2 * labels[i]] = rp8[2 * labels[i] + 1] = __builtin_nanf("");
 }
 
+bool i8_bounds_usable(const mlvdb_index* h);
+
 bool i8_eligible(const mlvdb_index* h) {
-    const char* env = getenv("MLVDB_I8");  // read per pass: tools/scan_ab.py switches it inside one process
-    return !(env && env[0] == '0') && (h->Xb || h->i8_only) && h->ld % 256 == 0;
+    return h->tn.i8 != 0 && (h->Xb || h->i8_only) && h->ld8 > 0;  // (tools/scan_ab.py switches I8 inside one process: set_tuning)
 }
 
 // Bring the int8 shadow up to date (rows appended since the last pass).  Must run with the index's own norms in h->rn
 // (a row-mask search swaps them for a masked copy afterwards).
 int update_i8_shadow(mlvdb_index* h, hipStream_t s) {
-    const size_t need_x8 = (size_t)h->capacity * h->ld, need_rp = (size_t)h->capacity * 2 * sizeof(float);
+    const size_t need_x8 = (size_t)h->capacity * h->ld8, need_rp = (size_t)h->capacity * 2 * sizeof(float);
     if (h->x8.bytes < need_x8 || h->rp8.bytes < need_rp || !h->rowerr8.p) {
         HIP_TRY(h, h->x8.ensure(need_x8));
         HIP_TRY(h, h->rp8.ensure(need_rp));
@@ -389,7 +429,7 @@ int update_i8_shadow(mlvdb_index* h, hipStream_t s) {
     }
     if (h->i8_rows < h->total) {
         HIP_TRY(h, launch_shadow8_rows(h->X, h->rn, h->x8.p, h->rp8.as<float>(), h->rowerr8.as<float>(), h->i8_rows, h->total,
-                                       h->ld, h->space, s));
+                                       h->ld, h->ld8, h->space, s));
         h->i8_rows = h->total;
         HIP_TRY(h, hipMemcpyAsync(&h->i8_err, h->rowerr8.p, sizeof(float), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
@@ -408,8 +448,8 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
     // One scale per row: a row with an outlier component quantises badly.  Cosine bounds carry every row's own error;
     // l2 / ip still use the index-wide maximum, which would then admit everything: beyond 0.03 (typical data sits at
     // 0.008-0.015) they keep to the bf16 shadow, whose error is relative per component.
-    if (!(h->i8_err <= (h->space == kSpaceCosine ? 0.5f : 0.03f))) return MLVDB_OK;
-    HIP_TRY(h, h->qimg8.ensure((size_t)kFilterQueries * h->ld));
+    if (!i8_bounds_usable(h)) return MLVDB_OK;
+    HIP_TRY(h, h->qimg8.ensure((size_t)kFilterQueries * h->ld8));
     HIP_TRY(h, h->sq8.ensure(kFilterQueries * sizeof(float)));
     fa.X8 = h->x8.p;
     fa.rp8 = h->mask_active ? h->rp8_masked.as<float>() : h->rp8.as<float>();  // a masked-out row is a NaN pair: "not a row"
@@ -454,12 +494,10 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
     // together (138 us for 768 MB), the exact scan of a 12k-row prefix is a latency chain on 24 workgroups (57 us), and the
     // ~3,500 candidates per query it leaves cost the ranking kernel 31 us -- more than the three 15 us refines it saves.
     {
-        const char* sb = getenv("MLVDB_SMALL_BATCH");
         const bool small = fa.X8 && nq <= 8 && !h->mask_active && h->total <= (int64_t)2500000 && filter_narrow_ok(fa) &&
-                           (sb && sb[0] == '1');
+                           h->tn.small_batch == 1;
         if (small) {
-            int64_t units = 16;  // x 768 rows
-            if (const char* v = getenv("MLVDB_SMALL_SEED")) units = std::max<int64_t>(1, atoll(v));
+            const int64_t units = std::max<int64_t>(1, h->tn.small_batch_units);  // x 768 rows
             const int64_t n_exact = std::min<int64_t>(h->total, units * kFilterTile);
             HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * k * sizeof(int64_t)));
             HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * k * sizeof(float)));
@@ -485,8 +523,7 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
     // size so that thresholds tighten early
     // rows of the dense seeding pass: a multiple of kFilterTile (the first scan round starts there), at most kSeedRows
     // (MLVDB_SEED_ROWS, in units of kFilterTile = 768 rows: tuning, read per call)
-    int64_t seed_rows = kSeedRows;
-    if (const char* v = getenv("MLVDB_SEED_ROWS")) seed_rows = std::min<int64_t>(kSeedRows, std::max<int64_t>(1, atoll(v)) * kFilterTile);
+    const int64_t seed_rows = std::min<int64_t>(kSeedRows, std::max<int64_t>(1, h->tn.seed_rows) * kFilterTile);
     const int64_t n_seed = std::min<int64_t>(h->total, seed_rows);
     int64_t first_row = seed_rows;
     {
@@ -495,21 +532,20 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
         // puts all 3840 bounds of every query into the lists + the exact-threshold refine over them; the prefix rows
         // then belong to the first scan round.  Slower: 2.16 vs 2.04 ms per 256-query wave, 0.303 vs 0.288 ms at batch 1
         // (3840 x 768 x 256 fp64 multiply-adds are not free); the dense pass stays the default.
-        const char* env = getenv("MLVDB_SEED_EXACT");
+        const bool seed_exact = h->tn.seed_exact == 1;
         // Batches of 1-2 queries (round 3): the exact k-th best of the prefix by a kernel made for it (one 16-row group per
         // wave all over the chip + a one-block selection of the k-th: 8 + 10 us) instead of the dense int8 pass + exact-threshold refine (7 + 15.5 us
         // of latency chains at batch 1); the prefix rows then belong to the first scan round.  MLVDB_SMALL_SEED=0: the dense pass.
-        const char* sm = getenv("MLVDB_SMALL_SEED");
-        int small_nq = 2;  // (4-8 queries: no gain from either step; profiles/r03/small_batch_fused_finish_and_prefix_seed_1m.txt)
-        if (const char* v = getenv("MLVDB_SMALL_NQ")) small_nq = std::max(0, std::min(8, atoi(v)));
-        if (fa.X8 && nq <= small_nq && k <= 64 && !h->mask_active && filter_narrow_ok(fa) && !(env && env[0] == '1') &&
-            !(sm && sm[0] == '0')) {
+        // (4-8 queries: no gain from either step; profiles/r03/small_batch_fused_finish_and_prefix_seed_1m.txt)
+        const int small_nq = std::max(0, std::min(8, h->tn.small_nq));
+        if (fa.X8 && nq <= small_nq && k <= 64 && !h->mask_active && filter_narrow_ok(fa) && !seed_exact &&
+            h->tn.small_seed != 0) {
             HIP_TRY(h, h->seed_d64.ensure(((size_t)kFilterQueries * 64 + (size_t)8 * kSeedRows) * sizeof(double)));
             double* d64 = h->seed_d64.as<double>();
-            HIP_TRY(h, launch_prefix_exact(h->X, fa.rn, fa.Qpad, fa.qaux, nq, (int32_t)n_seed, h->ld, h->space, d64, s));
+            HIP_TRY(h, launch_prefix_exact(h->X, fa.rn, fa.Qpad, fa.qaux, nq, (int32_t)n_seed, h->ld, h->space, d64, h->tn, s));
             HIP_TRY(h, launch_filter_prefix_thr(fa, d64, (int32_t)n_seed, k, s));
             first_row = 0;
-        } else if (env && env[0] == '1') {
+        } else if (seed_exact) {
             HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * k * sizeof(int64_t)));
             HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * k * sizeof(float)));
             HIP_TRY(h, h->seed_cnt.ensure(kFilterQueries * sizeof(int32_t)));
@@ -527,17 +563,13 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
     // (MLVDB_ROUND1 / MLVDB_ROUND2: tuning, read per call)
     // r1 = 85: 3840 + 240 tiles of 256 rows -- one tile for (nearly) every CU costs what 192 tiles did (64: +1.5 % per 10M-row
     // wave; 170: the same as 85; r2 = 1024 .. 2389: within noise, 4096: +2.5 %; profiles/r02/scan_ab_round_sizes_10m.txt)
-    int64_t r1 = 85, r2 = 2048;
-    if (const char* v = getenv("MLVDB_ROUND1")) r1 = std::max<int64_t>(6, atoll(v));
-    if (const char* v = getenv("MLVDB_ROUND2")) r2 = std::max<int64_t>(r1, atoll(v));
+    const int64_t r1 = std::max<int64_t>(6, h->tn.round1), r2 = std::max<int64_t>(r1, h->tn.round2);
     const int64_t bounds[] = {first_row, (int64_t)kFilterTile * r1, (int64_t)kFilterTile * r2, h->total};
     // Batches of 1-2 queries: the refine after the LAST round also rescores and ranks (one launch instead of three:
     // launch_filter_finish_small); MLVDB_SMALL_FINISH=0: the three kernels
     // (one block per query: at 4-8 queries the rescoring kernel's spread over the whole chip wins again -- 0.261 vs 0.247 ms at 4)
-    int small_nq = 2;
-    if (const char* v = getenv("MLVDB_SMALL_NQ")) small_nq = std::max(0, std::min(8, atoi(v)));
-    bool small_finish = fa.X8 && nq <= small_nq && k <= 64 && filter_refine_can_fuse(fa);
-    if (const char* v = getenv("MLVDB_SMALL_FINISH")) small_finish = small_finish && v[0] != '0';
+    const int small_nq = std::max(0, std::min(8, h->tn.small_nq));
+    const bool small_finish = fa.X8 && nq <= small_nq && k <= 64 && filter_refine_can_fuse(fa) && h->tn.small_finish != 0;
     bool ranked = false;
     for (int r = 0; r < 3; ++r) {
         const int64_t b = std::min(bounds[r], h->total), e = std::min(bounds[r + 1], h->total);
@@ -548,7 +580,7 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
         HIP_TRY(h, launch_filter_scan(fa, b, e, s, &info));
         rc = scan_event(h, s, false);
         if (rc) return rc;
-        if (getenv("MLVDB_DEBUG_ENTRIES")) {  // tuning aid: entries appended by this scan launch (synchronises the stream)
+        if (h->tn.debug_entries) {  // tuning aid: entries appended by this scan launch (synchronises the stream)
             std::vector<uint32_t> wc((size_t)kScanMaxGrid * 8, 0u);
             HIP_TRY(h, hipMemcpyAsync(wc.data(), fa.wgcnt, wc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
@@ -562,7 +594,7 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
                     (long long)b, (long long)e, (unsigned long long)sum, (double)sum / fa.nq, (unsigned long long)mx);
         }
 #ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1, MLVDB_SCAN_DIAG=234: where a scan launch's time goes (its waves stamp their phases)
-        if (fa.wgbuf && getenv("MLVDB_SCAN_DIAG") && atoi(getenv("MLVDB_SCAN_DIAG")) == 234) {
+        if (fa.wgbuf && h->tn.scan_diag == 234) {
             const int nwg = (int)std::min<int64_t>(256, (e - b + 255) / 256);
             std::vector<unsigned long long> st((size_t)nwg * 8 * 8, 0ull);
             HIP_TRY(h, hipMemcpyAsync(st.data(), fa.wgbuf + (size_t)256 * kWgCap, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -605,7 +637,7 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
         }
         if (fa.X8) HIP_TRY(h, launch_filter_refine_thr(fa, k, -1, fuse, s));
 #ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: where the refine kernel's time goes (its blocks stamp their phases)
-        if (fa.X8 && fa.wgbuf && getenv("MLVDB_DEBUG_REFINE")) {
+        if (fa.X8 && fa.wgbuf && h->tn.debug_refine) {
             std::vector<unsigned long long> st((size_t)fa.nq * 8, 0ull);
             HIP_TRY(h, hipMemcpyAsync(st.data(), fa.wgbuf, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
             HIP_TRY(h, hipStreamSynchronize(s));
@@ -634,7 +666,7 @@ int finish_filter_pass(mlvdb_index* h, hipStream_t s, FilterArgs& fa, int32_t q0
     // counters: [0] rescored pairs, [1] fallback queries (accumulated over the passes of a call), [2] flag count
     unsigned long long* stats = h->counters.as<unsigned long long>();
 #ifdef MLVDB_SCAN_DIAGNOSTICS
-    if (fa.wgbuf && getenv("MLVDB_DEBUG_REFINE")) HIP_TRY(h, hipMemsetAsync(fa.wgbuf, 0, (16384 + 1024) * 8, s));
+    if (fa.wgbuf && h->tn.debug_refine) HIP_TRY(h, hipMemsetAsync(fa.wgbuf, 0, (16384 + 1024) * 8, s));
 #endif
     // (its ranking kernel also compacts the overflowed queries for the device-decided fallback below: qsel, nflag)
     HIP_TRY(h, h->qsel.ensure(kFilterQueries * sizeof(int32_t)));
@@ -643,7 +675,7 @@ int finish_filter_pass(mlvdb_index* h, hipStream_t s, FilterArgs& fa, int32_t q0
         HIP_TRY(h, launch_filter_rescore(fa, k, q0, out_labels, out_dist, out_counts, out_d64, stats,
                                          defer_fallback ? nullptr : h->qsel.as<int32_t>(), nflag, s));
 #ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: where the ranking kernel's time goes (its blocks stamp their phases)
-    if (!ranked && fa.wgbuf && getenv("MLVDB_DEBUG_REFINE")) {
+    if (!ranked && fa.wgbuf && h->tn.debug_refine) {
         std::vector<unsigned long long> st(16384 + 1024, 0ull);
         HIP_TRY(h, hipMemcpyAsync(st.data(), fa.wgbuf, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
@@ -804,8 +836,31 @@ __global__ void range_resolve_kernel(uint32_t* overflow, const uint32_t* cnt, co
     overflow[q] = cnt[q] > cap ? 1u : 0u;
 }
 
-bool use_filter(const mlvdb_index* h, int64_t nq) {
-    if (h->strategy == MLVDB_STRATEGY_EXACT || !filter_supported(h->ld)) return false;
+bool i8_bounds_usable(const mlvdb_index* h) { return h->i8_err <= (h->space == kSpaceCosine ? 0.5f : 0.03f); }
+
+// Is a filter body available for this index right now?  ld % 64 == 0: always (bf16 shadow, int8 shadow, or the fp32 rows
+// converted in registers).  Any other ld has only the int8 body: the (zero-padded) int8 shadow is brought up to date here
+// and its bounds must be usable (attach_i8's criterion: l2 / ip rows that quantise too badly go to the exact scan).
+int filter_ready(mlvdb_index* h, hipStream_t s, bool* ready) {
+    *ready = false;
+    if (h->strategy == MLVDB_STRATEGY_EXACT || h->total == 0) return MLVDB_OK;
+    if (filter_supported(h->ld)) {
+        *ready = true;
+        return MLVDB_OK;
+    }
+    if (!i8_eligible(h)) return MLVDB_OK;
+    if (h->mask_active) {
+        *ready = h->mask_pairs_ready && i8_bounds_usable(h);
+        return MLVDB_OK;
+    }
+    int rc = update_i8_shadow(h, s);
+    if (rc) return rc;
+    *ready = i8_bounds_usable(h);
+    return MLVDB_OK;
+}
+
+bool use_filter(const mlvdb_index* h, int64_t nq, bool ready) {
+    if (h->strategy == MLVDB_STRATEGY_EXACT || !ready) return false;
     if (h->strategy == MLVDB_STRATEGY_FILTER) return true;
     const bool shadowed = h->Xb != nullptr || h->i8_only;
     if (nq >= 12 || (nq >= 8 && shadowed)) return h->total >= 32768;
@@ -884,14 +939,22 @@ int mlvdb_index_create(int device, int32_t dim, int32_t space, int64_t capacity_
     h->dim = dim;
     h->ld = layout_ld(dim);
     h->space = space;
+    h->tn = tuning_from_env();  // the one moment the environment is consulted
     {
-        const char* ns = getenv("MLVDB_NO_SHADOW");
-        const char* sm = getenv("MLVDB_SHADOW");
-        // Round 3: where the int8 shadow exists (dim % 256 == 0) it is the only one by default -- seeding pass, small
-        // batches of every space, scans, range and row-mask searches all run on it: 1.25x the corpus in HBM instead of
-        // 1.75x.  MLVDB_SHADOW=bf16 keeps the bf16 shadow as well (the bf16 bodies for A/B, MLVDB_I8=0).
-        h->i8_only = h->ld % 256 == 0 && !(ns && ns[0] == '1') && !(sm && !strcmp(sm, "bf16"));
-        h->shadow = filter_supported(h->ld) && !(ns && ns[0] == '1') && !h->i8_only;
+        // Which shadow the index keeps (decided here, once).  The int8 shadow has its own width ld8 = round_up(ld, 256), zero
+        // padded -- zero columns change neither a dot product nor a norm -- so every dim >= 64 gets the int8 body (round 4;
+        // I8_PAD=0: only dim % 256 == 0, round 3).  It is the only shadow wherever it streams fewer bytes per row than the
+        // bf16 one would (ld8 < 2 ld) or no bf16 body exists (ld % 64 != 0): seeding pass, small batches, scans, range and
+        // row-mask searches all run on it.  ld = 64 / 128 keep the bf16 shadow (same bytes, tighter bounds).
+        // SHADOW_BF16=1 (MLVDB_SHADOW=bf16) keeps the bf16 shadow as well (the bf16 bodies for A/B, I8=0).
+        const Tuning& tn = h->tn;
+        h->ld8 = 0;
+        if (!tn.no_shadow && dim >= 64) {
+            const int32_t cand = (h->ld + 255) / 256 * 256;
+            if (cand == h->ld || (tn.i8_pad && (cand < 2 * h->ld || !filter_supported(h->ld)))) h->ld8 = cand;
+        }
+        h->i8_only = h->ld8 > 0 && !tn.shadow_bf16;
+        h->shadow = filter_supported(h->ld) && !tn.no_shadow && !h->i8_only;
     }
     e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -1190,7 +1253,10 @@ static int search_device_impl(mlvdb_index* h, const float* queries_device, int64
     if (!h->counters_pending) HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 32, s));
     h->counters_stream = s;
     HIP_TRY(h, h->qerr.ensure((size_t)nq * sizeof(float)));
-    const bool filt = k <= MLVDB_MAX_TOPK && use_filter(h, nq);
+    bool ready = false;
+    rc = filter_ready(h, s, &ready);
+    if (rc) return rc;
+    const bool filt = k <= MLVDB_MAX_TOPK && use_filter(h, nq, ready);
     if (!filt)  // (the filter passes prepare their own queries: one fused launch each)
         HIP_TRY(h, launch_query_prep(queries_device, (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
                                      h->qaux.as<double>(), h->qerr.as<float>(), s));
@@ -1249,7 +1315,7 @@ int search_host(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, int
     // whole scan and every copy of the index's other stream -- the hit-enrichment gather of find_similar_stream -- waits
     // with it; measured on 4M rows: protocol stream 1.92 ms per wave parked vs 1.20 unparked (engine alone 1.07;
     // profiles/r03/protocol_stream_pinned_io_modes_4m.txt).  A blocking event wait instead of hipStreamSynchronize: no change.
-    static const bool pinned = [] { const char* e = getenv("MLVDB_PINNED_IO"); return !(e && e[0] == '0'); }();
+    const bool pinned = h->tn.pinned_io != 0;
     h->flags_in_out = pinned;  // the pass copies its overflow flags device-to-device behind the outputs (no parked D2H either)
     h->flags_out = reinterpret_cast<uint32_t*>(dout + ((obytes + 15) & ~(size_t)15));
     if (pinned) {
@@ -1376,7 +1442,10 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
     std::memcpy(h->pin_in.p, queries, (size_t)nq * h->dim * sizeof(float));  // pinned staging: one DMA (search_host)
     HIP_TRY(h, hipMemcpyAsync(h->io_q.p, h->pin_in.p, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(h, h->qerr.ensure((size_t)nq * sizeof(float)));
-    const bool filt = use_filter(h, nq);
+    bool ready = false;
+    rc = filter_ready(h, s, &ready);
+    if (rc) return rc;
+    const bool filt = use_filter(h, nq, ready);
     if (!filt)  // (the filter passes prepare their own queries: one fused launch each)
         HIP_TRY(h, launch_query_prep(h->io_q.as<float>(), (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
                                      h->qaux.as<double>(), h->qerr.as<float>(), s));
@@ -1398,12 +1467,9 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
         fa.rhit_cnt = h->rhit_cnt.as<uint32_t>();
         // int8 bounds (half the scan time of the bf16 body; MLVDB_RANGE_I8=0 keeps the bf16 one): their band admits
         // ~8x more candidates than there are hits, which the chunked rescoring below absorbs
-        {
-            const char* env = getenv("MLVDB_RANGE_I8");
-            if (filt && !(env && env[0] == '0')) {
-                rc = attach_i8(h, s, fa);
-                if (rc) return rc;
-            }
+        if (filt && h->tn.range_i8 != 0) {
+            rc = attach_i8(h, s, fa);
+            if (rc) return rc;
         }
         if (filt) {  // (also clears the candidate counters)
             rc = prep_pass(h, s, fa, h->io_q.as<float>() + (size_t)q0 * h->dim, h->qpad.as<float>() + (size_t)q0 * h->ld,
@@ -1566,9 +1632,37 @@ int mlvdb_index_set_strategy(mlvdb_index* h, int32_t strategy) {
     return guarded(h, [&]() -> int {
     if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");
     if (strategy < 0 || strategy > 2) return fail(h, MLVDB_ERR_INVALID_ARG, "unknown strategy");
-    if (strategy == MLVDB_STRATEGY_FILTER && !filter_supported(h->ld))
-        return fail(h, MLVDB_ERR_UNSUPPORTED, "filter strategy needs dim padded to a multiple of 64");
+    if (strategy == MLVDB_STRATEGY_FILTER && !filter_supported(h->ld) && h->ld8 == 0)
+        return fail(h, MLVDB_ERR_UNSUPPORTED, "filter strategy needs dim >= 64 (or an index created with a shadow)");
     h->strategy = strategy;
+    return MLVDB_OK;
+    });
+}
+
+int mlvdb_index_set_tuning(mlvdb_index* h, const char* assignment) {
+    return guarded(h, [&]() -> int {
+    if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");
+    const char* eq = assignment ? strchr(assignment, '=') : nullptr;
+    if (!eq || eq == assignment) return fail(h, MLVDB_ERR_INVALID_ARG, "tuning assignment must be KEY=VALUE");
+    const TuningField* f = find_tuning_field(assignment, (size_t)(eq - assignment));
+    if (!f) return fail(h, MLVDB_ERR_INVALID_ARG, "unknown tuning key");
+    if (!strcmp(f->name, "NO_SHADOW") || !strcmp(f->name, "SHADOW_BF16") || !strcmp(f->name, "I8_PAD"))
+        return fail(h, MLVDB_ERR_UNSUPPORTED, "creation-time knob: set MLVDB_<KEY> in the environment before mlvdb_index_create");
+    char* end = nullptr;
+    const long v = strtol(eq + 1, &end, 10);
+    if (end == eq + 1 || *end != '\0') return fail(h, MLVDB_ERR_INVALID_ARG, "tuning value must be an integer");
+    h->tn.*(f->field) = (int)v;
+    return MLVDB_OK;
+    });
+}
+
+int mlvdb_index_get_tuning(const mlvdb_index* h, const char* key, int32_t* value) {
+    return guarded(const_cast<mlvdb_index*>(h), [&]() -> int {
+    if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");
+    if (!key || !value) return fail(const_cast<mlvdb_index*>(h), MLVDB_ERR_INVALID_ARG, "null key / value");
+    const TuningField* f = find_tuning_field(key, strlen(key));
+    if (!f) return fail(const_cast<mlvdb_index*>(h), MLVDB_ERR_INVALID_ARG, "unknown tuning key");
+    *value = h->tn.*(f->field);
     return MLVDB_OK;
     });
 }

@@ -27,6 +27,66 @@ inline hipError_t ensure_dynamic_lds(std::atomic<uint64_t>& done, const void* ke
     return e;
 }
 
+// ---------------------------------------------------------------- tuning state (per handle)
+// Every knob the kernels' launchers and the pass orchestration consult.  Filled ONCE, by mlvdb_index_create, from the
+// MLVDB_* environment variables of that moment (tuning_from_env, api.hip: the library's only getenv loop), and changed
+// afterwards only through mlvdb_index_set_tuning(h, "KEY=VAL") -- nothing on the search path reads the environment, so
+// host threads that serve different handles (MultiDeviceEngine: one per shard) never race a setenv in glibc.
+// Variants marked [AB] exist only in `make AB=1` builds (tools/scan_ab.py, the `ab`-marked tests); the default
+// library ignores them.
+#define MLVDB_TUNING_FIELDS(X)                                                                                          \
+    X(i8, "I8", 1)                     /* 0: bf16 bodies on an index that keeps a bf16 shadow */                       \
+    X(no_shadow, "NO_SHADOW", 0)       /* creation: no shadow at all (the filter converts fp32 rows in registers) */   \
+    X(shadow_bf16, "SHADOW_BF16", 0)   /* creation: keep the bf16 shadow beside the int8 one (MLVDB_SHADOW=bf16) */    \
+    X(i8_pad, "I8_PAD", 1)             /* creation: int8 shadow zero-padded to a multiple of 256 columns for any dim */\
+    X(small_batch, "SMALL_BATCH", 0)   /* single-round path for <= 8 queries (measured slower) */                      \
+    X(small_batch_units, "SMALL_BATCH_UNITS", 16)                                                                       \
+    X(small_seed, "SMALL_SEED", 1)     /* 1-2 queries: exact prefix seed */                                             \
+    X(small_finish, "SMALL_FINISH", 1) /* 1-2 queries: fused last refine + rescoring + ranking */                       \
+    X(small_nq, "SMALL_NQ", 2)                                                                                          \
+    X(seed_rows, "SEED_ROWS", 5)       /* dense seeding pass, units of 768 rows */                                      \
+    X(seed_exact, "SEED_EXACT", 0)                                                                                      \
+    X(seed_i8, "SEED_I8", 1)                                                                                            \
+    X(round1, "ROUND1", 85)            /* ends of the first / second scan round, units of 768 rows */                   \
+    X(round2, "ROUND2", 2048)                                                                                           \
+    X(refine_picks, "REFINE_PICKS", 0) /* 0 = 1.5 k, at least 16 */                                                     \
+    X(pinned_io, "PINNED_IO", 1)                                                                                        \
+    X(event_fence, "EVENT_FENCE", 0)                                                                                    \
+    X(range_i8, "RANGE_I8", 1)                                                                                          \
+    X(range_flat, "RANGE_FLAT", 1)                                                                                      \
+    X(range_l2, "RANGE_L2", 1)         /* range passes: fp16 second-level bound before the exact gather */             \
+    X(bigk, "BIGK", 1)                 /* top_k in (64, 1024] on the filter path (0: paged exact scan) */              \
+    X(bigk_budget, "BIGK_BUDGET", 1200000) /* entries one scan launch of a big-k pass may append (sizes its rounds) */ \
+    X(l2_shadow, "L2_SHADOW", 1)       /* fp16 row-major shadow for second-level bounds (built lazily; 0: never) */    \
+    X(debug_entries, "DEBUG_ENTRIES", 0)                                                                                \
+    X(debug_refine, "DEBUG_REFINE", 0)                                                                                  \
+    X(scan_narrow, "SCAN_NARROW", 1)                                                                                    \
+    X(narrow_i8_max, "NARROW_I8_MAX", 8)                                                                                \
+    X(narrow_wgs, "NARROW_WGS", 0)     /* 0 = as many workgroups per CU as the image leaves LDS for */                  \
+    X(narrow_balance, "NARROW_BALANCE", 1)                                                                              \
+    X(scan_xcd, "SCAN_XCD", 0)                                                                                          \
+    X(scan_asm, "SCAN_ASM", 1)                                                                                          \
+    X(scan_nqt, "SCAN_NQT", 0)         /* query tiles of the int8 body: 0 = by batch size, else 4 / 8 / 16 */          \
+    X(scan_nw, "SCAN_NW", 8)           /* [AB] */                                                                       \
+    X(scan_mt, "SCAN_MT", 2)           /* [AB] */                                                                       \
+    X(scan_va, "SCAN_VA", 1)           /* [AB] 0: AccVGPR accumulators, serial admission test (round 1) */             \
+    X(scan_var, "SCAN_VAR", 0)         /* 237: round 2's body; the other codes [AB] */                                  \
+    X(scan_prio, "SCAN_PRIO", -1)      /* [AB] -1 = the body's default */                                               \
+    X(scan_nt, "SCAN_NT", 1)           /* [AB] */                                                                       \
+    X(scan_dma, "SCAN_DMA", 1)         /* [AB] */                                                                       \
+    X(scan_stag, "SCAN_STAG", 0)       /* [AB] */                                                                       \
+    X(scan_diag, "SCAN_DIAG", 0)       /* make DIAG=1 builds */                                                         \
+    X(exact_nt, "EXACT_NT", 1)                                                                                          \
+    X(exact_nblk, "EXACT_NBLK", 0)                                                                                      \
+    X(prefix_pf, "PREFIX_PF", 24)                                                                                       \
+    X(prefix_waves, "PREFIX_WAVES", 4)
+
+struct Tuning {
+#define X(field, name, dflt) int field = dflt;
+    MLVDB_TUNING_FIELDS(X)
+#undef X
+};
+
 // ---------------------------------------------------------------- layout kernels (kernels_layout.hip)
 // stage: row-major [n, dim] on the device -> panels; rows first_row..first_row+n-1
 hipError_t launch_scatter_rows(const float* stage, float* X, int64_t first_row, int64_t n, int32_t dim, int32_t ld,
@@ -70,7 +130,7 @@ struct ExactPlan {
     int threads;   // block size
     size_t lds_bytes;
 };
-ExactPlan plan_exact(int64_t nrows, int32_t ld, int32_t nq_sel, int32_t k);
+ExactPlan plan_exact(int64_t nrows, int32_t ld, int32_t nq_sel, int32_t k, const Tuning& tn);
 
 struct ExactArgs {
     const float* X;
@@ -88,6 +148,7 @@ struct ExactArgs {
     const double* cursor_d;   // optional paging cursor per query (nullptr = none):
     const int32_t* cursor_l;  //   only rows strictly after (cursor_d, cursor_l) in rank order are admitted
     TopEntry* partial;        // [nq_sel][nblk][k]
+    const Tuning* tn;         // host only
 };
 hipError_t launch_exact_scan(const ExactArgs& a, const ExactPlan& p, hipStream_t s);
 // merge partial lists -> final outputs at the original query index
@@ -98,7 +159,7 @@ hipError_t launch_exact_merge(const TopEntry* partial, int32_t nq_sel, const int
 
 // exact fp64 distances of rows 0..m-1 to every query (tombstoned rows: +inf): d64 = [nq][m]
 hipError_t launch_prefix_exact(const float* X, const float* rn, const float* Qpad, const double* qaux, int32_t nq, int32_t m,
-                               int32_t ld, int32_t space, double* d64, hipStream_t s);
+                               int32_t ld, int32_t space, double* d64, const Tuning& tn, hipStream_t s);
 // exact fp64 distances of given pairs: out[q][j] = d(query q, row labels[q][j]) (labels on the device, each < total or < 0 = +inf)
 hipError_t launch_pair_distances(const float* X, const float* Qpad, const double* qaux, const int64_t* labels, int32_t nq,
                                  int32_t m, int32_t ld, int32_t space, double* out64, float* out32, hipStream_t s);
@@ -138,11 +199,13 @@ bool filter_supported(int32_t ld);
 size_t filter_qimg_bytes(int32_t ld);   // bf16 query image for one pass of kFilterQueries
 
 struct FilterArgs {
+    const Tuning* tn;       // host only: the handle's tuning state (never dereferenced on the device)
     const float* X;
     const void* Xb;         // bf16 shadow of X (layout_offset_b) or nullptr: the scan then converts fp32 in registers
     const float* rn;
     int64_t total;
     int32_t ld;
+    int32_t ld8;            // columns of the int8 shadow and of the int8 query image: round_up(ld, 256), zero padded (0: no int8 shadow)
     int32_t space;
     const float* Qpad;      // [nq][ld] raw queries of this pass (q0..q0+nq)
     const double* qaux;
@@ -193,7 +256,7 @@ struct ScanInfo {
 // int8 shadow: (re)build the panels covering rows [row_begin, row_end) (also rp8 and the index-wide error), the query image of a
 // pass (after launch_filter_prep: overrides ke with the int8 error term), exact thresholds from the k best bounds
 hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t row_begin,
-                               int64_t row_end, int32_t ld, int32_t space, hipStream_t s);
+                               int64_t row_end, int32_t ld, int32_t ld8, int32_t space, hipStream_t s);
 hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s);
 bool filter_refine_can_fuse(const FilterArgs& a);
 bool filter_narrow_ok(const FilterArgs& a);  // the pass's scans run on the narrow kernel (<= 64 queries, image resident in LDS)

@@ -326,15 +326,13 @@ __global__ __launch_bounds__(256) void prefix_exact_kernel(const float* __restri
 }
 
 hipError_t launch_prefix_exact(const float* X, const float* rn, const float* Qpad, const double* qaux, int32_t nq, int32_t m,
-                               int32_t ld, int32_t space, double* d64, hipStream_t s) {
+                               int32_t ld, int32_t space, double* d64, const Tuning& tn, hipStream_t s) {
     if (nq <= 0 || m <= 0) return hipErrorInvalidValue;
     const size_t lds = (size_t)ld * sizeof(double);
     // a whole 768-column row in flight per lane (24 groups x two banks) when the row is a whole number of such halves:
     // one round trip per row instead of three (the kernel is one latency chain per wave); MLVDB_PREFIX_PF=8: tuning
-    bool pf24 = (ld / 16) % 24 == 0;
-    if (const char* v = getenv("MLVDB_PREFIX_PF")) pf24 = pf24 && atoi(v) == 24;
-    int nw = 4;  // waves per block, 16 rows each (MLVDB_PREFIX_WAVES: tuning)
-    if (const char* v = getenv("MLVDB_PREFIX_WAVES")) nw = std::max(1, std::min(4, atoi(v)));
+    const bool pf24 = (ld / 16) % 24 == 0 && tn.prefix_pf == 24;
+    const int nw = std::max(1, std::min(4, tn.prefix_waves));  // waves per block, 16 rows each
     const dim3 grid((unsigned)nq, (unsigned)(((int64_t)m + 16 * nw - 1) / (16 * nw)));
     hipError_t e = hipSuccess;
 #define MLVDB_LAUNCH_PREFIX(SP)                                                                                        \
@@ -375,7 +373,7 @@ hipError_t launch_pair_distances(const float* X, const float* Qpad, const double
     return e != hipSuccess ? e : hipGetLastError();
 }
 
-ExactPlan plan_exact(int64_t nrows, int32_t ld, int32_t nq_sel, int32_t k) {
+ExactPlan plan_exact(int64_t nrows, int32_t ld, int32_t nq_sel, int32_t k, const Tuning& tn) {
     ExactPlan p;
     int qt = nq_sel >= 8 ? 8 : nq_sel >= 4 ? 4 : nq_sel >= 2 ? 2 : 1;
     while (qt > 1 && (size_t)qt * ld * sizeof(double) > 64 * 1024) qt >>= 1;
@@ -390,7 +388,7 @@ ExactPlan plan_exact(int64_t nrows, int32_t ld, int32_t nq_sel, int32_t k) {
     // one block per CU is the sweet spot for the streaming scan (tools/exact_ab.py); with several query
     // tiles the corpus is split over fewer blocks each
     int64_t cap = std::min<int64_t>(256, 1024 / p.nqtiles);
-    if (const char* e = getenv("MLVDB_EXACT_NBLK")) cap = atoi(e);  // tuning experiments only
+    if (tn.exact_nblk > 0) cap = tn.exact_nblk;  // tuning experiments only
     if (cap < 8) cap = 8;
     if (nblk > cap) nblk = cap;
     if (nblk < 1) nblk = 1;
@@ -418,7 +416,7 @@ template <int SPACE>
 static hipError_t launch_space(const ExactArgs& a, const ExactPlan& p, hipStream_t s) {
     // non-temporal corpus loads (every row is read once per launch); MLVDB_EXACT_NT=0 selects plain loads for the
     // batch-1 shape only (A/B: tools/exact_ab.py)
-    static const bool plain = [] { const char* e = getenv("MLVDB_EXACT_NT"); return e && atoi(e) == 0; }();
+    const bool plain = a.tn && a.tn->exact_nt == 0;
     if (p.qt == 1 && plain) return launch_one<SPACE, 1, 2, 16, false>(a, p, s);
     switch (p.qt) {
         case 1: return launch_one<SPACE, 1, 2, 16, true>(a, p, s);

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
     constexpr int kFilterTileRows = NW * 16 * kMT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ld = a.ld;
-    const int nsteps = I8 ? ld / 64 : ld / 32;  // a multiple of R (the launcher picks R = 4 or 2)
+    const int nsteps = I8 ? a.ld8 / 64 : ld / 32;  // a multiple of R (the launcher picks R = 4 or 2); int8: the shadow's own (zero-padded) width
     uint4* qlds = reinterpret_cast<uint4*>(smem);  // [nsteps][NQT][64]
     float* thr_l = reinterpret_cast<float*>(smem + (size_t)nsteps * NQT * 1024);  // [256]
     float* sq_l = thr_l + kFilterQueries;
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
     float4 xr[R][kMT];
     float4 rnv[kMT], rbv[kMT];
     const float kq = I8 ? (SPACE == kSpaceCosine ? a.ke8[kFilterQueries] : 1.0f) : 0.f;  // cosine: the factor of the rows' own errors
-    const uint32_t panel_bytes = (uint32_t)ld * (I8 ? 16 : 32);  // 16 rows of int8 / bf16
+    const uint32_t panel_bytes = I8 ? (uint32_t)a.ld8 * 16 : (uint32_t)ld * 32;  // 16 rows of int8 / bf16
     const uint32_t wave_bytes = kMT * panel_bytes;
     const uint64_t tile_stride_bytes = (uint64_t)gridDim.x * (NW * wave_bytes);
     const char* pre_base = reinterpret_cast<const char*>(I8 ? a.X8 : a.Xb) + (uint64_t)(tile_begin + blockIdx.x) * (NW * wave_bytes) +
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4;
     const int c16 = lane & 15;
-    const int nkc = I8 ? a.ld / (2 * kFilterChunkK) : a.ld / kFilterChunkK;
+    const int nkc = I8 ? a.ld8 / (2 * kFilterChunkK) : a.ld / kFilterChunkK;
     for (int t = threadIdx.x; t < kFilterQueries; t += kThreads) {
         float thr = a.thr[t], sqv = a.qscale[t], kev = a.ke[t];
         if (I8) {
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     }
 
     const uint32_t chunk_bytes = (uint32_t)(kChunkVec * sizeof(uint4));
-    const uint32_t pb = (uint32_t)a.ld * (I8 ? 16u : 32u);  // bytes of one shadow panel (16 rows)
+    const uint32_t pb = I8 ? (uint32_t)a.ld8 * 16u : (uint32_t)a.ld * 32u;  // bytes of one shadow panel (16 rows)
     const uint32_t wbytes = MT * pb;           // this wave's panels of a tile
     const uint64_t tile_bytes = (uint64_t)NW * wbytes;
     const int64_t first_tile = tile0;
@@ -1544,7 +1544,7 @@ __device__ __forceinline__ int64_t layout_offset_i8(int64_t row, int32_t col, in
 // max_j(b_j K) >= T) as sharp as the 8 exact tests it stands for.
 __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const float* rn, int8_t* X8, float* rp8,
                                                            unsigned int* row_err8, int64_t slab_begin, int64_t slab_end,
-                                                           int64_t panel_end, int32_t ld, int32_t space) {
+                                                           int64_t panel_end, int32_t ld, int32_t ld8, int32_t space) {
     const int lane = threadIdx.x & 63;
     const int64_t slab = slab_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slab >= slab_end) return;
@@ -1590,7 +1590,7 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
         const float inv = 1.0f / sx;
         double err2 = 0.0, n2 = 0.0;
         const float4* src = reinterpret_cast<const float4*>(X + panel * (int64_t)(kPanelRows * ld) + lane_group_offset(lane));
-        uint32_t* dst = reinterpret_cast<uint32_t*>(X8 + panel * (int64_t)(kPanelRows * ld)) + r * 4 + g;
+        uint32_t* dst = reinterpret_cast<uint32_t*>(X8 + panel * (int64_t)(kPanelRows * ld8)) + r * 4 + g;  // columns ld..ld8 stay zero
         for (int cg = 0; cg < ngroups; ++cg) {
             const float4 v = src[cg * (kGroupFloats / 4)];
             const float x[4] = {v.x, v.y, v.z, v.w};
@@ -1628,12 +1628,12 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
 }
 
 hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t row_begin,
-                               int64_t row_end, int32_t ld, int32_t space, hipStream_t s) {
+                               int64_t row_end, int32_t ld, int32_t ld8, int32_t space, hipStream_t s) {
     const int64_t pe = (row_end + kPanelRows - 1) / kPanelRows;
     const int64_t sb = row_begin / (2 * kPanelRows), se = (pe + 1) / 2;
     if (se <= sb) return hipSuccess;
     shadow8_rows_kernel<<<(unsigned)((se - sb + 3) / 4), 256, 0, s>>>(X, rn, static_cast<int8_t*>(X8), rp8,
-                                                                       reinterpret_cast<unsigned int*>(row_err8), sb, se, pe, ld, space);
+                                                                       reinterpret_cast<unsigned int*>(row_err8), sb, se, pe, ld, ld8, space);
     return hipGetLastError();
 }
 
@@ -1661,8 +1661,8 @@ __global__ __launch_bounds__(256) void filter_prep8_kernel(const FilterArgs a) {
     const float sq = amax > 0.f ? amax / 127.0f : 1.0f;
     const float isq = 1.0f / sq;
     double err2 = 0.0;
-    for (int c = threadIdx.x; c < ld; c += 256) {
-        const float v = q < a.nq ? a.Qpad[(int64_t)q * ld + c] * inv : 0.f;
+    for (int c = threadIdx.x; c < a.ld8; c += 256) {  // (columns ld..ld8 of the image: zeros, like the shadow's)
+        const float v = q < a.nq && c < ld ? a.Qpad[(int64_t)q * ld + c] * inv : 0.f;
         float t = __builtin_rintf(v * isq);
         t = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, t));
         const double e = (double)v - (double)sq * (double)t;
@@ -1763,6 +1763,7 @@ __global__ __launch_bounds__(256) void filter_prep_fused_kernel(const FilterArgs
     const float invf = (float)inv;
     // 2. bf16 image in B-fragment order (filter_prep_kernel) and its measured rounding error (query_prep_kernel)
     __bf16* img = reinterpret_cast<__bf16*>(a.qimg);
+    const bool want_bf16 = ld % kFilterChunkK == 0;  // (another ld has no bf16 / fp32 filter body: only the int8 image is used)
     const int n16 = q >> 4, c16 = q & 15;
     double e2 = 0.0;
     float amax = 0.f;
@@ -1777,7 +1778,7 @@ __global__ __launch_bounds__(256) void filter_prep_fused_kernel(const FilterArgs
             const int t = (c >> 4) & 3;
             ks = t >> 1; g = (c >> 2) & 3; j = (t & 1) * 4 + (c & 3);
         }
-        img[((((int64_t)kc * 16 + n16) * 2 + ks) * 64 + (c16 + 16 * g)) * 8 + j] = b;
+        if (want_bf16) img[((((int64_t)kc * 16 + n16) * 2 + ks) * 64 + (c16 + 16 * g)) * 8 + j] = b;
         if (c < dim) {
             const double e = (double)x * inv - (double)(float)(__bf16)(x * invf);
             e2 = __builtin_fma(e, e, e2);
@@ -1815,8 +1816,8 @@ __global__ __launch_bounds__(256) void filter_prep_fused_kernel(const FilterArgs
     const float isq = 1.0f / sq;
     int8_t* img8 = reinterpret_cast<int8_t*>(a.qimg8);
     double err2 = 0.0;
-    for (int c = threadIdx.x; c < ld; c += 256) {
-        const float v = real ? dst[c] * invf : 0.f;
+    for (int c = threadIdx.x; c < a.ld8; c += 256) {  // (columns ld..ld8 of the image: zeros, like the shadow's)
+        const float v = real && c < ld ? dst[c] * invf : 0.f;
         float t = __builtin_rintf(v * isq);
         t = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, t));
         const double e = (double)v - (double)sq * (double)t;
@@ -1847,8 +1848,8 @@ __global__ __launch_bounds__(256) void filter_prep_fused_kernel(const FilterArgs
 
 hipError_t launch_filter_prep_fused(const FilterArgs& a, const float* queries, int32_t dim, float* Qpad, double* qaux, float* qerr,
                                     hipStream_t s) {
-    if (a.ld / kFilterChunkK <= 0) return hipErrorInvalidValue;
     const int want_i8 = a.X8 != nullptr;
+    if (!want_i8 && !filter_supported(a.ld)) return hipErrorInvalidValue;
     filter_prep_fused_kernel<<<kFilterQueries, 256, 0, s>>>(a, queries, dim, Qpad, qaux, qerr, want_i8);
     if (want_i8 && a.nq > 1) filter_prep8_fin_kernel<<<1, kFilterQueries, 0, s>>>(a, 1);  // (one query: done inside the kernel above)
     return hipGetLastError();
@@ -2405,9 +2406,9 @@ hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forc
     // rows scored exactly per query and round: 1.5 k (at least 16, at most 64); MLVDB_REFINE_PICKS overrides (tuning; = k
     // gives "the smallest exact score of the k largest bounds").  10M x 768, k = 10, per wave: 10 picks 1.962 ms, 16 1.935,
     // 30 1.953, 48 1.976 (profiles/r02/scan_ab_refine_picks_10m.txt): more picks are more page walks per round
-    const char* pv = getenv("MLVDB_REFINE_PICKS");
-    int picks = pv ? atoi(pv) : k + k / 2;
-    if (!pv && picks < 16) picks = 16;
+    const int pv = a.tn ? a.tn->refine_picks : 0;
+    int picks = pv > 0 ? pv : k + k / 2;
+    if (pv <= 0 && picks < 16) picks = 16;
     picks = picks < k ? k : (picks > 64 ? 64 : picks);
     kern<<<a.nq, 256, lds, s>>>(a, k, forced_cnt, fuse, picks, FinishOut{});
     return hipGetLastError();
@@ -2425,18 +2426,13 @@ hipError_t launch_filter_finish_small(const FilterArgs& a, int32_t k, int32_t q0
     static std::atomic<uint64_t> configured[3];
     if (hipError_t e = ensure_dynamic_lds(configured[a.space], reinterpret_cast<const void*>(kern), 160 * 1024); e != hipSuccess)
         return e;
-    const char* pv = getenv("MLVDB_REFINE_PICKS");
-    int picks = pv ? atoi(pv) : k + k / 2;
-    if (!pv && picks < 16) picks = 16;
+    const int pv = a.tn ? a.tn->refine_picks : 0;
+    int picks = pv > 0 ? pv : k + k / 2;
+    if (pv <= 0 && picks < 16) picks = 16;
     picks = picks < k ? k : (picks > 64 ? 64 : picks);
     FinishOut fo{q0, out_labels, out_dist, out_counts, out_d64, rescored, qsel, nflag};
     kern<<<a.nq, 256, lds, s>>>(a, k, -1, true, picks, fo);
     return hipGetLastError();
-}
-
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
 }
 
 template <int SPACE, bool XB, bool DENSE = false>
@@ -2469,11 +2465,11 @@ static size_t narrow_lds(int32_t ld, int nqt, int nw, bool i8 = false) {
 }
 bool filter_narrow_ok(const FilterArgs& a) {
     if (!(a.Xb || a.X8) || a.nq > kNarrowMaxQueries) return false;  // streams the int8 shadow when the pass has one, else the bf16 one
-    if (env_int("MLVDB_SCAN_NARROW", 1) == 0) return false;
+    if (a.tn->scan_narrow == 0) return false;
     // int8 bounds admit ~7x more rows than bf16 ones and this kernel appends them one atomic at a time: beyond 8
     // queries the 256-query body (appends staged per wave) is faster (profiles/r01/small_batch_ab_10m_i8.txt)
-    if (a.X8 && a.nq > env_int("MLVDB_NARROW_I8_MAX", 8)) return false;  // (tuning: the largest batch the int8 narrow kernel takes)
-    return narrow_lds(a.ld, narrow_nqt(a.nq), 8, a.X8 != nullptr) <= kNarrowLdsMax;
+    if (a.X8 && a.nq > a.tn->narrow_i8_max) return false;  // (tuning: the largest batch the int8 narrow kernel takes)
+    return narrow_lds(a.X8 ? a.ld8 : a.ld, narrow_nqt(a.nq), 8, a.X8 != nullptr) <= kNarrowLdsMax;
 }
 template <int SPACE, int NQT, bool DENSE, int R, int NW, bool I8 = false>
 static hipError_t launch_scan_narrow_n(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, int qgroups = 1) {
@@ -2481,13 +2477,13 @@ static hipError_t launch_scan_narrow_n(const FilterArgs& a, int64_t row_begin, i
     const int64_t tile_begin = row_begin / tile_rows;
     const int64_t tile_end = (row_end + tile_rows - 1) / tile_rows;
     if (tile_end <= tile_begin) return hipSuccess;
-    const size_t lds = narrow_lds(a.ld, NQT, NW, I8);
+    const size_t lds = narrow_lds(I8 ? a.ld8 : a.ld, NQT, NW, I8);
     const int64_t ntiles = tile_end - tile_begin;
     const int per_cu = (int)std::min<size_t>(32 / NW, (160 * 1024) / lds);  // workgroups resident per CU
-    const int max_grid = 256 * env_int("MLVDB_NARROW_WGS", per_cu);
+    const int max_grid = 256 * (a.tn->narrow_wgs > 0 ? a.tn->narrow_wgs : per_cu);
     // equal tile counts per workgroup: the kernel is a pure stream, a last round with a few busy workgroups is all tail
     const int64_t rounds = (ntiles + max_grid - 1) / max_grid;
-    const int grid = env_int("MLVDB_NARROW_BALANCE", 1) ? (int)((ntiles + rounds - 1) / rounds)
+    const int grid = a.tn->narrow_balance ? (int)((ntiles + rounds - 1) / rounds)
                                                         : (int)(ntiles < max_grid ? ntiles : max_grid);
     auto kern = filter_scan_narrow_kernel<SPACE, NQT, DENSE, R, NW, I8>;
     static std::atomic<uint64_t> configured{0};  // per instantiation
@@ -2543,7 +2539,7 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     if (lds_base_ok.load(std::memory_order_acquire) < 0) return hipErrorInvalidConfiguration;  // dynamic LDS would not start at 0
     if (hipError_t e = ensure_dynamic_lds(configured, reinterpret_cast<const void*>(kern), (int)lds); e != hipSuccess)
         return e;
-    const int xcd_mode = grid % 8 == 0 && ntiles >= grid && env_int("MLVDB_SCAN_XCD", 0) ? 1 : 0;
+    const int xcd_mode = grid % 8 == 0 && ntiles >= grid && a.tn->scan_xcd ? 1 : 0;
     kern<<<grid, NW * 64, lds, s>>>(a, tile_begin, tile_end, xcd_mode);
     // (the kernel's own tail moves the entries into the candidate lists: there is no scatter launch)
     info->nw = NW;
@@ -2552,36 +2548,33 @@ static hipError_t launch_scan_asm(const FilterArgs& a, int64_t row_begin, int64_
     return hipGetLastError();
 }
 
-// Picks the scan kernel for a launch: the assembly body whenever the bf16 shadow exists (variants by
-// environment variable, read per launch, for tuning), else the compiler-scheduled kernel.
+// Picks the scan kernel for a launch.  Default library: the int8 body (ArchVGPR accumulators) wherever the pass has an int8
+// shadow, the bf16 body (8 waves, LDS-DMA staging) for an index that keeps a bf16 shadow, the compiler-scheduled kernel for
+// an index without shadow.  `make AB=1` adds the tuning variants (Tuning::scan_*; tools/scan_ab.py and the `ab`-marked
+// tests); the handle's tuning state picks among them -- nothing here reads the environment.
 template <int SPACE>
 static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int64_t row_end, hipStream_t s, ScanInfo* info) {
+    const Tuning& tn = *a.tn;
     const int nkc = a.ld / kFilterChunkK;
     if (filter_narrow_ok(a)) return launch_scan_narrow<SPACE, false>(a, row_begin, row_end, s);  // appends to the lists itself
-    if ((a.Xb || a.X8) && env_int("MLVDB_SCAN_ASM", 1)) {
-        // hand-written body (tools/gen_scan_asm.py).  Default: one 8-wave workgroup per CU (256-row tiles:
-        // the query image is staged once per CU, by LDS-DMA), non-temporal X loads, ring of 4 k-steps -- measured
-        // fastest (profiles/r01/scan_ab_*.txt); a ring of R k-steps needs the tile's 2*nkc k-steps to be a
-        // multiple of R.  MLVDB_SCAN_NW / _NT / _R / _QD select the other generated variants (tuning).
-        const int nw = env_int("MLVDB_SCAN_NW", 8);
-        if (a.Xb && env_int("MLVDB_SCAN_MT", 2) == 4) {  // one wave per SIMD, 64 rows per wave
+    if ((a.Xb || a.X8) && tn.scan_asm) {
+        // hand-written body (tools/gen_scan_asm.py): one 8-wave workgroup per CU (256-row tiles: the query image is staged
+        // once per CU, by LDS-DMA), non-temporal X loads, ring of 4 k-steps -- measured fastest (profiles/r01/scan_ab_*.txt);
+        // a ring of R k-steps needs the tile's k-steps to be a multiple of R
+#ifdef MLVDB_AB
+        if (a.Xb && tn.scan_mt == 4) {  // one wave per SIMD, 64 rows per wave
             if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true, 4, false, 4>(a, row_begin, row_end, s, info);
             return launch_scan_asm<SPACE, 2, 4, true, 4, false, 4>(a, row_begin, row_end, s, info);
         }
-        if (a.X8 && a.ld % 256 == 0) {  // int8 shadow (the caller attached it): ld/128 chunks, an even number
-            // progress-based wave priorities: +2 % on the int8 body (profiles/r01/scan_ab_i8_prio_4m.txt); 3 % slower on the
-            // power-bound bf16 body, where they stay off
-#ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: the int8 body without its admission test (wrong results by design)
+#endif
+        if (a.X8 && a.ld8 > 0) {  // int8 shadow (the caller attached it): ld8/128 chunks, an even number
+#ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: timing diagnostics of the int8 body (wrong results by design)
             if constexpr (SPACE == kSpaceCosine) {
-                if (env_int("MLVDB_SCAN_DIAG", 0) == 209)
-                    return launch_scan_asm<SPACE, 4, 8, true, 209, true, 2, true>(a, row_begin, row_end, s, info);
-                if (env_int("MLVDB_SCAN_DIAG", 0) == 210)
-                    return launch_scan_asm<SPACE, 4, 8, true, 210, true, 2, true>(a, row_begin, row_end, s, info);
-                if (env_int("MLVDB_SCAN_DIAG", 0) == 212)
-                    return launch_scan_asm<SPACE, 4, 8, true, 212, true, 2, true>(a, row_begin, row_end, s, info);
-                if (env_int("MLVDB_SCAN_DIAG", 0) == 213)
-                    return launch_scan_asm<SPACE, 4, 8, true, 213, true, 2, true>(a, row_begin, row_end, s, info);
-                switch (env_int("MLVDB_SCAN_DIAG", 0)) {
+                switch (tn.scan_diag) {
+                    case 209: return launch_scan_asm<SPACE, 4, 8, true, 209, true, 2, true>(a, row_begin, row_end, s, info);
+                    case 210: return launch_scan_asm<SPACE, 4, 8, true, 210, true, 2, true>(a, row_begin, row_end, s, info);
+                    case 212: return launch_scan_asm<SPACE, 4, 8, true, 212, true, 2, true>(a, row_begin, row_end, s, info);
+                    case 213: return launch_scan_asm<SPACE, 4, 8, true, 213, true, 2, true>(a, row_begin, row_end, s, info);
                     case 234: return launch_scan_asm<SPACE, 4, 8, true, 234, true, 2, true>(a, row_begin, row_end, s, info);
                     case 223: return launch_scan_asm<SPACE, 4, 8, true, 223, true, 2, true>(a, row_begin, row_end, s, info);
                     case 224: return launch_scan_asm<SPACE, 4, 8, true, 224, true, 2, true>(a, row_begin, row_end, s, info);
@@ -2592,49 +2585,50 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                 }
             }
 #endif
-            if (env_int("MLVDB_SCAN_VA", 1)) {  // accumulators in ArchVGPRs: the admission test reads them directly
-                if constexpr (SPACE == kSpaceCosine) {  // tuning variants of the folded body
-                    const int var = env_int("MLVDB_SCAN_VAR", 0);
-                    if (var == 229 && (a.ld / 64) % 6 == 0)
-                        return launch_scan_asm<SPACE, 6, 8, true, 229, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 228 && (a.ld / 64) % 6 == 0)
-                        return launch_scan_asm<SPACE, 6, 8, true, 228, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 214 && (a.ld / 64) % 6 == 0)
-                        return launch_scan_asm<SPACE, 6, 8, true, 214, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 215) return launch_scan_asm<SPACE, 4, 8, true, 215, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 216) return launch_scan_asm<SPACE, 4, 8, true, 216, false, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 219) return launch_scan_asm<SPACE, 4, 8, true, 219, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 222 && (a.ld / 128) % 2 == 0)
-                        return launch_scan_asm<SPACE, 4, 8, true, 222, true, 2, true, true>(a, row_begin, row_end, s, info);
-                    if (var == 220) return launch_scan_asm<SPACE, 4, 8, true, 220, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 221) return launch_scan_asm<SPACE, 4, 8, true, 221, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 230) return launch_scan_asm<SPACE, 4, 4, true, 230, false, 4, true>(a, row_begin, row_end, s, info);
-                    if (var == 231) return launch_scan_asm<SPACE, 4, 8, true, 231, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 232) return launch_scan_asm<SPACE, 4, 8, true, 232, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 233) return launch_scan_asm<SPACE, 4, 8, true, 233, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 235) return launch_scan_asm<SPACE, 4, 8, true, 235, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 236) return launch_scan_asm<SPACE, 4, 8, true, 236, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 237) return launch_scan_asm<SPACE, 4, 8, true, 237, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 217) return launch_scan_asm<SPACE, 4, 4, true, 217, false, 2, true>(a, row_begin, row_end, s, info);
-                    if (var == 218) return launch_scan_asm<SPACE, 4, 4, true, 218, true, 2, true>(a, row_begin, row_end, s, info);
-                }
-                return launch_scan_asm<SPACE, 4, 8, true, 211, true, 2, true>(a, row_begin, row_end, s, info);
+#ifdef MLVDB_AB
+            if (!tn.scan_va) {  // round 1: AccVGPR accumulators, serial admission phase; with / without wave priorities
+                if (tn.scan_prio != 0) return launch_scan_asm<SPACE, 4, 8, true, 208, true, 2, true>(a, row_begin, row_end, s, info);
+                return launch_scan_asm<SPACE, 4, 8, true, 208, false, 2, true>(a, row_begin, row_end, s, info);
             }
-            if (env_int("MLVDB_SCAN_PRIO", 1))
-                return launch_scan_asm<SPACE, 4, 8, true, 208, true, 2, true>(a, row_begin, row_end, s, info);
-            return launch_scan_asm<SPACE, 4, 8, true, 208, false, 2, true>(a, row_begin, row_end, s, info);
+            if constexpr (SPACE == kSpaceCosine) {  // tuning variants of the folded body
+                const int var = tn.scan_var;
+                if (var == 229 && (a.ld8 / 64) % 6 == 0) return launch_scan_asm<SPACE, 6, 8, true, 229, true, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 228 && (a.ld8 / 64) % 6 == 0) return launch_scan_asm<SPACE, 6, 8, true, 228, true, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 214 && (a.ld8 / 64) % 6 == 0) return launch_scan_asm<SPACE, 6, 8, true, 214, true, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 215) return launch_scan_asm<SPACE, 4, 8, true, 215, true, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 216) return launch_scan_asm<SPACE, 4, 8, true, 216, false, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 219) return launch_scan_asm<SPACE, 4, 8, true, 219, true, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 222) return launch_scan_asm<SPACE, 4, 8, true, 222, true, 2, true, true>(a, row_begin, row_end, s, info);
+                if (var == 220) return launch_scan_asm<SPACE, 4, 8, true, 220, true, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 221) return launch_scan_asm<SPACE, 4, 8, true, 221, true, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 230) return launch_scan_asm<SPACE, 4, 4, true, 230, false, 4, true>(a, row_begin, row_end, s, info);
+                if (var == 231) return launch_scan_asm<SPACE, 4, 8, true, 231, true, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 232) return launch_scan_asm<SPACE, 4, 8, true, 232, true, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 233) return launch_scan_asm<SPACE, 4, 8, true, 233, true, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 235) return launch_scan_asm<SPACE, 4, 8, true, 235, true, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 236) return launch_scan_asm<SPACE, 4, 8, true, 236, true, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 217) return launch_scan_asm<SPACE, 4, 4, true, 217, false, 2, true>(a, row_begin, row_end, s, info);
+                if (var == 218) return launch_scan_asm<SPACE, 4, 4, true, 218, true, 2, true>(a, row_begin, row_end, s, info);
+            }
+#endif
+            if constexpr (SPACE == kSpaceCosine) {  // round 2's default body stays in the default library as the A/B reference
+                if (tn.scan_var == 237) return launch_scan_asm<SPACE, 4, 8, true, 237, true, 2, true>(a, row_begin, row_end, s, info);
+            }
+            return launch_scan_asm<SPACE, 4, 8, true, 211, true, 2, true>(a, row_begin, row_end, s, info);
         }
         // everything below streams the bf16 shadow (an int8-only index without usable int8 bounds has none: its
         // fp32 rows are converted in registers by the compiler-scheduled kernel)
         if (!a.Xb) return launch_scan_one<SPACE, false>(a, row_begin, row_end, s, info);
+#ifdef MLVDB_AB
+        const int nw = tn.scan_nw;
         if constexpr (SPACE == kSpaceCosine) {
-            if (nw == 8 && nkc % 2 == 0 && env_int("MLVDB_SCAN_PRIO", 0) != 0)
+            if (nw == 8 && nkc % 2 == 0 && tn.scan_prio == 1)
                 return launch_scan_asm<SPACE, 4, 8, true, 4, true>(a, row_begin, row_end, s, info);
-            if (nkc % 2 == 0 && env_int("MLVDB_SCAN_NT", 1) == 0)
+            if (nkc % 2 == 0 && tn.scan_nt == 0)
                 return nw == 8 ? launch_scan_asm<SPACE, 4, 8, false>(a, row_begin, row_end, s, info)
                                : launch_scan_asm<SPACE, 4, 4, false>(a, row_begin, row_end, s, info);
 #ifdef MLVDB_SCAN_DIAGNOSTICS  // make DIAG=1: timing diagnostics (tools/scan_ab.py --no-check), wrong results by design
-            switch (nw == 8 && nkc % 2 == 0 ? env_int("MLVDB_SCAN_DIAG", 0) : 0) {  // timing diagnostics, wrong results
+            switch (nw == 8 && nkc % 2 == 0 ? tn.scan_diag : 0) {
                 case 101: return launch_scan_asm<SPACE, 4, 8, true, 101>(a, row_begin, row_end, s, info);
                 case 102: return launch_scan_asm<SPACE, 4, 8, true, 102>(a, row_begin, row_end, s, info);
                 case 103: return launch_scan_asm<SPACE, 4, 8, true, 103>(a, row_begin, row_end, s, info);
@@ -2646,18 +2640,20 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
             }
 #endif
         }
-        if (nw == 8) {
-            if (env_int("MLVDB_SCAN_DMA", 1)) {  // query image staged by LDS-DMA (default, +2 %) instead of through registers
-                if (nkc % 2 == 0 && env_int("MLVDB_SCAN_STAG", 0))  // later half of the waves half a tile behind
-                    return launch_scan_asm<SPACE, 4, 8, true, 4, false, 2, true, true>(a, row_begin, row_end, s, info);
-                if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8, true, 4, false, 2, true>(a, row_begin, row_end, s, info);
-                return launch_scan_asm<SPACE, 2, 8, true, 4, false, 2, true>(a, row_begin, row_end, s, info);
-            }
+        if (nw == 8 && nkc % 2 == 0 && tn.scan_dma && tn.scan_stag)  // later half of the waves half a tile behind
+            return launch_scan_asm<SPACE, 4, 8, true, 4, false, 2, true, true>(a, row_begin, row_end, s, info);
+        if (nw == 8 && !tn.scan_dma) {  // query image staged through registers
             if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8, true>(a, row_begin, row_end, s, info);
             return launch_scan_asm<SPACE, 2, 8, true>(a, row_begin, row_end, s, info);
         }
-        if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true>(a, row_begin, row_end, s, info);
-        return launch_scan_asm<SPACE, 2, 4, true>(a, row_begin, row_end, s, info);
+        if (nw != 8) {  // two 4-wave workgroups per CU
+            if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 4, true>(a, row_begin, row_end, s, info);
+            return launch_scan_asm<SPACE, 2, 4, true>(a, row_begin, row_end, s, info);
+        }
+#endif
+        // query image staged by LDS-DMA (+2 % over the register-staged variant)
+        if (nkc % 2 == 0) return launch_scan_asm<SPACE, 4, 8, true, 4, false, 2, true>(a, row_begin, row_end, s, info);
+        return launch_scan_asm<SPACE, 2, 8, true, 4, false, 2, true>(a, row_begin, row_end, s, info);
     }
     // compiler-scheduled kernel: corpora without shadow (fp32 rows converted in registers), and the A/B reference
     if (a.Xb) return launch_scan_one<SPACE, true>(a, row_begin, row_end, s, info);
@@ -2685,14 +2681,14 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
         }
         return launch_update(a, k, (int32_t)rows, s);
     }
-    if (a.X8 && env_int("MLVDB_SEED_I8", 1)) {
+    if (a.X8 && a.tn->seed_i8) {
         // Round 3: the dense pass of a 256-query batch on the int8 shadow too -- the narrow kernel (64 queries' image in LDS)
         // once per group of 64 queries (grid.y): 30 row tiles x 4 groups = 120 workgroups instead of the 30 of the bf16
         // kernel below, half the MFMAs, and no pass of the default path reads the bf16 shadow any more (so an index need
         // not keep one: 1.25x instead of 1.75x the corpus in HBM).  Every bound goes into the lists either way; the refine
         // that follows takes the threshold from exact scores.
         // queries per group: as many as the image leaves room for in LDS (64 up to ld = 2304, 32 up to 4736, else 16)
-        const int nqt = narrow_lds(a.ld, 4, 4, true) <= kNarrowLdsMax ? 4 : (narrow_lds(a.ld, 2, 4, true) <= kNarrowLdsMax ? 2 : 1);
+        const int nqt = narrow_lds(a.ld8, 4, 4, true) <= kNarrowLdsMax ? 4 : (narrow_lds(a.ld8, 2, 4, true) <= kNarrowLdsMax ? 2 : 1);
         const int groups = (a.nq + 16 * nqt - 1) / (16 * nqt);
 #define MLVDB_SEED_I8(SP)                                                                                              \
     (nqt == 4 ? launch_scan_narrow_n<SP, 4, true, 4, 4, true>(a, 0, rows, s, groups)                                  \
@@ -2785,7 +2781,7 @@ hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, i
     hipError_t e = hipMemsetAsync(a.rhit_cnt, 0, kFilterQueries * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     // MLVDB_RANGE_FLAT=0: round 2's (query, 256-candidate chunk) grid (A/B)
-    const bool flat = env_int("MLVDB_RANGE_FLAT", 1) != 0;
+    const bool flat = a.tn->range_flat != 0;
     int waves = kRescoreWaves;
     while (waves > 1 && (size_t)waves * a.ld * sizeof(double) > 144 * 1024) waves >>= 1;
     const size_t lds_score = flat ? std::max((size_t)waves * a.ld * sizeof(double), (size_t)96 * 1024)

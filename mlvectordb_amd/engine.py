@@ -80,6 +80,17 @@ class HipScanEngine:
     def set_strategy(self, strategy: str) -> None:
         self._check(self._lib.mlvdb_index_set_strategy(self._h, _native.STRATEGY_CODES[strategy]), "set_strategy")
 
+    def set_tuning(self, **knobs: int) -> None:
+        """Tuning state of the handle (``mlvdb_index_set_tuning``): ``set_tuning(SCAN_VAR=237, I8=0)``.  The MLVDB_* environment
+        variables are only read when the handle is created; this is how a live handle is switched (tools/scan_ab.py)."""
+        for key, value in knobs.items():
+            self._check(self._lib.mlvdb_index_set_tuning(self._h, f"{key}={int(value)}".encode()), f"set_tuning({key})")
+
+    def get_tuning(self, key: str) -> int:
+        out = C.c_int32(0)
+        self._check(self._lib.mlvdb_index_get_tuning(self._h, key.encode(), C.byref(out)), f"get_tuning({key})")
+        return int(out.value)
+
     def set_profiling(self, enabled: bool) -> None:
         self._check(self._lib.mlvdb_index_set_profiling(self._h, int(bool(enabled))), "set_profiling")
 

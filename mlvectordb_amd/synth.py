@@ -70,5 +70,9 @@ def iter_corpus(first: int, n: int, dim: int, piece_rows: int = 250_000, threads
             del chunk
 
 
-def queries(nq: int, dim: int) -> np.ndarray:
-    return np.random.default_rng(QUERY_SEED).standard_normal((nq, dim), dtype=np.float32)
+def queries(nq: int, dim: int, batch_index: int = 0) -> np.ndarray:
+    """Query batch ``batch_index``: batch 0 is SURVEY 8d's ``default_rng(4321)``; batches 1, 2, ... come from
+    ``default_rng([4321, i])`` (bench.py rotates through several, so that thresholds, candidate counts and branch
+    behaviour are not those of one draw)."""
+    seed = QUERY_SEED if batch_index == 0 else [QUERY_SEED, int(batch_index)]
+    return np.random.default_rng(seed).standard_normal((nq, dim), dtype=np.float32)

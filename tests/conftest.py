@@ -14,6 +14,7 @@ OUT_DIR = ROOT / "gpurun_out"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ab: tuning variants that exist only in the `make AB=1` library (tools/gpu_suite.sh --ab); skipped elsewhere")
 
 
 def _has_gpu() -> bool:

@@ -110,6 +110,8 @@ def test_every_handle_entry_refuses_a_null_handle_with_a_status_code():
         "mlvdb_pair_distances": (null, buf, 1, buf, 1, buf, buf),
         "mlvdb_index_set_strategy": (null, 0),
         "mlvdb_index_set_profiling": (null, 0),
+        "mlvdb_index_set_tuning": (null, b"I8=0"),
+        "mlvdb_index_get_tuning": (null, b"I8", C.byref(C.c_int32(0))),
         "mlvdb_index_last_stats": (null, C.byref(_native.Stats())),
     }
     handle_entries = [n for n, (_, argtypes) in _native.SIGNATURES.items()
@@ -132,3 +134,15 @@ def test_every_extern_c_entry_runs_inside_the_exception_guard():
         if name == "mlvdb_abi_version":
             continue
         assert body.lstrip().startswith("return guarded("), f"{name} is not wrapped by guarded()"
+
+
+def test_the_search_path_never_reads_the_environment():
+    """VERDICT r3 item 5: tuning state lives in the handle (filled once by mlvdb_index_create, changed by mlvdb_index_set_tuning);
+    getenv racing a setenv from another thread is undefined in glibc and MultiDeviceEngine runs one host thread per shard.
+    The library's sources contain exactly one environment read: the loop of tuning_from_env (api.hip)."""
+    csrc = ROOT / "mlvectordb_amd" / "csrc"
+    uses = {p.name: len(re.findall(r"\bgetenv\s*\(", p.read_text())) for p in list(csrc.glob("*.hip")) + list(csrc.glob("*.h"))}
+    assert sum(uses.values()) <= 2 and set(n for n, c in uses.items() if c) == {"api.hip"}, uses
+    text = (csrc / "api.hip").read_text()
+    body = text[text.index("Tuning tuning_from_env()"):text.index("const TuningField* find_tuning_field")]
+    assert body.count("getenv(") == sum(uses.values())

@@ -118,8 +118,8 @@ def test_committed_golden_vectors(name, strategy):
 
     g = np.load(GOLDEN / f"{name}.npz")
     meta = json.loads(str(g["meta"]))
-    if strategy == "filter" and meta["d"] % 64:
-        pytest.skip("filter path needs dim % 64 == 0; AUTO routes such corpora to the exact scan")
+    if strategy == "filter" and meta["d"] < 64:
+        pytest.skip("the filter path needs dim >= 64 (an int8 shadow padded to 256 columns); AUTO routes smaller dims to the exact scan")
     rows, qs, deleted = regenerate_inputs(meta)
     (labels, dist, counts), _ = run_hip(rows, qs, meta["k"], meta["space"], strategy, deleted)
     assert np.array_equal(labels, g["labels"]) and np.array_equal(counts, g["counts"])
@@ -182,6 +182,41 @@ def test_int8_only_shadow_matches_oracle(space, shadow, monkeypatch):
             assert_knn_matches(eng.search(qs[:16], k), oracle_knn(qs[:16], rows[old], k, space), f"int8only-compact/{space}")
         finally:
             eng.close()
+
+
+@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+@pytest.mark.parametrize("d", [65, 100, 300, 384, 1000])
+def test_any_dim_runs_on_the_zero_padded_int8_shadow(space, d):
+    """the reference takes any dim from the first vector (index.py:54).  The int8 shadow is padded with zero
+    columns to a multiple of 256 (they change neither a dot product nor a norm), so d = 100 / 300 / 384 / 1000 run the int8
+    body: 256-query passes, 1-8 queries (narrow kernel), row masks, range queries, appends in pieces, tombstones, compaction."""
+    n = 60_001 if d <= 384 else 30_001
+    rows, qs = make_case(700 + d, n, d, 44, dup=True)
+    deleted = deleted_mask(17, n, 0.07)
+    eng = HipScanEngine(d, space, device=0, strategy="filter")
+    try:
+        eng.append(rows[: n // 2])
+        eng.append(rows[n // 2:])
+        eng.tombstone(np.nonzero(deleted)[0])
+        got = eng.search(qs, 10)
+        st = eng.last_stats()
+        assert st["strategy_used"] == 2 and st["bound_dtype"] == 2 and st["fallback_queries"] == 0, st
+        assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"padded-int8/{space}/d{d}")
+        small = eng.search(qs[:3], 7)
+        st = eng.last_stats()
+        assert st["strategy_used"] == 2 and st["bound_dtype"] == 2, st
+        assert_knn_matches(small, oracle_knn(qs[:3], rows, 7, space, deleted), f"padded-int8-narrow/{space}/d{d}")
+        mask = (np.arange(n) % 4 != 1).astype(np.uint8)
+        gm = eng.search(qs[:12], 10, mask)
+        assert_knn_matches(gm, oracle_knn(qs[:12], rows, 10, space, deleted | (mask == 0)), f"padded-int8-mask/{space}/d{d}")
+        radius = float(got[1][:, 4].mean())
+        hits = eng.range(qs[:6], radius, 64)
+        want = exact_scan.range_query(qs[:6], rows, radius, space, deleted=deleted)
+        assert all(np.array_equal(h[0], w[0]) for h, w in zip(hits, want))
+        old = eng.compact()
+        assert_knn_matches(eng.search(qs[:16], 10), oracle_knn(qs[:16], rows[old], 10, space), f"padded-int8-compact/{space}/d{d}")
+    finally:
+        eng.close()
 
 
 def test_k_larger_than_live_rows_pads():
@@ -324,25 +359,15 @@ def test_range_capacity_overflow_is_reported_then_resolved():
         eng.close()
 
 
+# one case per live code path of the DEFAULT library (the tuning variants of `make AB=1` are in tests/test_ab_variants.py, marked `ab`)
 SCAN_VARIANTS = [
-    {},                                              # defaults: int8 shadow body where dim % 256 == 0, else the bf16 body below
-    {"MLVDB_SCAN_PRIO": "0"},                        # int8 body without the progress-based wave priorities
-    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16"},                               # bf16 body: one 8-wave workgroup per CU, Q by LDS-DMA
-    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16", "MLVDB_SCAN_DMA": "0"},        # Q staged through registers (global -> VGPR -> ds_write)
-    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16", "MLVDB_SCAN_NW": "4"},         # two 4-wave workgroups per CU
-    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16", "MLVDB_SCAN_MT": "4"},         # one wave per SIMD, 64 rows per wave
-    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16", "MLVDB_SCAN_NT": "0"},         # (cosine only) temporal X loads
-    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16", "MLVDB_SCAN_ASM": "0"},        # the hipcc-scheduled kernel (also serves corpora without shadow)
-    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16", "MLVDB_SCAN_STAG": "1"},       # later half of the waves half a tile behind (rotated k origin)
-    {"MLVDB_SCAN_VAR": "230"},                       # (cosine, int8) one wave per SIMD, 64 rows per wave, AccVGPR accumulators
-    {"MLVDB_SCAN_VAR": "231"},                       # (cosine, int8) four Q buffers, B-fragment reads across the chunk barrier
-    {"MLVDB_SCAN_VAR": "233"},                       # ... with the early-out hit stubs
-    {"MLVDB_SCAN_VAR": "235"},                       # (cosine, int8) straight-line append routine
-    {"MLVDB_SCAN_VAR": "236"},                       # ... with the early-out hit stubs (= the default body since round 3)
-    {"MLVDB_SCAN_VAR": "237"},                       # round 2's default body
+    {},                                              # defaults: the int8 body (shadow zero-padded to a multiple of 256 columns); bf16 body for d = 64 / 128
+    {"MLVDB_I8": "0", "MLVDB_SHADOW": "bf16"},       # bf16 body: one 8-wave workgroup per CU, Q by LDS-DMA (rings of 4 and of 2 k-steps)
+    {"MLVDB_SCAN_VAR": "237"},                       # (cosine, int8) round 2's default body: the A/B reference kept in the default library
     {"MLVDB_SCAN_XCD": "1"},                         # every XCD scans one contiguous eighth of the tile range
     {"MLVDB_SHADOW": "bf16"},                        # both shadows kept (round 2's default): int8 scans, bf16 seeding / narrow passes off
     {"MLVDB_SEED_I8": "0"},                          # int8-only index, seeding pass by the compiler kernel on the fp32 rows
+    {"MLVDB_I8_PAD": "0"},                           # round 3: int8 shadow only where dim % 256 == 0
 ]
 
 NARROW_CASES = [
@@ -443,7 +468,8 @@ def test_scan_kernel_variants_agree_with_oracle(variant, space, d, monkeypatch):
     deleted = deleted_mask(7, n, 0.05)
     got, stats = run_hip(rows, qs, 10, space, "filter", deleted, append_chunks=3)
     assert stats["strategy_used"] == 2 and stats["fallback_queries"] == 0
-    assert stats["bound_dtype"] == (2 if d % 256 == 0 and variant.get("MLVDB_I8") != "0" else 1)
+    ld8 = 0 if d in (64, 128) or (variant.get("MLVDB_I8_PAD") == "0" and d % 256) else -(-d // 256) * 256
+    assert stats["bound_dtype"] == (2 if ld8 and variant.get("MLVDB_I8") != "0" else 1)
     assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"variant {variant}/{space}/d{d}")
 
 

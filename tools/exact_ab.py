@@ -15,10 +15,10 @@ for _, rows in synth.iter_corpus(0, N, D, threads=16):
 q = torch.from_numpy(synth.queries(8, D)).cuda()
 lab = torch.empty((8, K), dtype=torch.int64, device="cuda"); dst = torch.empty((8, K), dtype=torch.float32, device="cuda"); cnt = torch.empty(8, dtype=torch.int32, device="cuda")
 eng.set_profiling(True)
-# MLVDB_EXACT_NT=0 (read once per process) selects plain loads for batch 1: run the script twice to compare
+# eng.set_tuning(EXACT_NT=0) selects plain loads for batch 1
 for nq in (1, 2, 4, 8):
     for nblk in ("256", "512"):
-        os.environ["MLVDB_EXACT_NBLK"] = nblk
+        eng.set_tuning(EXACT_NBLK=int(nblk))
         lat = []
         for i in range(40):
             torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -1084,19 +1084,14 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     return "\n".join(text) + "\n"
 
 
-# (space, NW, R, nt) instantiated by kernels_filter.hip: the production set, and experiments (cosine only)
-CONFIGS = [(sp, nw, r, True, 4, False, 2, False, False) for sp in SPACES for nw in (4, 8) for r in (2, 4)] + [
-    ("cosine", 4, 4, False, 4, False, 2, False, False), ("cosine", 8, 4, False, 4, False, 2, False, False),
-    ("cosine", 8, 4, True, 4, True, 2, False, False)] + [
-    (sp, 4, r, True, 4, False, 4, False, False) for sp in SPACES for r in (2, 4)] + [
-    (sp, 8, r, True, 4, False, 2, True, False) for sp in SPACES for r in (2, 4)] + [
-    (sp, 8, 4, True, 4, False, 2, True, True) for sp in SPACES]
-# int8 shadow bodies (QD slot 208 in the dispatch), with and without progress-based wave priorities: the int8 body is
-# not pinned by the power cap (pipe 56 % busy at 1.95 GHz), so evening out the barrier parking pays here (+2 %)
-I8_CONFIGS = [(sp, 8, 4, True, 4, pr, 2, True, False) for sp in SPACES for pr in (False, True)]
-# timing diagnostics (cosine, NW=8, R=4, nt): QD slot carries the knob: 101 = nolds, 102 = nox, 103 = both
-DIAG = {101: {"nolds"}, 102: {"nox"}, 103: {"nolds", "nox"}, 104: {"nolds", "nox", "nobar"},
-        107: {"nohit"}, 108: {"stamp"}, 109: {"noadm"}}
+# ---------------------------------------------------------------------------------------------------------------------
+# What gets generated.  Every entry: (file name, dispatch condition of filter_scan_asm_kernel's template arguments, thunk
+# that returns the text, kind) with kind "default" (the library as shipped), "ab" (`make AB=1`: tuning variants for
+# tools/scan_ab.py and the `ab`-marked tests) or "diag" (`make DIAG=1`: timing diagnostics, wrong results by design).
+def cond(space, nw, r, nt, qd, prio, mt, dma, stag):
+    return (f"SPACE == {SPACES[space]} && NW == {nw} && R == {r} && NT == {'true' if nt else 'false'} && QD == {qd}"
+            f" && PRIO == {'true' if prio else 'false'} && MT == {mt} && DMA == {'true' if dma else 'false'}"
+            f" && STAG == {'true' if stag else 'false'}")
 
 
 def inc_name(space, nw, r, nt, qd, prio, mt, dma, stag=False):
@@ -1111,136 +1106,117 @@ def default_i8_body(space):
     return generate(space, 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True)
 
 
+def with_dbg(knobs, *args, **kw):
+    DBG.clear()
+    DBG.update(knobs)
+    try:
+        return generate(*args, **kw)
+    finally:
+        DBG.clear()
+
+
+def entries():
+    E = []
+    # ---- default library
+    for sp in SPACES:   # the int8 bodies with ArchVGPR accumulators (wave priorities on): QD slot 211
+        E.append((f"scan_asm_{sp}_i8_va.inc", cond(sp, 8, 4, True, 211, True, 2, True, False), (lambda sp=sp: default_i8_body(sp)), "default"))
+    # 237: round 2's default body (append routine with eight skipped row blocks, stubs without the early out): the A/B reference
+    E.append(("scan_asm_cosine_i8_va_r2.inc", cond("cosine", 8, 4, True, 237, True, 2, True, False),
+              lambda: with_dbg((), "cosine", 4, 4, 8, True, True, 2, True, False, True, True), "default"))
+    for sp in SPACES:   # bf16 bodies of an index that keeps a bf16 shadow: 8 waves, LDS-DMA staging, ring of 4 (2: odd chunk counts)
+        for r in (4, 2):
+            c = (sp, 8, r, True, 4, False, 2, True, False)
+            E.append((inc_name(*c), cond(*c), (lambda c=c: with_dbg((), c[0], c[2], c[4], c[1], c[3], c[5], c[6], c[7], c[8])), "default"))
+    # ---- make AB=1: the other geometries of the bf16 body
+    ab_cfgs = [(sp, nw, r, True, 4, False, 2, False, False) for sp in SPACES for nw in (4, 8) for r in (2, 4)] + [
+        ("cosine", 4, 4, False, 4, False, 2, False, False), ("cosine", 8, 4, False, 4, False, 2, False, False),
+        ("cosine", 8, 4, True, 4, True, 2, False, False)] + [
+        (sp, 4, r, True, 4, False, 4, False, False) for sp in SPACES for r in (2, 4)] + [
+        (sp, 8, 4, True, 4, False, 2, True, True) for sp in SPACES]
+    for c in ab_cfgs:
+        E.append((inc_name(*c), cond(*c), (lambda c=c: with_dbg((), c[0], c[2], c[4], c[1], c[3], c[5], c[6], c[7], c[8])), "ab"))
+    # int8 bodies with AccVGPR accumulators and the serial admission phase (round 1; QD slot 208), with / without wave priorities
+    for sp in SPACES:
+        for pr in (False, True):
+            E.append((f"scan_asm_{sp}_i8{'_pr' if pr else ''}.inc", cond(sp, 8, 4, True, 208, pr, 2, True, False),
+                      (lambda sp=sp, pr=pr: with_dbg((), sp, 4, 4, 8, True, pr, 2, True, False, True)), "ab"))
+    G = lambda *a, **k: (lambda: with_dbg((), *a, **k))
+    cos = "cosine"
+    # tuning variants of the folded cosine body (DESIGN / profiles/r02, r03)
+    E += [
+        ("scan_asm_cosine_i8_va_r6.inc", cond(cos, 8, 6, True, 214, True, 2, True, False), G(cos, 6, 4, 8, True, True, 2, True, False, True, True), "ab"),
+        ("scan_asm_cosine_i8_va_qd8.inc", cond(cos, 8, 4, True, 215, True, 2, True, False), G(cos, 4, 8, 8, True, True, 2, True, False, True, True), "ab"),
+        ("scan_asm_cosine_i8_va_nopr.inc", cond(cos, 8, 4, True, 216, False, 2, True, False), G(cos, 4, 4, 8, True, False, 2, True, False, True, True), "ab"),
+        ("scan_asm_cosine_i8_va_nw4.inc", cond(cos, 4, 4, True, 217, False, 2, True, False), G(cos, 4, 4, 4, True, False, 2, True, False, True, True), "ab"),
+        ("scan_asm_cosine_i8_va_nw4_pr.inc", cond(cos, 4, 4, True, 218, True, 2, True, False), G(cos, 4, 4, 4, True, True, 2, True, False, True, True), "ab"),
+        ("scan_asm_cosine_i8_va_q3d.inc", cond(cos, 8, 6, True, 229, True, 2, True, False), G(cos, 6, 4, 8, True, True, 2, True, False, True, True, False, None, 0, True), "ab"),
+        ("scan_asm_cosine_i8_va_r6b3.inc", cond(cos, 8, 6, True, 228, True, 2, True, False), G(cos, 6, 4, 8, True, True, 2, True, False, True, True, False, None, 3), "ab"),
+        ("scan_asm_cosine_i8_va_stag.inc", cond(cos, 8, 4, True, 222, True, 2, True, True), G(cos, 4, 4, 8, True, True, 2, True, True, True, True), "ab"),
+        ("scan_asm_cosine_i8_va_p0.inc", cond(cos, 8, 4, True, 220, True, 2, True, False), G(cos, 4, 4, 8, True, True, 2, True, False, True, True, False, 0), "ab"),
+        ("scan_asm_cosine_i8_va_p4.inc", cond(cos, 8, 4, True, 221, True, 2, True, False), G(cos, 4, 4, 8, True, True, 2, True, False, True, True, False, 1), "ab"),
+        ("scan_asm_cosine_i8_mt4.inc", cond(cos, 4, 4, True, 230, False, 4, True, False), G(cos, 4, 4, 4, True, False, 4, True, False, True), "ab"),
+        ("scan_asm_cosine_i8_va_q4.inc", cond(cos, 8, 4, True, 219, True, 2, True, False), G(cos, 4, 4, 8, True, True, 2, True, False, True, True, True), "ab"),
+        ("scan_asm_cosine_i8_va_qa.inc", cond(cos, 8, 4, True, 231, True, 2, True, False), G(cos, 4, 4, 8, True, True, 2, True, False, True, True, qa=True), "ab"),
+        ("scan_asm_cosine_i8_va_eo.inc", cond(cos, 8, 4, True, 232, True, 2, True, False), G(cos, 4, 4, 8, True, True, 2, True, False, True, True, eo=True), "ab"),
+        ("scan_asm_cosine_i8_va_qa_eo.inc", cond(cos, 8, 4, True, 233, True, 2, True, False), G(cos, 4, 4, 8, True, True, 2, True, False, True, True, qa=True, eo=True), "ab"),
+        ("scan_asm_cosine_i8_va_fs.inc", cond(cos, 8, 4, True, 235, True, 2, True, False), G(cos, 4, 4, 8, True, True, 2, True, False, True, True, fs=True), "ab"),
+        ("scan_asm_cosine_i8_va_eo_fs.inc", cond(cos, 8, 4, True, 236, True, 2, True, False), G(cos, 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True), "ab"),
+    ]
+    # ---- make DIAG=1 (implies AB): timing diagnostics.  bf16 body (NW=8, R=4, nt, register staging): QD slot = the knob
+    D = lambda knobs, *a, **k: (lambda: with_dbg(knobs, *a, **k))
+    for code, knobs in ((101, {"nolds"}), (102, {"nox"}), (103, {"nolds", "nox"}), (104, {"nolds", "nox", "nobar"}),
+                        (107, {"nohit"}), (108, {"stamp"}), (109, {"noadm"})):
+        E.append((f"scan_asm_diag{code}.inc", cond(cos, 8, 4, True, code, False, 2, False, False), D(knobs, cos, 4, 4, 8, True, False), "diag"))
+    # int8 body, AccVGPR accumulators: 209 without its admission test, 210 the test's arithmetic without the accumulator reads
+    E.append(("scan_asm_diag209.inc", cond(cos, 8, 4, True, 209, True, 2, True, False), D({"noadm"}, cos, 4, 4, 8, True, True, 2, True, False, True), "diag"))
+    E.append(("scan_asm_diag210.inc", cond(cos, 8, 4, True, 210, True, 2, True, False), D({"noread", "nohit"}, cos, 4, 4, 8, True, True, 2, True, False, True), "diag"))
+    # folded body: 212 no hit ever taken, 213 no admission test, 223..227 without its MFMAs / X loads / B reads / Q staging
+    for code, knobs in ((212, {"nohit"}), (213, {"noadm"}), (223, {"nomfma", "nohit"}), (224, {"nox", "nohit"}), (225, {"nolds", "nohit"}),
+                        (226, {"nox", "nolds", "nohit"}), (227, {"noq", "nohit"})):
+        E.append((f"scan_asm_diag{code}.inc", cond(cos, 8, 4, True, code, True, 2, True, False), D(knobs, cos, 4, 4, 8, True, True, 2, True, False, True, True), "diag"))
+    # 234: the default body; the C++ wrapper stamps its phases around it (correct results).  Stamps INSIDE the statement were
+    # tried: two more live SGPR outputs do not fit (the "s" inputs then come out as VGPRs and the assembler refuses them), two
+    # more VGPR outputs make hipcc's register allocator hang (> 40 minutes, killed)
+    E.append(("scan_asm_diag234.inc", cond(cos, 8, 4, True, 234, True, 2, True, False), lambda: default_i8_body(cos), "diag"))
+    return E
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--outdir", default=str(Path(__file__).resolve().parents[1] / "mlvectordb_amd" / "csrc"))
     ap.add_argument("--list", action="store_true", help="print the generated file names and exit")
+    ap.add_argument("--ab", action="store_true", help="also the tuning variants (make AB=1)")
+    ap.add_argument("--diag", action="store_true", help="also the timing diagnostics (make DIAG=1; implies --ab)")
     args = ap.parse_args()
-    names = [inc_name(*c) for c in CONFIGS] + [f"scan_asm_{sp}_i8{pr}.inc" for sp in SPACES for pr in ("", "_pr")] + [f"scan_asm_{sp}_i8_va.inc" for sp in SPACES] + ["scan_asm_diag212.inc", "scan_asm_diag213.inc", "scan_asm_diag223.inc", "scan_asm_diag224.inc", "scan_asm_diag225.inc", "scan_asm_diag226.inc", "scan_asm_diag227.inc", "scan_asm_cosine_i8_va_r6.inc", "scan_asm_cosine_i8_va_qd8.inc", "scan_asm_cosine_i8_va_nopr.inc", "scan_asm_cosine_i8_va_nw4.inc", "scan_asm_cosine_i8_va_nw4_pr.inc", "scan_asm_cosine_i8_va_q4.inc", "scan_asm_cosine_i8_va_p0.inc", "scan_asm_cosine_i8_va_p4.inc", "scan_asm_cosine_i8_va_stag.inc", "scan_asm_cosine_i8_va_r6b3.inc", "scan_asm_cosine_i8_va_q3d.inc", "scan_asm_cosine_i8_mt4.inc", "scan_asm_cosine_i8_va_qa.inc", "scan_asm_cosine_i8_va_eo.inc", "scan_asm_cosine_i8_va_qa_eo.inc", "scan_asm_cosine_i8_va_fs.inc", "scan_asm_cosine_i8_va_eo_fs.inc", "scan_asm_cosine_i8_va_r2.inc", "scan_asm_diag234.inc"] + [f"scan_asm_diag{c}.inc" for c in DIAG] + ["scan_asm_diag209.inc", "scan_asm_diag210.inc", "scan_asm_dispatch.inc", "scan_asm_consts.inc"]
+    kinds = {"default"} | ({"ab"} if args.ab or args.diag else set()) | ({"diag"} if args.diag else set())
+    E = entries()
+    names = [e[0] for e in E if e[3] in kinds] + ["scan_asm_dispatch.inc", "scan_asm_consts.inc"]
     if args.list:
         print(" ".join(names))
         return
-    for c in CONFIGS:
-        space, nw, r, nt, qd, prio, mt, dma, stag = c
-        (Path(args.outdir) / inc_name(*c)).write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag))
-    for space, nw, r, nt, qd, prio, mt, dma, stag in I8_CONFIGS:
-        (Path(args.outdir) / f"scan_asm_{space}_i8{'_pr' if prio else ''}.inc").write_text(generate(space, r, qd, nw, nt, prio, mt, dma, stag, True))
-    for space in SPACES:   # the int8 bodies with ArchVGPR accumulators (wave priorities on): QD slot 211
-        (Path(args.outdir) / f"scan_asm_{space}_i8_va.inc").write_text(default_i8_body(space))
-    for code, knobs in DIAG.items():
-        DBG.clear()
-        DBG.update(knobs)
-        (Path(args.outdir) / f"scan_asm_diag{code}.inc").write_text(generate("cosine", 4, 4, 8, True, False))
-        DBG.clear()
-    DBG.update({"noadm"})   # 209: the int8 body (cosine, wave priorities) without its admission test
-    (Path(args.outdir) / "scan_asm_diag209.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True))
-    DBG.clear()
-    DBG.update({"noread", "nohit"})   # 210: ... with the test's arithmetic but without the accumulator reads (and no hits)
-    (Path(args.outdir) / "scan_asm_diag210.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True))
-    DBG.clear()
-    # tuning variants of the folded cosine body (QD slot: 214 ring of 6 k-steps, 215 B fragments read 8 ahead, 216 no wave priorities)
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_r6.inc").write_text(generate("cosine", 6, 4, 8, True, True, 2, True, False, True, True))
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_qd8.inc").write_text(generate("cosine", 4, 8, 8, True, True, 2, True, False, True, True))
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_nopr.inc").write_text(generate("cosine", 4, 4, 8, True, False, 2, True, False, True, True))
-    # 217 / 218: two 4-wave workgroups per CU (independent barriers: one's chunk-boundary bubble under the other's MFMAs)
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_nw4.inc").write_text(generate("cosine", 4, 4, 4, True, False, 2, True, False, True, True))
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_nw4_pr.inc").write_text(generate("cosine", 4, 4, 4, True, True, 2, True, False, True, True))
-    # 220 / 221: the default body with its code placement pinned to a 64-byte boundary / that + 4 bytes
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_p0.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, False, 0))
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_p4.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, False, 1))
-    # 222: the later half of the waves half a tile behind (round 1's stagger, now that no serial admission phase is left)
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_stag.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, True, True, True))
-    # 228: ring of 6 k-steps refilled in bursts of 3 (3 contiguous KiB per panel at once)
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_r6b3.inc").write_text(generate("cosine", 6, 4, 8, True, True, 2, True, False, True, True, False, None, 3))
-    # 229: ring of 6 + Q staged three chunks ahead, awaited two chunks later
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_q3d.inc").write_text(generate("cosine", 6, 4, 8, True, True, 2, True, False, True, True, False, None, 0, True))
-    # 230: 64 rows per wave, one wave per SIMD (4-wave workgroups), AccVGPR accumulators a[0:255], serial admission test --
-    # the int8 counterpart of MLVDB_SCAN_MT=4, to be compared with the 32-row body of the same structure (QD slot 208)
-    (Path(args.outdir) / "scan_asm_cosine_i8_mt4.inc").write_text(generate("cosine", 4, 4, 4, True, False, 4, True, False, True))
-    # 219: four Q buffers, one barrier per two chunks
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_q4.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, True))
-    DBG.update({"nohit"})   # 212: the folded pre-test computed, no hit ever taken
-    (Path(args.outdir) / "scan_asm_diag212.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
-    DBG.clear()
-    # the folded body without its X loads / B reads / Q staging (and never taking a hit: the bounds are garbage then)
-    for code, knobs in ((224, {"nox", "nohit"}), (225, {"nolds", "nohit"}), (226, {"nox", "nolds", "nohit"}), (227, {"noq", "nohit"}),
-                        (223, {"nomfma", "nohit"})):   # 223: no MFMAs at all: the kernel's streams (X, Q, B reads, barriers) alone
-        DBG.update(knobs)
-        (Path(args.outdir) / f"scan_asm_diag{code}.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
-        DBG.clear()
-    # round 3: B-fragment reads across the chunk barrier (231), early-out hit stubs (232), both (233)
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_qa.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, qa=True))
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_eo.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, eo=True))
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_qa_eo.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, qa=True, eo=True))
-    # straight-line append routine (235), with the early-out stubs (236)
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_fs.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, fs=True))
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_eo_fs.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True))
-    # 237: round 2's default body (append routine with eight skipped row blocks, stubs without the early out), for A/B
-    (Path(args.outdir) / "scan_asm_cosine_i8_va_r2.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
-    # 234: the default body; the C++ wrapper stamps its phases around it (correct results; DIAG builds only).  Stamps INSIDE
-    # the statement were tried: two more live SGPR outputs do not fit (the "s" inputs then come out as VGPRs and the
-    # assembler refuses them), two more VGPR outputs make hipcc's register allocator hang (> 40 minutes, killed)
-    (Path(args.outdir) / "scan_asm_diag234.inc").write_text(default_i8_body("cosine"))
-    DBG.update({"noadm"})   # 213: ArchVGPR accumulators, no admission test at all
-    (Path(args.outdir) / "scan_asm_diag213.inc").write_text(generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True))
-    DBG.clear()
+    out = Path(args.outdir)
+    for name, _, thunk, kind in E:
+        if kind in kinds:
+            (out / name).write_text(thunk())
+    # the dispatch names every body; the AB / DIAG ones sit behind the build's macros, so their files need not exist otherwise
     disp = ["// GENERATED by tools/gen_scan_asm.py -- do not edit.  Body of filter_scan_asm_kernel<SPACE, R, NW, NT, QD, PRIO, MT, DMA, STAG>."]
-    for i, (space, nw, r, nt, qd, prio, mt, dma, stag) in enumerate(CONFIGS):
-        cond = (f"SPACE == {SPACES[space]} && NW == {nw} && R == {r} && NT == {'true' if nt else 'false'} && QD == {qd}"
-                f" && PRIO == {'true' if prio else 'false'} && MT == {mt} && DMA == {'true' if dma else 'false'}"
-                f" && STAG == {'true' if stag else 'false'}")
-        disp.append(("if" if i == 0 else "} else if") + f" constexpr ({cond}) {{")
-        disp.append(f'#include "{inc_name(space, nw, r, nt, qd, prio, mt, dma, stag)}"')
-    for sp, code in SPACES.items():
-        for pr in (False, True):
-            disp.append(f"}} else if constexpr (SPACE == {code} && NW == 8 && R == 4 && NT == true && QD == 208 && PRIO == {'true' if pr else 'false'} && MT == 2 && DMA == true && STAG == false) {{")
-            disp.append(f'#include "scan_asm_{sp}_i8{"_pr" if pr else ""}.inc"')
-    for sp, code in SPACES.items():
-        disp.append(f"}} else if constexpr (SPACE == {code} && NW == 8 && R == 4 && NT == true && QD == 211 && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
-        disp.append(f'#include "scan_asm_{sp}_i8_va.inc"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 6 && NT == true && QD == 214 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
-    disp.append('#include "scan_asm_cosine_i8_va_r6.inc"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 215 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
-    disp.append('#include "scan_asm_cosine_i8_va_qd8.inc"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 216 && PRIO == false && MT == 2 && DMA == true && STAG == false) {")
-    disp.append('#include "scan_asm_cosine_i8_va_nopr.inc"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 4 && R == 4 && NT == true && QD == 217 && PRIO == false && MT == 2 && DMA == true && STAG == false) {")
-    disp.append('#include "scan_asm_cosine_i8_va_nw4.inc"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 4 && R == 4 && NT == true && QD == 218 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
-    disp.append('#include "scan_asm_cosine_i8_va_nw4_pr.inc"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 6 && NT == true && QD == 229 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
-    disp.append('#include "scan_asm_cosine_i8_va_q3d.inc"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 6 && NT == true && QD == 228 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
-    disp.append('#include "scan_asm_cosine_i8_va_r6b3.inc"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 222 && PRIO == true && MT == 2 && DMA == true && STAG == true) {")
-    disp.append('#include "scan_asm_cosine_i8_va_stag.inc"')
-    for code, nm in ((220, "p0"), (221, "p4")):
-        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
-        disp.append(f'#include "scan_asm_cosine_i8_va_{nm}.inc"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 4 && R == 4 && NT == true && QD == 230 && PRIO == false && MT == 4 && DMA == true && STAG == false) {")
-    disp.append('#include "scan_asm_cosine_i8_mt4.inc"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 219 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
-    disp.append('#include "scan_asm_cosine_i8_va_q4.inc"')
-    for code, nm in ((231, "qa"), (232, "eo"), (233, "qa_eo"), (235, "fs"), (236, "eo_fs"), (237, "r2")):
-        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
-        disp.append(f'#include "scan_asm_cosine_i8_va_{nm}.inc"')
-    disp.append("#ifdef MLVDB_SCAN_DIAGNOSTICS  // timing diagnostics: wrong results by design, never in a product build")
-    for code in DIAG:
-        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == false && MT == 2 && DMA == false && STAG == false) {{")
-        disp.append(f'#include "scan_asm_diag{code}.inc"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 209 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
-    disp.append('#include "scan_asm_diag209.inc"')
-    disp.append("} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == 210 && PRIO == true && MT == 2 && DMA == true && STAG == false) {")
-    disp.append('#include "scan_asm_diag210.inc"')
-    for code in (212, 213, 223, 224, 225, 226, 227, 234):
-        disp.append(f"}} else if constexpr (SPACE == 1 && NW == 8 && R == 4 && NT == true && QD == {code} && PRIO == true && MT == 2 && DMA == true && STAG == false) {{")
-        disp.append(f'#include "scan_asm_diag{code}.inc"')
-    disp.append("#endif")
+    first = True
+    for kind, guard in (("default", None), ("ab", "MLVDB_AB"), ("diag", "MLVDB_SCAN_DIAGNOSTICS")):
+        if guard:
+            disp.append(f"#ifdef {guard}")
+        for name, c, _, k in E:
+            if k != kind:
+                continue
+            disp.append(("if" if first else "} else if") + f" constexpr ({c}) {{")
+            disp.append(f'#include "{name}"')
+            first = False
+        if guard:
+            disp.append("#endif")
     disp.append("} else {")
-    disp.append('    static_assert(SPACE < 0, "configuration not generated: add it to CONFIGS in tools/gen_scan_asm.py");')
+    disp.append('    static_assert(SPACE < 0, "configuration not generated (or not in this build: make AB=1 / DIAG=1): see entries() in tools/gen_scan_asm.py");')
     disp.append("}")
-    (Path(args.outdir) / "scan_asm_dispatch.inc").write_text("\n".join(disp) + "\n")
-    (Path(args.outdir) / "scan_asm_consts.inc").write_text(
+    (out / "scan_asm_dispatch.inc").write_text("\n".join(disp) + "\n")
+    (out / "scan_asm_consts.inc").write_text(
         "// GENERATED by tools/gen_scan_asm.py -- do not edit.\n"
         f"constexpr int kAsmWgCap = {WG_CAP};\n"
         f"constexpr int kAsmStageCapNw4 = {lds_stage_cap(4, 2, 2)};  // entries per wave staged in LDS\n"

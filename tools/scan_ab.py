@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
 """A/B the filter-scan kernel variants in ONE process on one resident corpus (tuning aid).
 
-Variants are compile-time instantiations picked per launch from environment variables
-(MLVDB_SCAN_ASM, MLVDB_SCAN_NW, MLVDB_SCAN_R, MLVDB_SCAN_MT), given as --envs "A=1,B=2;A=0".
+Variants are compile-time instantiations picked per launch from the handle's tuning state (mlvdb_index_set_tuning: the
+library reads the environment only when a handle is created), given as --envs "A=1,B=2;A=0" with the tuning keys
+(SCAN_VAR, SCAN_NW, I8, ...; an MLVDB_ prefix is accepted).  Most variants exist only in the AB build:
+    make -C mlvectordb_amd/csrc AB=1 && MLVDB_HIP_LIBRARY=mlvectordb_amd/csrc/libmlvdb_hip_ab.so python tools/scan_ab.py ...
 Prints per-variant median wave time and scan-kernel GB/s (HIP events), interleaved over rounds.
 """
 import argparse
-import os
 import sys
 import time
 from pathlib import Path
@@ -23,7 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--waves", type=int, default=6)
-    ap.add_argument("--envs", default="MLVDB_SCAN_ASM=0;MLVDB_SCAN_ASM=1;MLVDB_SCAN_ASM=1,MLVDB_SCAN_NW=8")
+    ap.add_argument("--envs", default=";SCAN_VAR=237")
     ap.add_argument("--space", default="cosine")
     ap.add_argument("--no-check", action="store_true", help="timing diagnostics that change the answer")
     args = ap.parse_args()
@@ -43,15 +44,13 @@ def main():
     eng.set_profiling(True)
     combos = [c for c in args.envs.split(";")]
     keys = sorted({kv.split("=")[0] for c in combos for kv in c.split(",") if kv})
+    defaults = {key: eng.get_tuning(key) for key in keys}
     res = {c: {"wave": [], "scan": [], "bytes": 0} for c in combos}
     ref = None
     for rnd in range(args.rounds):
         for c in combos:
-            for key in keys:
-                os.environ.pop(key, None)
-            for kv in c.split(","):
-                if kv:
-                    os.environ[kv.split("=")[0]] = kv.split("=")[1]
+            eng.set_tuning(**defaults)
+            eng.set_tuning(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in c.split(",") if kv})
             for w in range(args.waves):
                 t0 = time.perf_counter()
                 eng.search_device(q.data_ptr(), args.batch, k, lab.data_ptr(), dst.data_ptr(), cnt.data_ptr(), 0, 0)

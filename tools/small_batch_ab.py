@@ -35,7 +35,7 @@ for nq in batches:
     ref = None
     line = [f"nq {nq:3d}:"]
     for name, strat, narrow in modes:
-        os.environ["MLVDB_SCAN_NARROW"] = narrow
+        eng.set_tuning(SCAN_NARROW=int(narrow))
         eng.set_strategy(strat)
         lat = []
         for i in range(args.iters + 5):
