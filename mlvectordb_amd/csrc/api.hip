@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <new>
 
 #include "internal.h"
@@ -87,6 +88,8 @@ struct mlvdb_index {
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;  // mlvdb_index_get_rows_at: a hit-enrichment gather must not queue behind the next scan
     DevBuf gather_out, gather_lab;     // its private buffers (a search may be running on `stream` from another host thread)
+    std::mutex aux_mutex;              // ... shared by the two entry points that use it (get_rows_at, pair_distances): a consumer
+                                       // thread enriching wave i and a caller scoring pairs must not swap the buffers under each other
     // workspaces (grow only)
     DevBuf stage, qpad, qaux, partial, qsel, seed_lab, seed_dist, seed_cnt, seed_d64;
     DevBuf cand_range, rhits, rhit_cnt;  // range passes: larger candidate lists, exact hits, hit counts
@@ -100,6 +103,10 @@ struct mlvdb_index {
     bool mask_active = false;  // h->rn is a masked copy (mlvdb_search_batch_filtered)
     bool mask_pairs_ready = false;  // ... and rp8_masked holds the masked copy of the int8 shadow's row pairs
     DevBuf rp8_masked;
+    // fp16 row-major shadow for the mid bounds (kernels_refine.hip): built lazily by the first range query / top_k > 64 search
+    DevBuf x16, s16, rowerr16, picks, npicks;
+    int64_t l2_rows = 0;      // rows [0, l2_rows) of the fp16 shadow are current (0 after compact / reset / regrowth)
+    bool l2_failed = false;   // its allocation failed once (HBM full): the callers fall back, nobody retries per call
     DevBuf qimg, fmisc, cand, rescr, wgbuf, wgcnt, io_q, io_lab, io_dist, io_cnt, io_d64, counters, labels_in;
     DevBuf page_lab, page_dist, page_cnt, page_d64, cur_d, cur_l;  // top_k > MLVDB_MAX_TOPK paging
     PinBuf pin_in, pin_out;          // pinned staging of the host-pointer entries (queries in; labels / distances / counts out)
@@ -735,6 +742,136 @@ int finish_filter_pass(mlvdb_index* h, hipStream_t s, FilterArgs& fa, int32_t q0
     return MLVDB_OK;
 }
 
+// ---- the fp16 row-major shadow of the mid bounds (kernels_refine.hip): kept current lazily, like the int8 shadow.
+// *m gets X16 == nullptr when the index keeps none (Tuning L2_SHADOW=0, or HBM was full when it was first wanted): the
+// callers then do without the second level.
+int attach_mid(mlvdb_index* h, hipStream_t s, MidArgs* m) {
+    *m = MidArgs{};
+    if (!h->tn.l2_shadow || h->l2_failed || h->total == 0) return MLVDB_OK;
+    const int32_t ld16 = (h->dim + 63) / 64 * 64;
+    const size_t need = (size_t)h->capacity * ld16 * sizeof(uint16_t), need_s = (size_t)h->capacity * sizeof(float);
+    if (h->x16.bytes < need || h->s16.bytes < need_s || !h->rowerr16.p) {
+        hipError_t e = h->x16.ensure(need);
+        if (e == hipSuccess) e = h->s16.ensure(need_s);
+        if (e == hipSuccess) e = h->rowerr16.ensure(sizeof(float));
+        if (e != hipSuccess) {  // not an error of the call: the index works without it
+            (void)hipGetLastError();
+            h->x16.release();
+            h->s16.release();
+            h->l2_failed = true;
+            return MLVDB_OK;
+        }
+        h->l2_rows = 0;
+    }
+    if (h->l2_rows == 0) {
+        HIP_TRY(h, hipMemsetAsync(h->x16.p, 0, need, s));  // (the columns dim..ld16 of every row stay zero)
+        HIP_TRY(h, hipMemsetAsync(h->rowerr16.p, 0, sizeof(float), s));
+    }
+    if (h->l2_rows < h->total) {
+        HIP_TRY(h, launch_shadow16_rows(h->X, h->x16.p, h->s16.as<float>(), h->rowerr16.as<float>(), h->l2_rows, h->total, h->ld,
+                                        ld16, s));
+        h->l2_rows = h->total;
+    }
+    m->X16 = h->x16.as<_Float16>();
+    m->s16 = h->s16.as<float>();
+    m->row_err16 = h->rowerr16.as<float>();
+    m->ld16 = ld16;
+    return MLVDB_OK;
+}
+
+int run_paged_exact(mlvdb_index* h, hipStream_t s, const float* Qpad, const double* qaux, int64_t nq_space,
+                    const int32_t* qsel, int32_t nsel, int32_t k, int64_t* out_labels, float* out_dist,
+                    int32_t* out_counts, double* out_d64);
+
+// ---- top_k in (64, 1024]: one pass of <= 256 queries on the filter path (round 4; DESIGN "big-k passes").
+// Structure: dense seeding pass over the first <= 65,280 rows (every bound into the query's 65,536-slot list) -> [select
+// the best-bounded entries -> mid (fp16) bounds for those not refined yet -> threshold = k-th largest mid LOWER bound, prune]
+// -> scan rounds of geometrically growing size, each followed by the same three kernels -> mid bounds for whatever is left
+// unrefined -> exact fp64 rescoring of the survivors (~1.02 k rows per query) -> ranking by (distance, label).
+// Round sizes: a launch may append ~BIGK_BUDGET entries per 256 queries x k before its waves' append buffers (2,048 entries
+// each) run over; with n rows seen the k-th best is at quantile k / n, so the next m rows yield ~nq m (k / n) band entries:
+// m = n BUDGET / (nq k).  A query whose list or wave buffer overflows all the same is served by the paged exact scan.
+// *handled = false: the index has no mid shadow (the caller takes the paged exact scan).
+int run_bigk_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, float* Qpad, double* qaux, int32_t q0, int32_t nq,
+                  int32_t k, int64_t* out_labels, float* out_dist, int32_t* out_counts, double* out_d64, bool* handled) {
+    *handled = false;
+    MidArgs m{};
+    int rc = attach_mid(h, s, &m);
+    if (rc) return rc;
+    if (!m.X16) return MLVDB_OK;
+    FilterArgs fa{};
+    rc = setup_filter_ws(h, fa, Qpad + (size_t)q0 * h->ld, qaux + q0, h->qerr.as<float>() + q0, nq);
+    if (rc) return rc;
+    HIP_TRY(h, h->cand_range.ensure((size_t)kFilterQueries * kRangeCandCap * sizeof(CandEntry)));
+    HIP_TRY(h, h->rhits.ensure((size_t)kFilterQueries * kCandCap * sizeof(RangeHit)));
+    HIP_TRY(h, h->rhit_cnt.ensure(kFilterQueries * sizeof(uint32_t)));
+    HIP_TRY(h, h->picks.ensure((size_t)kFilterQueries * kPicksCap * sizeof(uint32_t)));
+    HIP_TRY(h, h->npicks.ensure(kFilterQueries * sizeof(uint32_t)));
+    fa.cand = h->cand_range.as<CandEntry>();
+    fa.cand_cap = kRangeCandCap;
+    fa.rhits = h->rhits.as<RangeHit>();
+    fa.rhit_cnt = h->rhit_cnt.as<uint32_t>();
+    rc = attach_i8(h, s, fa);
+    if (rc) return rc;
+    rc = prep_pass(h, s, fa, queries_raw + (size_t)q0 * h->dim, Qpad + (size_t)q0 * h->ld, qaux + q0, h->qerr.as<float>() + q0);
+    if (rc) return rc;
+    h->stats.bound_dtype = fa.X8 ? 2 : 1;
+    uint32_t* picks = h->picks.as<uint32_t>();
+    uint32_t* npicks = h->npicks.as<uint32_t>();
+    MidArgs mp = m;  // refine the picks / (m) everything still unrefined
+    mp.picks = picks;
+    mp.npicks = npicks;
+    mp.picks_cap = kPicksCap;
+    const int32_t want = k + std::max(32, k / 4);
+    auto refine = [&](int32_t forced_cnt) -> int {
+        HIP_TRY(h, launch_bigk_select(fa, want, forced_cnt, picks, npicks, kPicksCap, s));
+        HIP_TRY(h, launch_mid_score(fa, mp, s));
+        HIP_TRY(h, launch_bigk_thr_prune(fa, m, k, forced_cnt, s));
+        return MLVDB_OK;
+    };
+    // seed: dense over the first rows (a multiple of 128; a whole number of 768-row units when rounds follow)
+    const int64_t n_seed = h->total > kBigSeedRows ? (int64_t)kBigSeedRows : (h->total + 127) / 128 * 128;
+    HIP_TRY(h, launch_filter_dense_scan(fa, n_seed, s));
+    rc = refine((int32_t)n_seed);
+    if (rc) return rc;
+    const double growth = std::min(24.0, std::max(1.5, 1.0 + (double)std::max(1, h->tn.bigk_budget) / ((double)std::max(nq, 16) * k)));
+    int64_t b = std::min<int64_t>(n_seed, h->total);
+    while (b < h->total) {
+        int64_t e = (int64_t)((double)b * growth) / kFilterTile * kFilterTile;
+        if (e <= b) e = b + kFilterTile;
+        if (e > h->total || (double)e * 1.25 > (double)h->total) e = h->total;  // (no sliver of a last round)
+        rc = scan_event(h, s, true);
+        if (rc) return rc;
+        ScanInfo info;
+        HIP_TRY(h, launch_filter_scan(fa, b, e, s, &info));
+        rc = scan_event(h, s, false);
+        if (rc) return rc;
+        h->stats.scan_launches += 1;
+        h->stats.rows_scanned += e - b;
+        rc = refine(-1);
+        if (rc) return rc;
+        b = e;
+    }
+    // whatever survived without a mid bound (the band of the last rounds) gets one; the threshold then rests on all of them
+    HIP_TRY(h, launch_mid_score(fa, m, s));
+    HIP_TRY(h, launch_bigk_thr_prune(fa, m, k, -1, s));
+    unsigned long long* stats = h->counters.as<unsigned long long>();
+    HIP_TRY(h, launch_knn_rescore_rank(fa, k, q0, out_labels, out_dist, out_counts, out_d64, stats, s));
+    // overflowed queries (a list or a wave's append buffer ran over, or more than 8,192 rows tie into the top k): the
+    // paged exact scan serves them; the decision needs the host here (one synchronisation per pass, top_k > 64 only)
+    int32_t n_flagged = 0;
+    rc = collect_overflow(h, s, fa, &n_flagged);
+    if (rc) return rc;
+    if (n_flagged) {
+        h->host_fallbacks += n_flagged;
+        rc = run_paged_exact(h, s, fa.Qpad, fa.qaux, nq, h->qsel.as<int32_t>(), n_flagged, k, out_labels + (size_t)q0 * k,
+                             out_dist + (size_t)q0 * k, out_counts + q0, out_d64 ? out_d64 + (size_t)q0 * k : nullptr);
+        if (rc) return rc;
+    }
+    *handled = true;
+    return MLVDB_OK;
+}
+
 // ---- top_k above MLVDB_MAX_TOPK: rank-ordered pages of the exact scan.  Page p returns the next
 // entries strictly after the cursor (fp64 distance, label) of page p-1, so pages never overlap.
 // Query ids: blockIdx / thread index i addresses qsel[i] when a selection is given.
@@ -990,7 +1127,7 @@ int mlvdb_index_destroy(mlvdb_index* h) {
     if (h->rn) (void)hipFree(h->rn);
     if (h->Xb) (void)hipFree(h->Xb);
     for (DevBuf* b : {&h->stage, &h->qpad, &h->qaux, &h->partial, &h->qsel, &h->seed_lab, &h->seed_dist, &h->seed_cnt,
-                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->rescr, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->qerr, &h->rowerr, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt, &h->io_d64, &h->gather_out, &h->gather_lab, &h->cand_range, &h->rhits, &h->rhit_cnt, &h->rp8_masked, &h->x8, &h->rp8, &h->rowerr8, &h->qimg8, &h->sq8,
+                      &h->seed_d64, &h->qimg, &h->fmisc, &h->cand, &h->rescr, &h->wgbuf, &h->wgcnt, &h->row_mask, &h->rn_masked, &h->qerr, &h->rowerr, &h->io_q, &h->io_lab, &h->io_dist, &h->io_cnt, &h->io_d64, &h->gather_out, &h->gather_lab, &h->cand_range, &h->rhits, &h->rhit_cnt, &h->rp8_masked, &h->x16, &h->s16, &h->rowerr16, &h->picks, &h->npicks, &h->x8, &h->rp8, &h->rowerr8, &h->qimg8, &h->sq8,
                       &h->counters, &h->labels_in, &h->page_lab, &h->page_dist, &h->page_cnt, &h->page_d64, &h->cur_d,
                       &h->cur_l})
         b->release();
@@ -1137,6 +1274,7 @@ int mlvdb_index_compact(mlvdb_index* h, int64_t* old_labels, int64_t capacity, i
     h->total = want;
     h->deleted = 0;
     h->i8_rows = 0;
+    h->l2_rows = 0;
     return MLVDB_OK;
     });
 }
@@ -1165,6 +1303,7 @@ int mlvdb_index_reset(mlvdb_index* h, int32_t space) {
     h->total = 0;
     h->deleted = 0;
     h->i8_rows = 0;
+    h->l2_rows = 0;
     if (space >= 0) h->space = space;
     return MLVDB_OK;
     });
@@ -1199,6 +1338,7 @@ int mlvdb_index_get_rows_at(mlvdb_index* h, const int64_t* labels, int64_t n, fl
     // Own stream and buffers: rows are immutable once appended, so this may overlap a search that another host thread
     // has in flight on h->stream (QueryProcessor.find_similar_stream enriches wave i while wave i+1 is scanned).
     hipStream_t s = h->aux_stream;
+    std::lock_guard<std::mutex> aux_lock(h->aux_mutex);
     const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(64u << 20) / ((int64_t)h->dim * 4));
     for (int64_t done = 0; done < n; done += chunk_rows) {
         const int64_t m = std::min(chunk_rows, n - done);
@@ -1257,10 +1397,29 @@ static int search_device_impl(mlvdb_index* h, const float* queries_device, int64
     rc = filter_ready(h, s, &ready);
     if (rc) return rc;
     const bool filt = k <= MLVDB_MAX_TOPK && use_filter(h, nq, ready);
-    if (!filt)  // (the filter passes prepare their own queries: one fused launch each)
+    if (!filt && k <= MLVDB_MAX_TOPK)  // (the filter passes prepare their own queries: one fused launch each)
         HIP_TRY(h, launch_query_prep(queries_device, (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
                                      h->qaux.as<double>(), h->qerr.as<float>(), s));
-    if (k > MLVDB_MAX_TOPK) {
+    bool bigk_done = false;
+    if (k > MLVDB_MAX_TOPK && k <= kBigKMax && h->tn.bigk && use_filter(h, nq, ready) && h->total - h->deleted > (int64_t)k) {
+        // top_k 65..1024 stays on the filter path (round 4): passes of 256 queries with 65,536-slot lists, mid bounds, exact
+        // rescoring of the survivors.  (The first pass tells whether the index has a mid shadow at all.)
+        h->counters_pending = true;
+        for (int64_t q0 = 0; q0 < nq; q0 += kFilterQueries) {
+            const int32_t n = (int32_t)std::min<int64_t>(kFilterQueries, nq - q0);
+            bool handled = false;
+            rc = run_bigk_pass(h, s, queries_device, h->qpad.as<float>(), h->qaux.as<double>(), (int32_t)q0, n, k, out_labels_device,
+                               out_dist_device, out_counts_device, out_dist64_device, &handled);
+            if (rc) return rc;
+            if (!handled) break;  // (only ever the first pass)
+            bigk_done = true;
+        }
+        if (bigk_done) h->stats.strategy_used = MLVDB_STRATEGY_FILTER;
+    }
+    if (bigk_done) {
+    } else if (k > MLVDB_MAX_TOPK) {
+        HIP_TRY(h, launch_query_prep(queries_device, (int32_t)nq, h->dim, h->ld, h->space, h->qpad.as<float>(),
+                                     h->qaux.as<double>(), h->qerr.as<float>(), s));
         h->stats.strategy_used = MLVDB_STRATEGY_EXACT;
         rc = run_paged_exact(h, s, h->qpad.as<float>(), h->qaux.as<double>(), nq, nullptr, (int32_t)nq, k, out_labels_device,
                              out_dist_device, out_counts_device, out_dist64_device);
@@ -1301,8 +1460,6 @@ int search_host(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, int
     HIP_TRY(h, h->io_q.ensure(qbytes));
     const size_t fbytes = kFilterQueries * sizeof(uint32_t), obytes_all = ((obytes + 15) & ~(size_t)15) + fbytes;
     HIP_TRY(h, h->io_out.ensure(obytes_all));
-    HIP_TRY(h, h->pin_in.ensure(qbytes));
-    HIP_TRY(h, h->pin_out.ensure(obytes_all));
     // (Tried in round 3: outputs of small batches written by the kernels straight into host-mapped pinned memory -- no D2H
     // copy, one host wait instead of two.  No gain: 0.239 vs 0.238 ms at batch 1 on 1M x 768; removed.)
     char* dout = h->io_out.as<char>();
@@ -1315,10 +1472,16 @@ int search_host(mlvdb_index* h, const float* queries, int64_t nq, int32_t k, int
     // whole scan and every copy of the index's other stream -- the hit-enrichment gather of find_similar_stream -- waits
     // with it; measured on 4M rows: protocol stream 1.92 ms per wave parked vs 1.20 unparked (engine alone 1.07;
     // profiles/r03/protocol_stream_pinned_io_modes_4m.txt).  A blocking event wait instead of hipStreamSynchronize: no change.
-    const bool pinned = h->tn.pinned_io != 0;
+    // (pinned staging only while it stays small: a paged search with nq = 1024, k = 16384 would pin ~400 MB per handle -- per
+    // shard under MultiDeviceEngine -- for the handle's lifetime, and every growth goes through hipHostFree / hipHostMalloc,
+    // which synchronise the device; above 16 MB the pageable copies of round 2 are used and nothing stays pinned)
+    constexpr size_t kPinnedMax = (size_t)16 << 20;
+    const bool pinned = h->tn.pinned_io != 0 && qbytes <= kPinnedMax && obytes_all <= kPinnedMax;
     h->flags_in_out = pinned;  // the pass copies its overflow flags device-to-device behind the outputs (no parked D2H either)
     h->flags_out = reinterpret_cast<uint32_t*>(dout + ((obytes + 15) & ~(size_t)15));
     if (pinned) {
+        HIP_TRY(h, h->pin_in.ensure(qbytes));
+        HIP_TRY(h, h->pin_out.ensure(obytes_all));
         std::memcpy(h->pin_in.p, queries, qbytes);
         HIP_TRY(h, hipMemcpyAsync(h->io_q.p, h->pin_in.p, qbytes, hipMemcpyHostToDevice, h->stream));
     } else {
@@ -1506,6 +1669,17 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
             range_resolve_kernel<<<1, n_flagged, 0, s>>>(fa.overflow, fa.cnt, qsel, (uint32_t)fa.cand_cap);
             HIP_TRY(h, hipGetLastError());
         }
+        // mid bounds first (round 4): the int8 band admits ~8x the hits; a pass over the candidates' fp16 rows (whole 128-byte
+        // lines, half the bytes of the fp32 rows) prunes it to ~1.01x, so the exact gather below touches (nearly) only hits
+        if (filt && h->tn.range_l2) {
+            MidArgs m{};
+            rc = attach_mid(h, s, &m);
+            if (rc) return rc;
+            if (m.X16) {
+                HIP_TRY(h, launch_mid_score(fa, m, s));
+                HIP_TRY(h, launch_bigk_thr_prune(fa, m, 0, -1, s));
+            }
+        }
         // exact fp64 distance of every candidate (blocks over query x candidate chunk), then sort + emit per query
         HIP_TRY(h, launch_range_rescore(fa, radius, (int32_t)q0, cap_eff, h->io_lab.as<int64_t>(),
                                         h->io_dist.as<float>(), h->io_cnt.as<int64_t>(), s));
@@ -1605,6 +1779,7 @@ int mlvdb_pair_distances(mlvdb_index* h, const float* queries, int64_t nq, const
     for (int64_t i = 0; i < nq * m; ++i)
         if (labels[i] >= h->total) return fail(h, MLVDB_ERR_INVALID_ARG, "label out of range");
     hipStream_t s = h->aux_stream;  // rows are immutable once appended: may overlap a search in flight on h->stream
+    std::lock_guard<std::mutex> aux_lock(h->aux_mutex);
     // private buffers of the auxiliary stream (gather_out / gather_lab) + query staging of its own
     const size_t qbytes = (size_t)nq * h->dim * sizeof(float), pbytes = (size_t)nq * h->ld * sizeof(float);
     const size_t abytes = (size_t)nq * sizeof(double), o64 = (size_t)nq * m * sizeof(double), o32 = (size_t)nq * m * sizeof(float);

@@ -282,5 +282,36 @@ hipError_t launch_filter_range_thr(const FilterArgs& a, float radius, hipStream_
 hipError_t launch_exact_range_scan(const FilterArgs& a, float radius, const int32_t* qsel, int32_t nsel, hipStream_t s);
 hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, int64_t capacity, int64_t* out_labels,
                                 float* out_dist, int64_t* out_counts, hipStream_t s);
+// The dense pass alone: every (query, row) bound of rows [0, rows) -> slot `row` of the query's list (rows a multiple of 128,
+// <= a.cand_cap).  launch_filter_seed_scan = this + the first refine / update; big-k passes seed up to 65,280 rows with it.
+hipError_t launch_filter_dense_scan(const FilterArgs& a, int64_t rows, hipStream_t s);
+// kNN ending on the range kernels (big-k passes): exact fp64 distance of every list entry (range_score_flat_kernel with an
+// infinite radius), then the ranking kernel in kNN mode: the k nearest by (distance, label), int32 counts, padded tails,
+// optional fp64 distances; more than kCandCap live entries flag the query (overflow = 2) for the paged exact scan.
+hipError_t launch_knn_rescore_rank(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
+                                   int32_t* out_counts, double* out_d64, unsigned long long* rescored, hipStream_t s);
+
+// ---------------------------------------------------------------- mid bounds + big-k candidate lists (kernels_refine.hip)
+constexpr uint32_t kRefinedBit = 0x80000000u;  // CandEntry::row bit 31: u is the entry's mid (fp16) upper bound, not the scan's
+constexpr int kBigKMax = 1024;                 // largest top_k of a filter pass (beyond: paged exact scan)
+constexpr int kBigSeedRows = 65280;            // dense seeding pass of a big-k pass: 85 x 768 rows (<= kRangeCandCap)
+constexpr int kPicksCap = 2048;                // pick-list slots per query (>= kBigKMax + kBigKMax / 4 + 32)
+
+struct MidArgs {
+    const _Float16* X16;     // row-major fp16 shadow [rows][ld16]: x ~ s16[row] * h
+    const float* s16;        // [rows] scale of the row
+    const float* row_err16;  // device scalar: max over rows of |x - s16 h| / |x| (rounded up)
+    int32_t ld16;            // round_up(dim, 64): 128 bytes per row and step
+    const uint32_t* picks;   // [256][picks_cap] list indices to refine, or nullptr: every entry without a mid bound
+    const uint32_t* npicks;  // [256]
+    int32_t picks_cap;
+};
+hipError_t launch_shadow16_rows(const float* X, void* X16, float* s16, float* row_err16, int64_t row_begin, int64_t row_end,
+                                int32_t ld, int32_t ld16, hipStream_t s);
+hipError_t launch_mid_score(const FilterArgs& a, const MidArgs& m, hipStream_t s);
+hipError_t launch_bigk_select(const FilterArgs& a, int32_t want, int32_t forced_cnt, uint32_t* picks, uint32_t* npicks,
+                              int32_t picks_cap, hipStream_t s);
+// k > 0: threshold from the k-th largest mid lower bound, then prune; k == 0: prune only (range passes)
+hipError_t launch_bigk_thr_prune(const FilterArgs& a, const MidArgs& m, int32_t k, int32_t forced_cnt, hipStream_t s);
 
 }  // namespace mlvdb

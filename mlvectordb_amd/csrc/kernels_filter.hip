@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "bound_common.h"
 #include "internal.h"
 #include "scan_common.h"
 
@@ -107,16 +108,6 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const FilterArgs a) {
         }
     }
 }
-
-// round a double down to a float that is <= it
-__device__ __forceinline__ float float_below(double v) {
-    float f = (float)v;
-    if ((double)f > v) f = __uint_as_float(f > 0.f ? __float_as_uint(f) - 1 : (f < 0.f ? __float_as_uint(f) + 1 : 0x80000001u));
-    return f;
-}
-
-// round a double up to a float that is >= it
-__device__ __forceinline__ float float_above(double v) { return -float_below(-v); }
 
 // thr[q] from the exact distance of the k-th nearest seed row
 __global__ __launch_bounds__(256) void filter_seed_thr_kernel(const FilterArgs a, const double* seed_d64, int32_t k) {
@@ -214,7 +205,7 @@ __device__ __forceinline__ void scan_epilogue(const FilterArgs& a, const f32x4 (
         for (int n = 0; n < NQT; ++n) {
             const float sq = (SPACE == kSpaceL2 || I8) ? sq_l[16 * n + c16] : 1.0f;
             const float ke = ke_l[16 * n + c16];
-            CandEntry* dst = a.cand + (int64_t)(qbase + 16 * n + c16) * kCandCap + (row0 - base_row);
+            CandEntry* dst = a.cand + (int64_t)(qbase + 16 * n + c16) * a.cand_cap + (row0 - base_row);
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
@@ -866,13 +857,6 @@ __device__ __forceinline__ float entry_eps(int space, float ke, float sq, float 
     return sq * ke * nr + kSlack * nr * nr;
 }
 
-__device__ __forceinline__ uint32_t float_order_key(float f) {  // monotone float -> uint (larger float, larger key)
-    const uint32_t b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float float_from_order_key(uint32_t k) {
-    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
 
 // One block per query.  thr[q] = max(thr[q], k-th largest lower bound l = u - 2 eps); entries with
 // u < thr are dropped.  The k-th largest lower bound is found by a 4-pass radix select on the order
@@ -1273,7 +1257,7 @@ __global__ __launch_bounds__(256) void range_score_kernel(const FilterArgs a, co
     for (uint32_t i0 = begin + wave * 16; i0 < end; i0 += 64) {
         const uint32_t idx = i0 + r;
         const bool have = idx < end;
-        const int32_t row = have ? list[idx].row : 0;
+        const int32_t row = have ? (int32_t)((uint32_t)list[idx].row & ~kRefinedBit) : 0;
         const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 16 + g * 4};
         double acc[1][1], nx[1];
         accumulate_rows<SPACE, 1, 1, 8>(base, qs, ld, g, acc, nx);
@@ -1357,7 +1341,7 @@ __global__ __launch_bounds__(kRescoreWaves * 64) void range_score_flat_kernel(co
         const CandEntry* list = a.cand + (int64_t)q * a.cand_cap;
         const uint32_t idx = (u - pre[q]) * 16 + r;
         const bool have = idx < cnt;
-        const int32_t row = have ? list[idx].row : 0;
+        const int32_t row = have ? (int32_t)((uint32_t)list[idx].row & ~kRefinedBit) : 0;  // (bit 31: the entry carries a mid bound)
         const float* base[1] = {a.X + (int64_t)(row >> 4) * (kPanelRows * ld) + (row & 15) * 16 + g * 4};
         double acc[1][1], nx[1];
         accumulate_rows<SPACE, 1, 1, kRescorePF>(base, qs, ld, g, acc, nx);
@@ -1400,8 +1384,17 @@ constexpr int kRankSegs = kRankThreads / kRankTargets;
 constexpr int kRankGrid = 256;  // one block per CU; the (query, 32-hit chunk) work items are dealt to the blocks in turn.  (A grid of
                                 // nq x 32 blocks, most of which exit at once, took 2.5 ms just to be dispatched: every block asks
                                 // for 98 KB of LDS.)
+// knn_k > 0 (big-k passes, launch_knn_rescore_rank): the same ranking as the end of a kNN pass -- capacity = knn_k, counts are
+// int32 (min(hits, k)), tails are padded (label -1, distance +inf), the fp64 distances go to out_d64 when asked for.
+struct KnnOut {
+    int32_t k;                    // 0: range mode
+    int32_t* counts;
+    double* d64;
+    unsigned long long* rescored;
+};
 __global__ __launch_bounds__(kRankThreads) void range_rank_kernel(const FilterArgs a, const int32_t q0, const int64_t capacity,
-                                                                    int64_t* out_labels, float* out_dist, int64_t* out_counts) {
+                                                                    int64_t* out_labels, float* out_dist, int64_t* out_counts,
+                                                                    const KnnOut ko) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint32_t pre[kFilterQueries + 1];  // work items of the queries before q
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1418,7 +1411,18 @@ __global__ __launch_bounds__(kRankThreads) void range_rank_kernel(const FilterAr
                         a.overflow[q] = 2u;         // the paged exact kNN (api.hip reads the flag after the kernel)
                         a.cnt[q] = n;
                     }
-                    out_counts[q0 + q] = n;
+                    if (ko.k > 0) {
+                        const int32_t nk = n > (uint32_t)kCandCap ? 0 : (int32_t)min(n, (uint32_t)ko.k);
+                        ko.counts[q0 + q] = nk;
+                        for (int32_t i = nk; i < ko.k; ++i) {  // fewer than k live rows: pad (overflowed queries are redone whole)
+                            out_labels[(int64_t)(q0 + q) * capacity + i] = -1;
+                            out_dist[(int64_t)(q0 + q) * capacity + i] = __builtin_inff();
+                            if (ko.d64) ko.d64[(int64_t)(q0 + q) * capacity + i] = __builtin_inf();
+                        }
+                        if (ko.rescored) atomicAdd(ko.rescored, (unsigned long long)min(n, (uint32_t)kCandCap));
+                    } else {
+                        out_counts[q0 + q] = n;
+                    }
                 }
                 if (n > (uint32_t)kCandCap) n = 0;
             }
@@ -1498,6 +1502,7 @@ __global__ __launch_bounds__(kRankThreads) void range_rank_kernel(const FilterAr
         if (have && seg == 0 && (int64_t)rank < capacity) {
             out_labels[(int64_t)(q0 + q) * capacity + rank] = li;
             out_dist[(int64_t)(q0 + q) * capacity + rank] = (float)di;
+            if (ko.d64) ko.d64[(int64_t)(q0 + q) * capacity + rank] = di;
         }
     }
 }
@@ -2665,21 +2670,12 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
 // the tile entries) turns the lists into thresholds and drops what is below them.
 static hipError_t launch_update(const FilterArgs& a, int32_t k, int32_t forced_cnt, hipStream_t s);
 
-hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t k, hipStream_t s) {
-    const int64_t rows = (row_end + kSeedTileRows - 1) / kSeedTileRows * kSeedTileRows;
-    hipError_t e;
+hipError_t launch_filter_dense_scan(const FilterArgs& a, int64_t rows, hipStream_t s) {
     const bool xb = a.Xb != nullptr;
-    if (filter_narrow_ok(a)) {
-        FilterArgs b = a;  // (round 3: the narrow kernel runs on the int8 shadow for every space)
-        e = a.space == kSpaceL2       ? launch_scan_narrow<kSpaceL2, true>(b, 0, rows, s)
-            : a.space == kSpaceCosine ? launch_scan_narrow<kSpaceCosine, true>(b, 0, rows, s)
-                                      : launch_scan_narrow<kSpaceIp, true>(b, 0, rows, s);
-        if (e != hipSuccess) return e;
-        if (a.X8) {
-            const bool fuse = filter_refine_can_fuse(a);
-            if ((e = launch_filter_refine_thr(a, k, (int32_t)rows, fuse, s)) != hipSuccess || fuse) return e;
-        }
-        return launch_update(a, k, (int32_t)rows, s);
+    if (filter_narrow_ok(a)) {  // (round 3: the narrow kernel runs on the int8 shadow for every space)
+        return a.space == kSpaceL2       ? launch_scan_narrow<kSpaceL2, true>(a, 0, rows, s)
+               : a.space == kSpaceCosine ? launch_scan_narrow<kSpaceCosine, true>(a, 0, rows, s)
+                                         : launch_scan_narrow<kSpaceIp, true>(a, 0, rows, s);
     }
     if (a.X8 && a.tn->seed_i8) {
         // Round 3: the dense pass of a 256-query batch on the int8 shadow too -- the narrow kernel (64 queries' image in LDS)
@@ -2687,38 +2683,34 @@ hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t
         // kernel below, half the MFMAs, and no pass of the default path reads the bf16 shadow any more (so an index need
         // not keep one: 1.25x instead of 1.75x the corpus in HBM).  Every bound goes into the lists either way; the refine
         // that follows takes the threshold from exact scores.
-        // queries per group: as many as the image leaves room for in LDS (64 up to ld = 2304, 32 up to 4736, else 16)
+        // queries per group: as many as the image leaves room for in LDS (64 up to ld8 = 2304, 32 up to 4736, else 16)
         const int nqt = narrow_lds(a.ld8, 4, 4, true) <= kNarrowLdsMax ? 4 : (narrow_lds(a.ld8, 2, 4, true) <= kNarrowLdsMax ? 2 : 1);
         const int groups = (a.nq + 16 * nqt - 1) / (16 * nqt);
 #define MLVDB_SEED_I8(SP)                                                                                              \
     (nqt == 4 ? launch_scan_narrow_n<SP, 4, true, 4, 4, true>(a, 0, rows, s, groups)                                  \
               : nqt == 2 ? launch_scan_narrow_n<SP, 2, true, 4, 4, true>(a, 0, rows, s, groups)                       \
                          : launch_scan_narrow_n<SP, 1, true, 4, 4, true>(a, 0, rows, s, groups))
-        e = a.space == kSpaceL2 ? MLVDB_SEED_I8(kSpaceL2) : a.space == kSpaceCosine ? MLVDB_SEED_I8(kSpaceCosine) : MLVDB_SEED_I8(kSpaceIp);
+        return a.space == kSpaceL2 ? MLVDB_SEED_I8(kSpaceL2) : a.space == kSpaceCosine ? MLVDB_SEED_I8(kSpaceCosine) : MLVDB_SEED_I8(kSpaceIp);
 #undef MLVDB_SEED_I8
-        if (e != hipSuccess) return e;
-        const bool fuse = filter_refine_can_fuse(a);
-        if ((e = launch_filter_refine_thr(a, k, (int32_t)rows, fuse, s)) != hipSuccess || fuse) return e;
-        return launch_update(a, k, (int32_t)rows, s);
     }
     FilterArgs b = a;
     if (a.X8) b.ke = a.keb;  // bf16 bounds get the bf16 error term; `a.ke` (update, below) covers int8 entries too
     switch (a.space) {
         case kSpaceL2:
-            e = xb ? launch_scan_one<kSpaceL2, true, true>(b, 0, rows, s)
-                   : launch_scan_one<kSpaceL2, false, true>(b, 0, rows, s);
-            break;
+            return xb ? launch_scan_one<kSpaceL2, true, true>(b, 0, rows, s) : launch_scan_one<kSpaceL2, false, true>(b, 0, rows, s);
         case kSpaceCosine:
-            e = xb ? launch_scan_one<kSpaceCosine, true, true>(b, 0, rows, s)
-                   : launch_scan_one<kSpaceCosine, false, true>(b, 0, rows, s);
-            break;
+            return xb ? launch_scan_one<kSpaceCosine, true, true>(b, 0, rows, s)
+                      : launch_scan_one<kSpaceCosine, false, true>(b, 0, rows, s);
         default:
-            e = xb ? launch_scan_one<kSpaceIp, true, true>(b, 0, rows, s)
-                   : launch_scan_one<kSpaceIp, false, true>(b, 0, rows, s);
-            break;
+            return xb ? launch_scan_one<kSpaceIp, true, true>(b, 0, rows, s) : launch_scan_one<kSpaceIp, false, true>(b, 0, rows, s);
     }
+}
+
+hipError_t launch_filter_seed_scan(const FilterArgs& a, int64_t row_end, int32_t k, hipStream_t s) {
+    const int64_t rows = (row_end + kSeedTileRows - 1) / kSeedTileRows * kSeedTileRows;
+    hipError_t e = launch_filter_dense_scan(a, rows, s);
     if (e != hipSuccess) return e;
-    if (a.X8) {
+    if (a.X8) {  // int8 bounds are loose: the threshold comes from exact scores of the best bounds (the same kernel prunes)
         const bool fuse = filter_refine_can_fuse(a);
         if ((e = launch_filter_refine_thr(a, k, (int32_t)rows, fuse, s)) != hipSuccess || fuse) return e;
     }
@@ -2807,7 +2799,39 @@ hipError_t launch_range_rescore(const FilterArgs& a, float radius, int32_t q0, i
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(range_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_sort);
     if (e != hipSuccess) return e;
-    range_rank_kernel<<<kRankGrid, kRankThreads, lds_sort, s>>>(a, q0, capacity, out_labels, out_dist, out_counts);
+    range_rank_kernel<<<kRankGrid, kRankThreads, lds_sort, s>>>(a, q0, capacity, out_labels, out_dist, out_counts, KnnOut{});
+    return hipGetLastError();
+}
+
+hipError_t launch_knn_rescore_rank(const FilterArgs& a, int32_t k, int32_t q0, int64_t* out_labels, float* out_dist,
+                                   int32_t* out_counts, double* out_d64, unsigned long long* rescored, hipStream_t s) {
+    const size_t lds_sort = (size_t)kCandCap * (sizeof(double) + sizeof(int32_t));
+    hipError_t e = hipMemsetAsync(a.rhit_cnt, 0, kFilterQueries * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    int waves = kRescoreWaves;
+    while (waves > 1 && (size_t)waves * a.ld * sizeof(double) > 144 * 1024) waves >>= 1;
+    const size_t lds_score = std::max((size_t)waves * a.ld * sizeof(double), (size_t)96 * 1024);
+    const float inf = __builtin_inff();  // every live entry is a "hit"
+#define MLVDB_LAUNCH_KNN_SCORE(SP)                                                                                    \
+    do {                                                                                                              \
+        auto kern = range_score_flat_kernel<SP>;                                                                      \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                                (int)lds_score);                                                                      \
+        if (e == hipSuccess) kern<<<kRescoreGrid, waves * 64, lds_score, s>>>(a, inf);                                \
+    } while (0)
+    switch (a.space) {
+        case kSpaceL2: MLVDB_LAUNCH_KNN_SCORE(kSpaceL2); break;
+        case kSpaceCosine: MLVDB_LAUNCH_KNN_SCORE(kSpaceCosine); break;
+        default: MLVDB_LAUNCH_KNN_SCORE(kSpaceIp); break;
+    }
+#undef MLVDB_LAUNCH_KNN_SCORE
+    if (e != hipSuccess) return e;
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(range_rank_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_sort);
+    if (e != hipSuccess) return e;
+    range_rank_kernel<<<kRankGrid, kRankThreads, lds_sort, s>>>(a, q0, (int64_t)k, out_labels, out_dist, nullptr,
+                                                                KnnOut{k, out_counts, out_d64, rescored});
     return hipGetLastError();
 }
 

@@ -506,7 +506,11 @@ class Index:
         if ns is None or q.shape[1] != ns.dim:
             raise RuntimeError(f"namespace {namespace!r} is unknown or its dimensionality differs from the queries'")
         if isinstance(ids, np.ndarray) and ids.dtype.kind in "iu":
-            labels = np.asarray(ids, dtype=np.int64).reshape(q.shape[0], -1)
+            labels = np.asarray(ids, dtype=np.int64).reshape(q.shape[0], -1).copy()
+            inside = (labels >= 0) & (labels < ns.ids.n)
+            dead = np.zeros(labels.shape, dtype=bool)
+            dead[inside] = ~ns.ids.live[labels[inside]]
+            labels[dead | ~inside] = -1  # removed or unknown labels read as NaN, like removed ids (the engine itself would score them)
         else:
             rows = [list(r) for r in ids]
             m = len(rows[0]) if rows else 0

@@ -94,9 +94,18 @@ class _MetaColumn:
         self.starts: List[int] = [0]
         self.any = False
 
+    _COALESCE = 4096  # rows: consecutive small chunks are merged up to this size (QueryProcessor.insert writes one row at a time)
+
     def append(self, metadata, n: int) -> None:
-        self.chunks.append(None if metadata is None else list(metadata))
-        self.starts.append(self.starts[-1] + n)
+        last = self.chunks[-1] if self.chunks else None
+        last_n = self.starts[-1] - self.starts[-2] if self.chunks else 0
+        if self.chunks and last_n + n <= self._COALESCE and (metadata is None) == (last is None):
+            if metadata is not None:
+                last.extend(metadata)
+            self.starts[-1] += n
+        else:
+            self.chunks.append(None if metadata is None else list(metadata))
+            self.starts.append(self.starts[-1] + n)
         self.any = self.any or metadata is not None
 
     def __getitem__(self, r: int):
@@ -213,8 +222,10 @@ class ArrayStorage:
             return [None] * len(vector_ids)
         rows = ns.ids.lookup(vector_ids)
         vals = self._values_of(ns, rows)
-        return [StoredRow(u, None if vals is None else vals[i], ns.metadata[r]) if r >= 0 else None
-                for i, (u, r) in enumerate(zip(vector_ids, rows.tolist()))]
+        rl = rows.tolist()
+        meta = ns.metadata.take(rl)  # one vectorised chunk lookup (a per-row searchsorted made this quadratic after single inserts)
+        return [StoredRow(u, None if vals is None else vals[i], meta[i]) if r >= 0 else None
+                for i, (u, r) in enumerate(zip(vector_ids, rl))]
 
     def delete(self, vector_id: UUID, namespace: str) -> bool:
         ns = self._ns.get(namespace)
@@ -238,8 +249,8 @@ class ArrayStorage:
             rows = np.flatnonzero(ns.ids.live[:ns.ids.n])
             vals = self._values_of(ns, rows)
             ids = ns.ids.uuids_at(rows).tolist()
-            out[name] = [StoredRow(u, None if vals is None else vals[i], ns.metadata[r])
-                         for i, (u, r) in enumerate(zip(ids, rows.tolist()))]
+            meta = ns.metadata.take(rows.tolist())
+            out[name] = [StoredRow(u, None if vals is None else vals[i], meta[i]) for i, u in enumerate(ids)]
         return out
 
     @property

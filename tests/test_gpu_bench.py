@@ -29,7 +29,7 @@ def test_bare_gpus_2_starts_two_ranks_and_passes_the_sharded_gate():
     assert d["n_gpus"] == 2 and d["rank_devices"] == [0, 0] and d["scaling"] == "weak"
     gate = d["parity_gate"]
     assert gate["sharded_merge_equals_exact_ids"] is True and gate["filter_equals_exact_scan_ids"] is True
-    assert gate["queries_compared"] == 1024 and d["config"]["batch"] == 1024
+    assert gate["queries_compared"] == 1024 * gate["query_batches"] and gate["query_batches"] == 8 and d["config"]["batch"] == 1024
     assert d["value"] > 0 and abs(d["value"] - 2 * 1024 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
 
 
@@ -46,6 +46,14 @@ def test_one_gpu_line_has_the_contract_keys_on_a_small_shard():
     other = d["other_wave_mode"]
     assert d["wave_mode"] == "synchronised" and other["wave_mode"] == "back_to_back" and other["ms_per_step"] > 0
     assert abs(d["value"] - 256 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    # round 4: stable keys for both definitions, the sustained rate (>= 1000 waves per mode, rotating query batches), and
+    # SURVEY 8(d)'s fraction under its own name beside the shadow-bytes one
+    assert d["value_synchronised"] == d["value"] and d["value_back_to_back"] == other["value"]
+    sus = d["sustained"]
+    assert sus["waves_per_mode"] >= 1000 and sus["query_batches"] == d["parity_gate"]["query_batches"] == 8
+    assert sus["synchronised"]["ms_per_step"] > 0 and sus["back_to_back"]["scan_avg_launch_ms"] > 0
+    r = d["roofline"]
+    assert r["frac_basis"].endswith("shadow bytes") and r["alg_frac"] == r["alg_hbm_frac"] and r["alg_frac"] > r["frac"]
 
 
 def test_back_to_back_wave_mode_swaps_the_two_timed_regions():

@@ -137,6 +137,73 @@ def test_topk_above_64_is_served_in_rank_ordered_pages(n, d, nq, k, space):
 
 
 @pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+@pytest.mark.parametrize("k", [65, 100, 333, 1000])
+def test_topk_65_to_1000_stays_on_the_filter_path(space, k):
+    """the reference clamps top_k only to the live count (index.py:107) and its REST model admits 1..1000
+    (rest_api.py:24).  top_k in (64, 1024] runs as big-k passes: dense seed of 65,280 rows, scan rounds on the int8 body,
+    mid (fp16) bounds, exact rescoring of the survivors -- ids of the oracle, tombstones and duplicates included."""
+    d, n = 256, 150_001
+    rows, qs = make_case(1300 + k, n, d, 40, dup=True)
+    deleted = deleted_mask(23, n, 0.05)
+    eng = HipScanEngine(d, space, device=0, strategy="filter")
+    try:
+        for part in np.array_split(rows, 3):
+            eng.append(part)
+        eng.tombstone(np.nonzero(deleted)[0])
+        got = eng.search(qs, k)
+        st = eng.last_stats()
+        assert st["strategy_used"] == 2 and st["bound_dtype"] == 2 and st["fallback_queries"] == 0 and st["scan_launches"] >= 1, st
+        assert st["candidates_rescored"] < 3 * k * qs.shape[0], st   # the mid bounds leave ~k rows per query for the exact gather
+        assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"bigk/{space}/k{k}")
+        few = eng.search(qs[:3], k)     # 1-8 queries: the narrow kernel does the rounds
+        assert eng.last_stats()["strategy_used"] == 2
+        assert_knn_matches(few, oracle_knn(qs[:3], rows, k, space, deleted), f"bigk-narrow/{space}/k{k}")
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("space,d,n,k", [("cosine", 100, 80_001, 100), ("l2", 128, 80_001, 100), ("ip", 768, 70_003, 200),
+                                         ("l2", 768, 40_001, 100), ("cosine", 1000, 33_001, 65)])
+def test_bigk_on_other_shapes_masks_and_fallbacks(space, d, n, k, monkeypatch):
+    """Big-k passes on a padded int8 shadow (d = 100, 1000), on the bf16 shadow (d = 128), on a corpus smaller than the dense
+    seed (no scan round at all), under a row mask, with more than 256 queries; L2_SHADOW=0 (no mid shadow) takes the paged
+    exact scan; k above the live count pads."""
+    rows, qs = make_case(1500 + d, n, d, 300 if d == 128 else 20, dup=True)
+    deleted = deleted_mask(29, n, 0.05)
+    eng = HipScanEngine(d, space, device=0, strategy="filter")
+    try:
+        eng.append(rows)
+        eng.tombstone(np.nonzero(deleted)[0])
+        got = eng.search(qs, k)
+        st = eng.last_stats()
+        assert st["strategy_used"] == 2 and st["fallback_queries"] == 0, st
+        assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"bigk-shapes/{space}/d{d}")
+        mask = (np.arange(n) % 3 != 0).astype(np.uint8)
+        gm = eng.search(qs[:10], k, mask)
+        assert_knn_matches(gm, oracle_knn(qs[:10], rows, k, space, deleted | (mask == 0)), f"bigk-mask/{space}/d{d}")
+        eng.set_tuning(L2_SHADOW=0)
+        paged = eng.search(qs[:10], k)
+        assert eng.last_stats()["strategy_used"] == 1
+        assert_knn_matches(paged, oracle_knn(qs[:10], rows, k, space, deleted), f"bigk-paged/{space}/d{d}")
+    finally:
+        eng.close()
+
+
+def test_bigk_with_thousands_of_equal_rows_falls_back_exactly():
+    """12,000 copies of one row next to the query: every copy ties into the top k, more than the 8,192 hits one block ranks --
+    the query is flagged and served by the paged exact scan; the answer is still the oracle's (lowest labels first)."""
+    n, d, k = 120_000, 256, 100
+    rows, qs = make_case(4343, n, d, 4)
+    near = qs[0] + 0.01 * np.random.default_rng(5).standard_normal(d).astype(np.float32)
+    where = np.random.default_rng(6).choice(np.arange(5_000, n), size=12_000, replace=False)
+    rows[where] = near
+    got, stats = run_hip(rows, qs, k, "cosine", "filter", None, append_chunks=2)
+    assert stats["strategy_used"] == 2 and stats["fallback_queries"] >= 1, stats
+    assert_knn_matches(got, oracle_knn(qs, rows, k, "cosine"), "bigk equal rows")
+    assert np.array_equal(got[0][0], np.sort(where)[:k])
+
+
+@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
 def test_filter_without_bf16_shadow_matches_oracle(space, monkeypatch):
     """MLVDB_NO_SHADOW=1: the scan converts the fp32 panels in registers instead of reading the shadow."""
     monkeypatch.setenv("MLVDB_NO_SHADOW", "1")
