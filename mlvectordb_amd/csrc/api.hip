@@ -834,7 +834,11 @@ int run_bigk_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, float
     HIP_TRY(h, launch_filter_dense_scan(fa, n_seed, s));
     rc = refine((int32_t)n_seed);
     if (rc) return rc;
-    const double growth = std::min(24.0, std::max(1.5, 1.0 + (double)std::max(1, h->tn.bigk_budget) / ((double)std::max(nq, 16) * k)));
+    // growth of the rows seen per round: bounded by the waves' append buffers (BIGK_BUDGET entries per launch and 256 queries:
+    // 256 workgroups x 8 waves x ~1,000 slots, less the band factor ~8) and by the query's own list (half of its 65,536 slots
+    // for one round's band: m (k / n) 8 <= 32,768)
+    const double growth = std::min(std::min(24.0, 1.0 + 4096.0 / k),
+                                   std::max(1.5, 1.0 + (double)std::max(1, h->tn.bigk_budget) / ((double)std::max(nq, 16) * k)));
     int64_t b = std::min<int64_t>(n_seed, h->total);
     while (b < h->total) {
         int64_t e = (int64_t)((double)b * growth) / kFilterTile * kFilterTile;

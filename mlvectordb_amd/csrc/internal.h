@@ -56,7 +56,7 @@ inline hipError_t ensure_dynamic_lds(std::atomic<uint64_t>& done, const void* ke
     X(range_flat, "RANGE_FLAT", 1)                                                                                      \
     X(range_l2, "RANGE_L2", 1)         /* range passes: fp16 second-level bound before the exact gather */             \
     X(bigk, "BIGK", 1)                 /* top_k in (64, 1024] on the filter path (0: paged exact scan) */              \
-    X(bigk_budget, "BIGK_BUDGET", 1200000) /* entries one scan launch of a big-k pass may append (sizes its rounds) */ \
+    X(bigk_budget, "BIGK_BUDGET", 400000) /* entries one scan launch of a big-k pass may append (sizes its rounds) */ \
     X(l2_shadow, "L2_SHADOW", 1)       /* fp16 row-major shadow for second-level bounds (built lazily; 0: never) */    \
     X(debug_entries, "DEBUG_ENTRIES", 0)                                                                                \
     X(debug_refine, "DEBUG_REFINE", 0)                                                                                  \

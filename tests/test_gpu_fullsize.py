@@ -152,6 +152,13 @@ def test_config3_10m_cosine_all_256_queries_equal_the_exact_scan(engine_10m_cosi
     assert st4["strategy_used"] == 2 and st4["scan_launches"] == 12 and st4["fallback_queries"] == 0, st4
     _assert_identical(got4, want4, "10M/cosine/batch1024")
     assert np.array_equal(got4[0][:qs.shape[0]], lf)  # a query's answer does not depend on the pass it rides in
+    # top_k = 100 and 1000 at the full size: big-k passes on the filter path against the paged exact scan
+    for kk, nqq in ((100, B), (1000, 32)):
+        gotk, wantk, stk = _both_strategies(eng, qs[:nqq], kk)
+        assert stk["strategy_used"] == 2 and stk["bound_dtype"] == 2 and stk["fallback_queries"] == 0, stk
+        assert stk["candidates_rescored"] < 2 * kk * nqq, stk
+        _assert_identical(gotk, wantk, f"10M/cosine/k{kk}")
+        assert np.array_equal(gotk[0][:, :K], lf[:nqq])  # the first 10 of the 100 are the k = 10 answer
     # SURVEY 8d's secondary run: 10 % random tombstones
     dead = np.nonzero(np.random.default_rng(99).random(N10) < 0.1)[0].astype(np.int64)
     assert eng.tombstone(dead) == dead.size

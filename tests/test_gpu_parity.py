@@ -167,7 +167,7 @@ def test_topk_65_to_1000_stays_on_the_filter_path(space, k):
 def test_bigk_on_other_shapes_masks_and_fallbacks(space, d, n, k, monkeypatch):
     """Big-k passes on a padded int8 shadow (d = 100, 1000), on the bf16 shadow (d = 128), on a corpus smaller than the dense
     seed (no scan round at all), under a row mask, with more than 256 queries; L2_SHADOW=0 (no mid shadow) takes the paged
-    exact scan; k above the live count pads."""
+    exact scan."""
     rows, qs = make_case(1500 + d, n, d, 300 if d == 128 else 20, dup=True)
     deleted = deleted_mask(29, n, 0.05)
     eng = HipScanEngine(d, space, device=0, strategy="filter")
@@ -200,7 +200,7 @@ def test_bigk_with_thousands_of_equal_rows_falls_back_exactly():
     got, stats = run_hip(rows, qs, k, "cosine", "filter", None, append_chunks=2)
     assert stats["strategy_used"] == 2 and stats["fallback_queries"] >= 1, stats
     assert_knn_matches(got, oracle_knn(qs, rows, k, "cosine"), "bigk equal rows")
-    assert np.array_equal(got[0][0], np.sort(where)[:k])
+    assert got[0][0][0] == 1 and np.array_equal(got[0][0][1:], np.sort(where)[:k - 1])  # (make_case: query 0 is row 1 itself)
 
 
 @pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
