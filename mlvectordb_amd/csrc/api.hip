@@ -830,7 +830,10 @@ int run_bigk_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, float
         return MLVDB_OK;
     };
     // seed: dense over the first rows (a multiple of 128; a whole number of 768-row units when rounds follow)
-    const int64_t n_seed = h->total > kBigSeedRows ? (int64_t)kBigSeedRows : (h->total + 127) / 128 * 128;
+    // How many: the first scan round appends ~32 rows x nq x (k / n_seed) x 8 entries per wave and tile, which must stay
+    // well inside a wave's buffer: n_seed >= ~66 k nq / 256 (k = 100: 6,912 rows, k = 1000: the 65,280 a list takes)
+    const int64_t want_seed = std::min<int64_t>(kBigSeedRows, std::max<int64_t>(kSeedRows, ((int64_t)66 * k * std::max(nq, 16) / 256 + kFilterTile - 1) / kFilterTile * kFilterTile));
+    const int64_t n_seed = h->total > want_seed ? want_seed : (h->total + 127) / 128 * 128;
     HIP_TRY(h, launch_filter_dense_scan(fa, n_seed, s));
     rc = refine((int32_t)n_seed);
     if (rc) return rc;

@@ -156,7 +156,14 @@ __global__ __launch_bounds__(kMidWaves * 64) void mid_score_flat_kernel(const Fi
     const int nsteps = ld16 >> 6;  // 64 columns (128 bytes) per row and step
     int cur = -1;
     double qaux = 0.0, qn = 0.0;
-    for (uint32_t u = blockIdx.x + gridDim.x * wave; u < total; u += gridDim.x * nwaves) {
+    // every wave takes a CONTIGUOUS run of groups (waves numbered block-first, so a short list still spreads over the CUs):
+    // consecutive groups mostly belong to one query, whose fp64 copy in LDS is then loaded once per run -- dealt out one by
+    // one (the rescoring kernel's order) nearly every group of a long list meant a new query: 6 KB from L2 and a dependent
+    // round trip before the gather could start (145 us per range wave for 256k rows; profiles/r04)
+    const uint32_t nw_all = gridDim.x * nwaves, gw = (uint32_t)wave * gridDim.x + blockIdx.x;
+    const uint32_t per = (total + nw_all - 1) / nw_all;
+    const uint32_t u_end = min(total, (gw + 1) * per);
+    for (uint32_t u = gw * per; u < u_end; ++u) {
         int lo = 0, hi = kFilterQueries;  // the query with pre[q] <= u < pre[q + 1]
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
