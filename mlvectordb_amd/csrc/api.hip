@@ -545,8 +545,7 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
         // of latency chains at batch 1); the prefix rows then belong to the first scan round.  MLVDB_SMALL_SEED=0: the dense pass.
         // (4-8 queries: no gain from either step; profiles/r03/small_batch_fused_finish_and_prefix_seed_1m.txt)
         const int small_nq = std::max(0, std::min(8, h->tn.small_nq));
-        if (fa.X8 && nq <= small_nq && k <= 64 && !h->mask_active && filter_narrow_ok(fa) && !seed_exact &&
-            h->tn.small_seed != 0) {
+        if (fa.X8 && nq <= small_nq && k <= 64 && !h->mask_active && !seed_exact && h->tn.small_seed != 0) {
             HIP_TRY(h, h->seed_d64.ensure(((size_t)kFilterQueries * 64 + (size_t)8 * kSeedRows) * sizeof(double)));
             double* d64 = h->seed_d64.as<double>();
             HIP_TRY(h, launch_prefix_exact(h->X, fa.rn, fa.Qpad, fa.qaux, nq, (int32_t)n_seed, h->ld, h->space, d64, h->tn, s));

@@ -61,7 +61,7 @@ inline hipError_t ensure_dynamic_lds(std::atomic<uint64_t>& done, const void* ke
     X(debug_entries, "DEBUG_ENTRIES", 0)                                                                                \
     X(debug_refine, "DEBUG_REFINE", 0)                                                                                  \
     X(scan_narrow, "SCAN_NARROW", 1)                                                                                    \
-    X(narrow_i8_max, "NARROW_I8_MAX", 8)                                                                                \
+    X(narrow_i8_max, "NARROW_I8_MAX", 0) /* largest batch the int8 NARROW kernel scans (round 4: none -- the 4-tile assembly body is faster at every batch size) */                                                                                \
     X(narrow_wgs, "NARROW_WGS", 0)     /* 0 = as many workgroups per CU as the image leaves LDS for */                  \
     X(narrow_balance, "NARROW_BALANCE", 1)                                                                              \
     X(scan_xcd, "SCAN_XCD", 0)                                                                                          \

@@ -612,7 +612,9 @@ static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagre
 // the bf16 body; 208..219 = int8 bodies (208 AccVGPR accumulators; 211 ArchVGPR accumulators, cosine: admission folded into the
 // last k-step; 214 / 215 / 216 tuning variants of 211: ring of 6, read-ahead 8, no wave priorities; 209 / 210 / 212 / 213
 // timing diagnostics).
-constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 240; }
+constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 249; }
+// 241 / 242 (round 4): the default int8 body computing only the first 8 / 4 query tiles (passes of <= 128 / <= 64 queries)
+constexpr int scan_code_nqt(int qd) { return qd == 241 ? 8 : (qd == 242 ? 4 : 16); }
 constexpr int scan_code_qd(int qd) { return qd == 215 ? 8 : (qd > 8 ? 4 : qd); }
 constexpr bool scan_code_q4(int qd) { return qd == 219 || qd == 229 || qd == 231 || qd == 233; }  // four Q chunk buffers
 constexpr int scan_code_qbufs(int qd) { return scan_code_q4(qd) ? 4 : 2; }
@@ -753,7 +755,11 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     const uint32_t stg = (uint32_t)(kQBufs * chunk_bytes) + 3 * kFilterQueries * sizeof(float) + (uint32_t)wave * (12 * kStageCap);
     const uint32_t* ovfb = a.overflow;
     const uint32_t lane16 = lane * 16;
-    const uint32_t qvoff = (uint32_t)wave * 2048u + lane16;  // this thread's uint4 of fragment piece 2*wave + h
+    // LDS-DMA staging: which fragment of a Q chunk this wave moves (tools/gen_scan_asm.py, dma_pieces): query tile `wave` (+ 8), both
+    // k-step halves -- or, when only 4 query tiles are computed, the single fragment (tile wave & 3, half wave >> 2)
+    constexpr int kNQT = scan_code_nqt(QD);
+    const uint32_t wave_piece = kNQT == 4 ? (uint32_t)(wave & 3) * 2048u + (uint32_t)(wave >> 2) * 1024u : (uint32_t)wave * 2048u;
+    const uint32_t qvoff = wave_piece + lane16;  // this thread's uint4 of the wave's fragment
     const uint32_t rnvoff = g * (I8 ? 32 : 16);
     const uint32_t thra = (uint32_t)(kQBufs * chunk_bytes) + c16 * 4;
     const uint32_t c16v = c16;
@@ -765,7 +771,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     (void)vs;
     (void)vt;
     uint32_t ve[13], ldr, ldw, s_sldw;
-    const uint32_t wave2k = (uint32_t)wave * 2048u;  // LDS-DMA staging: this wave's piece offset inside a Q buffer
+    const uint32_t wave2k = __builtin_amdgcn_readfirstlane(wave_piece);  // LDS-DMA staging: this wave's fragment offset inside a Q buffer
     (void)ldw;
     (void)s_sldw;
     (void)wave2k;
@@ -2471,9 +2477,10 @@ static size_t narrow_lds(int32_t ld, int nqt, int nw, bool i8 = false) {
 bool filter_narrow_ok(const FilterArgs& a) {
     if (!(a.Xb || a.X8) || a.nq > kNarrowMaxQueries) return false;  // streams the int8 shadow when the pass has one, else the bf16 one
     if (a.tn->scan_narrow == 0) return false;
-    // int8 bounds admit ~7x more rows than bf16 ones and this kernel appends them one atomic at a time: beyond 8
-    // queries the 256-query body (appends staged per wave) is faster (profiles/r01/small_batch_ab_10m_i8.txt)
-    if (a.X8 && a.nq > a.tn->narrow_i8_max) return false;  // (tuning: the largest batch the int8 narrow kernel takes)
+    // int8 shadow: the assembly body generated for 4 query tiles (round 4) streams it at the copy ceiling and stages its hits
+    // per wave; this compiler-scheduled kernel appends them one atomic at a time and is slower at every batch size (10M x 768:
+    // 1.25-1.47 vs 1.20-1.21 ms for 1-8 queries, profiles/r04/small_batch_nqt4_vs_narrow_*.txt).  NARROW_I8_MAX > 0 brings it back (A/B).
+    if (a.X8 && a.nq > a.tn->narrow_i8_max) return false;
     return narrow_lds(a.X8 ? a.ld8 : a.ld, narrow_nqt(a.nq), 8, a.X8 != nullptr) <= kNarrowLdsMax;
 }
 template <int SPACE, int NQT, bool DENSE, int R, int NW, bool I8 = false>
@@ -2619,6 +2626,10 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
             if constexpr (SPACE == kSpaceCosine) {  // round 2's default body stays in the default library as the A/B reference
                 if (tn.scan_var == 237) return launch_scan_asm<SPACE, 4, 8, true, 237, true, 2, true>(a, row_begin, row_end, s, info);
             }
+            // passes of <= 64 / <= 128 queries: the same body computing 4 / 8 of the 16 query tiles (round 4; SCAN_NQT=16 pads)
+            const int nqt = tn.scan_nqt > 0 ? tn.scan_nqt : (a.nq <= 64 ? 4 : (a.nq <= 128 ? 8 : 16));
+            if (nqt <= 4 && a.nq <= 64) return launch_scan_asm<SPACE, 4, 8, true, 242, true, 2, true>(a, row_begin, row_end, s, info);
+            if (nqt <= 8 && a.nq <= 128) return launch_scan_asm<SPACE, 4, 8, true, 241, true, 2, true>(a, row_begin, row_end, s, info);
             return launch_scan_asm<SPACE, 4, 8, true, 211, true, 2, true>(a, row_begin, row_end, s, info);
         }
         // everything below streams the bf16 shadow (an int8-only index without usable int8 bounds has none: its

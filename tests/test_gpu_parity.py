@@ -459,6 +459,31 @@ def test_small_batches_through_the_filter_agree_with_oracle(space, d, nq, n, nar
     assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"narrow={narrow}/{space}/d{d}/nq{nq}")
 
 
+@pytest.mark.parametrize("space", ["cosine", "l2", "ip"])
+@pytest.mark.parametrize("nq", [9, 33, 64, 65, 100, 128, 129])
+def test_passes_of_9_to_128_queries_compute_only_their_query_tiles(space, nq):
+    """a pass of <= 64 / <= 128 queries runs the int8 body generated for 4 / 8 of the 16 query tiles (no MFMAs,
+    B reads, Q transfers or admission tests for the empty ones).  Same ids as the oracle and as the padded 16-tile body
+    (SCAN_NQT=16); ragged tiles, tombstones, duplicates, appends in pieces."""
+    d, n = 768, 70_003
+    rows, qs = make_case(2100 + nq, n, d, nq, dup=True)
+    deleted = deleted_mask(31, n, 0.05)
+    eng = HipScanEngine(d, space, device=0, strategy="filter")
+    try:
+        for part in np.array_split(rows, 3):
+            eng.append(part)
+        eng.tombstone(np.nonzero(deleted)[0])
+        got = eng.search(qs, 10)
+        st = eng.last_stats()
+        assert st["strategy_used"] == 2 and st["bound_dtype"] == 2 and st["fallback_queries"] == 0, st
+        assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"nqt/{space}/nq{nq}")
+        eng.set_tuning(SCAN_NQT=16)
+        padded = eng.search(qs, 10)
+        assert np.array_equal(padded[0], got[0]) and np.array_equal(padded[1], got[1])
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("space,d,nq", [("cosine", 4096, 40), ("l2", 2560, 70), ("ip", 8192, 20), ("cosine", 8192, 3),
                                         # 1-2 queries: the prefix seed with a 64 KB query in LDS; the fused finish at and beyond its ld = 2048 limit
                                         ("l2", 8192, 1), ("cosine", 4096, 2), ("ip", 2048, 1), ("cosine", 2304, 2)])

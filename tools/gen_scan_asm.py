@@ -61,6 +61,9 @@ QA = False     # generate(): four Q buffers, chunk c+2 staged during chunk c, on
 #                last QD fragments of chunk c, before the barrier (see generate)
 EO = False     # generate(): hit stubs leave at once when none of the 8 exact bounds passes (see gen_hit_stubs)
 FS = False     # generate(): append routine with a straight-line common case (see gen_slow_fast)
+NQT = 16       # generate(): query tiles (of 16 queries) the body computes: 16 = a full 256-query pass; 8 / 4 (int8 VA bodies, round 4) for
+#                passes of <= 128 / <= 64 queries -- the MFMAs, B-fragment reads, Q staging and admission tests of the empty tiles are
+#                not issued at all, which leaves a pure stream of the shadow (see generate)
 DBG = set()   # timing diagnostics only (wrong results): 'nolds' drops the B-fragment reads, 'nox' the X refills
 
 
@@ -212,7 +215,7 @@ def gen_pretest_l2ip(s, n, part, regs):
         a(f"v_max3_i32 {L2IP_T1}, {regs[3]}, {regs[4]}, {regs[5]}")
         a(f"v_max3_i32 {L2IP_T0}, {L2IP_T0}, {regs[6]}, {regs[7]}")
         a(f"v_max3_i32 {L2IP_T0}, {L2IP_T0}, {L2IP_T1}, 0")
-        if n + 1 < 16:
+        if n + 1 < NQT:
             l2ip_fetch(s, n + 1)
     else:
         a(f"v_cvt_f32_i32 {L2IP_T0}, {L2IP_T0}")
@@ -267,6 +270,22 @@ def gen_rowmax(s, part):
                 a(f"v_max_f32 {dst}, {dst}, %[{src}{NR - 1}]")
 
 
+def dma_pieces(NW):
+    """This wave's LDS-DMA transfers per chunk: (set name, index, k-step half, byte offset inside the chunk / the LDS buffer).
+    A chunk is 2 * NQT fragments of 1 KiB at n * 2048 + h * 1024 (the image keeps the 16-tile layout whatever NQT is).
+    NQT = 16: wave w moves tiles w and w + NW, both halves (4 transfers); NQT = 8: tile w, both halves (2); NQT = 4: ONE
+    fragment -- tile w & 3, half w >> 2: the wrapper puts that into the wave's base offsets (qvoff / wave2k), offset 0 here.
+    Every wave issues the same number of transfers: the counted vmcnt waits assume identical issue sequences."""
+    if NQT == 16:
+        KQ = 1024 // (NW * 64)
+        return [(sn, i, half, i * NW * 2048 + half * 1024) for sn, half in (("qb", 0), ("qa", 1)) for i in range(KQ)]
+    assert NW == 8
+    if NQT == 8:
+        return [("qb", 0, 0, 0), ("qa", 0, 1, 1024)]
+    assert NQT == 4
+    return [("qb", 0, 0, 0)]
+
+
 def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=False, final=False, sync=True, ch=0):
     """One 64-column chunk = 2 k-steps = 32 fragments x MT MFMAs.  final: the tile's last chunk, whose second k-step
     carries the admission pre-tests (FUSE)."""
@@ -285,8 +304,10 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
         else:
             s.emit("v_xor_b32 %[ldw], 0x8000, %[ldw]")
 
+    NF = 2 * NQT   # fragments per chunk: NQT query tiles x 2 k-steps (k-step major)
+
     def read(f):
-        h, n = f >> 4, f & 15
+        h, n = f // NQT, f % NQT
         s.lds(f"ds_read_b128 %[t{f % QD}], %[ldr] offset:{n * 2048 + h * 1024}", ("rd", f))
 
     def refill(h):
@@ -339,10 +360,9 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
         # LDS-DMA staging: chunk c+1 goes global -> LDS directly (buffer_load ... lds: LDS address = M0 +
         # 16*lane), early in chunk c; no staging registers, no ds_write (tools/probe: +5 % on the bare loop).
         f = 2
-        for setname, half in (("qb", 0), ("qa", 1)):
-            for i in range(KQ):
-                plan[f] = ("d", setname, i, half)
-                f += 1
+        for setname, i, half, const in dma_pieces(NW):
+            plan[f] = ("d", setname, i, half, const)
+            f += 1
     else:
         for setname, half, f in (("qb", 0, 16 - 2 * KQ), ("qa", 1, 32 - 2 * KQ)):
             for i in range(KQ):
@@ -357,10 +377,11 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
     if not QA:   # (QA: fragments 0..QD-1 were read at the end of the previous chunk / by the prologue)
         for f0 in range(QD):
             read(f0)
-    for f in range(32):
-        h, n = f >> 4, f & 15
+    prio_steps = {k * NF // 32: v for k, v in PRIO_STEPS.items()}
+    for f in range(NF):
+        h, n = f // NQT, f % NQT
         b = (step0 + h) % R
-        if prio and f in PRIO_STEPS:
+        if prio and f in prio_steps:
             # Experiment (off by default).  The two waves of a SIMD share its MFMA pipe and issue is
             # arbitrated by priority, then age: left alone, the older wave (0..NW/2-1) runs its 64 MFMAs
             # of the chunk first and parks at the barrier for a third of its life (s_memtime stamps:
@@ -368,7 +389,7 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
             # quarter chunk), the younger wave's steps half a quarter later, makes the two leapfrog
             # every 4 fragments and evens the parking out at 7 % -- and the scan gets 3 % SLOWER: the
             # kernel is power-bound (tools/probe), cycles saved come back as a lower clock.
-            who, level = PRIO_STEPS[f]
+            who, level = prio_steps[f]
             s.emit(f"s_cmp_eq_u32 %[wtype], {who}")
             s.emit(f"s_cbranch_scc0 .Lp{s.label}_%=")
             s.emit(f"s_setprio {level}")
@@ -391,20 +412,20 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
                         gen_rowmax(s, n)
                 else:
                     gen_pretest(s, n - 2, m)
-        if f + QD < 32:
+        if f + QD < NF:
             read(f + QD)
         elif QA:
             # the next chunk's first fragments: its buffer was published by the PREVIOUS barrier (staged two chunks
             # ahead), so the read stream never stops at a chunk boundary -- after the barrier the MFMAs go on at once
             # instead of both waves of the SIMD waiting out an LDS round trip with the pipe idle
-            if f + QD == 32:
+            if f + QD == NF:
                 s.emit("v_add_u32 %[ldr], 0x8000, %[ldr]")
                 s.emit("v_and_b32 %[ldr], 0x1ffff, %[ldr]")
-            read(f + QD - 32)
+            read(f + QD - NF)
         if f in plan:
-            kind, setname, i, half = plan[f]
+            kind, setname, i, half = plan[f][:4]
             reg = f"%[{setname}{i}]"
-            const = i * NW * 2048 + half * 1024
+            const = plan[f][4] if len(plan[f]) > 4 else i * NW * 2048 + half * 1024
             if kind == "d":
                 s.emit(f"s_add_u32 m0, %[sldw], 0x{const:x}")
                 s.emit(f"s_add_u32 %[st0], %[qcur], 0x{const:x}")
@@ -415,15 +436,15 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
             else:
                 s.emit(f"s_add_u32 %[st0], %[qcur], 0x{const:x}")
                 s.vmem(f"buffer_load_dwordx4 {reg}, %[qvoff], %[qsrd], %[st0] offen", (setname, i))
-        if n == 15:
+        if n == NQT - 1:
             refill(h)
     if final:   # the last two query tiles: nothing left to hide behind
-        gen_pretest(s, 14, 0)
-        gen_pretest(s, 14, 1)
-        s.emit("s_nop 7")   # XDL write (query tile 15's MFMAs, 8 instructions back) -> VALU read: 16 wait states with this
+        gen_pretest(s, NQT - 2, 0)
+        gen_pretest(s, NQT - 2, 1)
+        s.emit("s_nop 7")   # XDL write (the last query tile's MFMAs, 8 instructions back) -> VALU read: 16 wait states with this
         #                     (an 8-pass MFMA needs 11; once per tile, so the margin is free)
-        gen_pretest(s, 15, 0)
-        gen_pretest(s, 15, 1)
+        gen_pretest(s, NQT - 1, 0)
+        gen_pretest(s, NQT - 1, 1)
     # advance the Q cursor (chunk c+2 -> c+3, wrapping) and publish the chunk just staged
     s.emit("s_add_u32 %[qcur], %[qcur], 0x8000")
     s.emit("s_cmp_eq_u32 %[qcur], %[qbytes]")
@@ -440,7 +461,7 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
         nch = R // 2
         s.need_vm(*[(sn, i, (ch + 1) % nch) for sn in ("qb", "qa") for i in range(KQ)])
     elif dma:   # this wave's share of the chunk(s) staged since the last barrier has landed in LDS
-        s.need_vm(*[(sn, i) for sn in ("qb", "qa") for i in range(KQ)])
+        s.need_vm(*[(sn, i) for sn, i, _, _ in dma_pieces(NW)])
     if not QA:   # (QA: the reads in flight are of the next chunk's buffer, which nobody writes for two more chunks)
         s.drain_lg()
     if "stamp" in DBG:   # cycles parked at the barrier, summed in an SGPR (timing diagnostic)
@@ -524,14 +545,14 @@ def gen_admission(space):
         # rounded down and K = (1 + max eq8)/min sq8 (filter_prep8_fin_kernel); the append path stores the left-hand side,
         # the kernel's tail (the in-kernel scatter) turns it into the bound u = w*sq8 + ke8
         if "noadm" in DBG:   # timing diagnostic: no admission test at all (labels only: the hit stubs refer to them)
-            for n in range(16):
+            for n in range(NQT):
                 a(f".Lback{n}_%=:")
             return s.lines
         for j in range(NR):
             a(f"v_mul_f32 %[p{j}], %[k1], %[p{j}]")
         s.lds(f"ds_read_b32 %[e0], %[thra]", ("thr", 0))
-        for n in range(16):
-            if n + 1 < 16:
+        for n in range(NQT):
+            if n + 1 < NQT:
                 s.lds(f"ds_read_b32 %[e{(n + 1) & 1}], %[thra] offset:{(n + 1) * 64}", ("thr", n + 1))
             for j in range(NR):
                 m, i = j >> 2, j & 3
@@ -575,12 +596,12 @@ def gen_admission(space):
             s.lds(f"ds_read_b32 {sq(n)}, %[thra] offset:{1024 + n * 64}", ("sq", n))
 
     if "noadm" in DBG:   # timing diagnostic: no admission test at all (labels only: the hit stubs refer to them)
-        for n in range(16):
+        for n in range(NQT):
             a(f".Lback{n}_%=:")
         return s.lines
     fetch(0)
-    for n in range(16):
-        if n + 1 < 16:
+    for n in range(NQT):
+        if n + 1 < NQT:
             fetch(n + 1)
         for j in range(NR):
             m, i = j >> 2, j & 3
@@ -623,7 +644,7 @@ def gen_admission(space):
 
 def gen_hit_stubs(copy=""):
     out = []
-    for n in range(16):
+    for n in range(NQT):
         out.append(f".Lhit{n}{copy}_%=:")
         if FUSE and I8_SPACE == "cosine":   # the pre-test let a lane through: the 8 exact bounds of this query tile (gen_admission's arithmetic)
             for j in range(4 * MT):
@@ -795,14 +816,19 @@ def gen_flush(NW):
 
 
 def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False, q4=False, place=None, burst=0, q3d=False,
-             qa=False, eo=False, fs=False):
+             qa=False, eo=False, fs=False, nqt=16):
     """stag: both waves of a SIMD reach the admission test (VALU only) together and leave the MFMA pipe idle for it.
     With the stagger the later-dispatched half of a workgroup's waves (wtype 1) runs half a tile behind: it sits out
     the first nkc/2 chunk periods (staging only), starts every row tile at column ld/2 (k origin rotated by xrot,
     wrapping at the end of the panel; the shared Q chunk stream is the same for everybody) and therefore reaches its
     admission test while its SIMD partner is in mid-tile; the early half sits out nkc/2 periods at the end.
     hc = 0 (and xrot = 0) turns it off at run time."""
-    global MT, STAG, I8, I8_SPACE, VA
+    global MT, STAG, I8, I8_SPACE, VA, NQT
+    # nqt (int8 VA bodies): passes of <= 64 / <= 128 queries compute 4 / 8 of the 16 query tiles.  The empty tiles' MFMAs, B
+    # reads, Q transfers and admission tests are simply not generated; chunks, barriers, the ring and the image layout stay
+    # (a chunk period is then ~3,300 cycles of HBM stream against ~250 of MFMAs: the body is a pure stream of the shadow).
+    NQT = nqt
+    assert nqt == 16 or (nqt in (4, 8) and i8 and va and dma and NW == 8 and not (stag or q4 or q3d or qa or burst))
     MT = mt
     STAG = stag
     I8 = i8
@@ -881,7 +907,8 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     if not dma:
         a("v_mov_b32 %[ldw], %[qvoff]")        # ... and this one to buffer 1
     # ---- prologue: Q chunk 0 -> LDS buffer 0, chunk 1 -> the sets (register staging only), k-steps 0..R-1 -> the ring
-    pieces = [(i * NW * 2048 + half * 1024, setname, i) for half, setname in ((0, "qb"), (1, "qa")) for i in range(KQ)]
+    pieces = ([(const, setname, i) for setname, i, _, const in dma_pieces(NW)] if dma else
+              [(i * NW * 2048 + half * 1024, setname, i) for half, setname in ((0, "qb"), (1, "qa")) for i in range(KQ)])
     if dma:
         a("s_mov_b32 %[sldw], %[wave2k]")          # buffer 0; the first chunk toggles it to buffer 1
         for const, setname, i in pieces:
@@ -932,7 +959,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")   # counted waits below assume the steady-state issue pattern
     a("s_barrier")
     if FUSE and space == "cosine":   # the thresholds of this lane's query column in the 16 query tiles: constant for the whole launch
-        for n in range(16):
+        for n in range(NQT):
             a(f"ds_read_b32 %[tq{n}], %[thra]" + (f" offset:{n * 64}" if n else ""))
         a("s_waitcnt lgkmcnt(0)")
     if qa:   # the first tile's first fragments (every later chunk's are read at the end of the chunk before it)
@@ -1048,7 +1075,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     for j in range(13):
         ops_out.append(f'[e{j}] "=&v"(ve[{j}])')
     if FUSE:
-        for n in range(16 if space == "cosine" else L2IP_TQ):
+        for n in range(NQT if space == "cosine" else L2IP_TQ):
             ops_out.append(f'[tq{n}] "=&v"(vt[{n}])')
     ops_out += ['[ldr] "=&v"(ldr)'] + (['[sldw] "=&s"(s_sldw)'] if dma else ['[ldw] "=&v"(ldw)'])
     for name in [f"xso{m}" for m in range(MT)] + ["qcur", "cnt", "st0", "tl", "trow", "sn64", "wcnt", "sacc0", "sacc1"]:
@@ -1120,6 +1147,11 @@ def entries():
     # ---- default library
     for sp in SPACES:   # the int8 bodies with ArchVGPR accumulators (wave priorities on): QD slot 211
         E.append((f"scan_asm_{sp}_i8_va.inc", cond(sp, 8, 4, True, 211, True, 2, True, False), (lambda sp=sp: default_i8_body(sp)), "default"))
+    # 241 / 242 (round 4): the default body computing 8 / 4 of the 16 query tiles: passes of <= 128 / <= 64 queries
+    for sp in SPACES:
+        for code, nqt in ((241, 8), (242, 4)):
+            E.append((f"scan_asm_{sp}_i8_va_nqt{nqt}.inc", cond(sp, 8, 4, True, code, True, 2, True, False),
+                      (lambda sp=sp, nqt=nqt: with_dbg((), sp, 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True, nqt=nqt)), "default"))
     # 237: round 2's default body (append routine with eight skipped row blocks, stubs without the early out): the A/B reference
     E.append(("scan_asm_cosine_i8_va_r2.inc", cond("cosine", 8, 4, True, 237, True, 2, True, False),
               lambda: with_dbg((), "cosine", 4, 4, 8, True, True, 2, True, False, True, True), "default"))
