@@ -100,6 +100,7 @@ struct mlvdb_index {
     int64_t i8_rows = 0;      // rows [0, i8_rows) of the int8 shadow are current (0 after compact / reset / regrowth)
     float i8_err = 0.f;       // host copy of rowerr8 (read back whenever rows were converted)
     bool sqmin_fresh = false;  // fmisc was just (re)allocated: FilterArgs::sqmin[] not initialised yet
+    uint64_t l2c_passes = 0;   // l2c passes so far: their parity picks the QMAX word (the other one is being zeroed for the next pass)
     bool mask_active = false;  // h->rn is a masked copy (mlvdb_search_batch_filtered)
     bool mask_pairs_ready = false;  // ... and rp8_masked holds the masked copy of the int8 shadow's row pairs
     DevBuf rp8_masked;
@@ -377,7 +378,8 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     fa.ke = h->fmisc.as<float>() + 4 * kFilterQueries;
     fa.keb = h->fmisc.as<float>() + 5 * kFilterQueries;
     fa.ke8 = h->fmisc.as<float>() + 6 * kFilterQueries;  // 257 floats
-    fa.sqmin = h->fmisc.as<uint32_t>() + 7 * kFilterQueries + 128;
+    fa.sqmin = h->fmisc.as<uint32_t>() + 7 * kFilterQueries + 128;  // [0..1] smallest scale / largest error (cosine); [2..3] l2c QMAX by parity
+    fa.l2c_out = h->fmisc.as<float>() + 7 * kFilterQueries + 132;
     fa.rs = h->rescr.as<RangeHit>();
     fa.cand = h->cand.as<CandEntry>();
     fa.cand_cap = kCandCap;
@@ -422,7 +424,8 @@ bool i8_eligible(const mlvdb_index* h) {
 // Bring the int8 shadow up to date (rows appended since the last pass).  Must run with the index's own norms in h->rn
 // (a row-mask search swaps them for a masked copy afterwards).
 int update_i8_shadow(mlvdb_index* h, hipStream_t s) {
-    const size_t need_x8 = (size_t)h->capacity * h->ld8, need_rp = (size_t)h->capacity * 2 * sizeof(float);
+    // (l2: a third float-sized word per row behind the pairs: the integer offsets of the folded admission test, per pass)
+    const size_t need_x8 = (size_t)h->capacity * h->ld8, need_rp = (size_t)h->capacity * (h->space == kSpaceL2 ? 3 : 2) * sizeof(float);
     if (h->x8.bytes < need_x8 || h->rp8.bytes < need_rp || !h->rowerr8.p) {
         HIP_TRY(h, h->x8.ensure(need_x8));
         HIP_TRY(h, h->rp8.ensure(need_rp));
@@ -460,6 +463,9 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
     HIP_TRY(h, h->sq8.ensure(kFilterQueries * sizeof(float)));
     fa.X8 = h->x8.p;
     fa.rp8 = h->mask_active ? h->rp8_masked.as<float>() : h->rp8.as<float>();  // a masked-out row is a NaN pair: "not a row"
+    // l2: pairs + offsets through one buffer descriptor (32-bit offsets): 12 bytes per row must stay below 4 GB
+    fa.rp8_cap = h->space == kSpaceL2 && h->tn.scan_l2e && (uint64_t)h->capacity * 12ull < 0xfff00000ull ? h->capacity : 0;
+    if (fa.rp8_cap > 0 && h->tn.scan_l2c) fa.l2c = 2 + (int32_t)((h->l2c_passes++) & 1);
     fa.row_err8 = h->rowerr8.as<float>();
     fa.qimg8 = h->qimg8.p;
     fa.sq8 = h->sq8.as<float>();
@@ -474,10 +480,17 @@ int finish_filter_pass(mlvdb_index* h, hipStream_t s, FilterArgs& fa, int32_t q0
 int prep_pass(mlvdb_index* h, hipStream_t s, const FilterArgs& fa, const float* queries_raw, float* Qpad, double* qaux, float* qerr) {
     if (h->sqmin_fresh) {  // what the fused prep's atomicMin / atomicMax start from; afterwards every fin kernel restores it
         HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fa.sqmin), 0x7f7f7f7f, 1, s));
-        HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fa.sqmin + 1), 0, 1, s));
+        HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fa.sqmin + 1), 0, 3, s));  // ... and the two l2c QMAX words
         h->sqmin_fresh = false;
     }
     HIP_TRY(h, launch_filter_prep_fused(fa, queries_raw, h->dim, Qpad, qaux, qerr, s));
+    if (fa.X8 && fa.rp8_cap > 0) {
+        // l2: this pass's integer offsets (they depend on its largest query scale and on which rows are live): 29 us for 10M rows.
+        // (Tried: on a side stream beside the seeding pass and the first refine, joined by an event before the first assembly scan
+        // -- no gain, 1.971 vs 1.954 ms per wave in same-process A/Bs: profiles/r04/scan_ab_l2*_10m.txt; it stays in the pass's stream.)
+        const int64_t rows = std::min<int64_t>(h->capacity, (h->total + kFilterTile - 1) / kFilterTile * kFilterTile);
+        HIP_TRY(h, launch_filter_l2_offsets(fa, rows, s));
+    }
     return MLVDB_OK;
 }
 
@@ -1554,7 +1567,7 @@ int mlvdb_search_batch_ex(mlvdb_index* h, const float* queries, int64_t nq, int3
     if (i8_eligible(h)) {
         rc = update_i8_shadow(h, h->stream);
         if (rc) return rc;
-        HIP_TRY(h, h->rp8_masked.ensure((size_t)h->capacity * 2 * sizeof(float)));
+        HIP_TRY(h, h->rp8_masked.ensure((size_t)h->capacity * (h->space == kSpaceL2 ? 3 : 2) * sizeof(float)));
         HIP_TRY(h, launch_mask_pairs(h->rp8.as<float>(), h->row_mask.as<uint8_t>(), h->rp8_masked.as<float>(), h->total,
                                      h->capacity, h->stream));
         h->mask_pairs_ready = true;

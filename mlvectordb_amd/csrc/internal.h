@@ -66,6 +66,8 @@ inline hipError_t ensure_dynamic_lds(std::atomic<uint64_t>& done, const void* ke
     X(narrow_balance, "NARROW_BALANCE", 1)                                                                              \
     X(scan_xcd, "SCAN_XCD", 0)                                                                                          \
     X(scan_asm, "SCAN_ASM", 1)                                                                                          \
+    X(scan_l2c, "SCAN_L2C", 1)         /* l2: one query quantisation step per pass + one error coefficient: cosine's one-constant test */ \
+    X(scan_l2e, "SCAN_L2E", 1)         /* l2: folded admission test with per-row integer offsets (0: serial test, round 3's body) */ \
     X(scan_nqt, "SCAN_NQT", 0)         /* query tiles of the int8 body: 0 = by batch size, else 4 / 8 / 16 */          \
     X(scan_nw, "SCAN_NW", 8)           /* [AB] */                                                                       \
     X(scan_mt, "SCAN_MT", 2)           /* [AB] */                                                                       \
@@ -226,6 +228,10 @@ struct FilterArgs {
     // int8 shadow (cosine, ld % 256 == 0; MLVDB_I8=0 disables): all null / unused otherwise
     const void* X8;         // int8 rows, per-row scale: panels of 16 rows, 64-column groups of 1 KiB (layout_offset_i8)
     const float* rp8;       // [rows][2] cosine {scale/(|x|+1e-30), row error}, l2 / ip {scale, |x|}; NaN = tombstoned
+    int64_t rp8_cap;        // l2: rows the rp8 array was allocated for; behind its pairs (float index 2 * rp8_cap) lies the plane of
+                            // per-row int32 offsets of the folded l2 admission test (filter_l2_offsets_kernel).  0 = none
+    int32_t l2c;            // l2, common query scale for the pass: 0 = off, else 2 + (parity of the pass: which of sqmin[2..3] holds its QMAX)
+    float* l2c_out;         // l2: {SQ, KE} of the pass, written by filter_l2_offsets_kernel, read by the l2c scan bodies
     const float* row_err8;  // device scalar: max over rows of |x - scale * x8| / |x| (rounded up)
     void* qimg8;            // int8 query image
     float* sq8;             // [256] scale of the query image
@@ -258,6 +264,9 @@ struct ScanInfo {
 hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t row_begin,
                                int64_t row_end, int32_t ld, int32_t ld8, int32_t space, hipStream_t s);
 hipError_t launch_filter_prep8(const FilterArgs& a, hipStream_t s);
+// l2, once per pass (after the prep kernels): the integer offsets e_j of rows [0, rows) that fold the row term -|x|^2 of the l2
+// score into the scan's accumulators (tools/gen_scan_asm.py, l2e): needs a.rp8_cap > 0
+hipError_t launch_filter_l2_offsets(const FilterArgs& a, int64_t rows, hipStream_t s);
 bool filter_refine_can_fuse(const FilterArgs& a);
 bool filter_narrow_ok(const FilterArgs& a);  // the pass's scans run on the narrow kernel (<= 64 queries, image resident in LDS)
 hipError_t launch_filter_refine_thr(const FilterArgs& a, int32_t k, int32_t forced_cnt, bool fuse, hipStream_t s);

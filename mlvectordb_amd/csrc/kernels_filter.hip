@@ -614,7 +614,9 @@ static_assert(kAsmWgCap == kWgCap, "tools/gen_scan_asm.py and internal.h disagre
 // timing diagnostics).
 constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 249; }
 // 241 / 242 (round 4): the default int8 body computing only the first 8 / 4 query tiles (passes of <= 128 / <= 64 queries)
-constexpr int scan_code_nqt(int qd) { return qd == 241 ? 8 : (qd == 242 ? 4 : 16); }
+constexpr int scan_code_nqt(int qd) { return (qd == 241 || qd == 247 || qd == 244) ? 8 : ((qd == 242 || qd == 248 || qd == 245) ? 4 : 16); }
+// 246 / 247 / 248 (round 4): l2 with the folded admission test, per-row integer offsets through the first k-step's C operand
+constexpr bool scan_code_l2e(int qd) { return qd >= 243 && qd <= 248; }  // 243-245: l2c (+ one query scale, one error coefficient per pass)
 constexpr int scan_code_qd(int qd) { return qd == 215 ? 8 : (qd > 8 ? 4 : qd); }
 constexpr bool scan_code_q4(int qd) { return qd == 219 || qd == 229 || qd == 231 || qd == 233; }  // four Q chunk buffers
 constexpr int scan_code_qbufs(int qd) { return scan_code_q4(qd) ? 4 : 2; }
@@ -766,6 +768,21 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     const uint32_t crow = (uint32_t)wave * (uint32_t)kWaveRows + g * 4;
     static_assert(kWgCap == 16384 && sizeof(WgEntry) == 16, "the assembly hard-codes the append buffer geometry");
 
+    // l2e bodies: the offsets plane lies 8 x rp8_cap bytes behind the pairs; eo0 = that distance less 4 bytes per row of this
+    // wave's first row (the pairs' descriptor base already points 8 bytes per row into the array): mod 2^32, < 2^32 by the
+    // launcher's check
+    const uint32_t eo0 = __builtin_amdgcn_readfirstlane(
+        (uint32_t)(8ull * (uint64_t)a.rp8_cap - 4ull * (uint64_t)(first_tile * kTileRowsV + wave * kWaveRows)));
+    (void)eo0;
+    // l2c bodies: the pass's common query scale SQ and error coefficient KE (filter_l2_offsets_kernel; SGPR operands)
+    const float sqc = scan_code_l2e(QD) ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a.l2c_out[0]))) : 0.f;
+    const float kec = scan_code_l2e(QD) ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a.l2c_out[1]))) : 0.f;
+    (void)sqc;
+    (void)kec;
+    u32x4s veo[MT];
+    uint32_t s_eo;
+    (void)veo;
+    (void)s_eo;
     u32x4s xring[R * MT], qsa[kQPer], qsb[kQPer], qt[scan_code_qd(QD)];
     float vr[4 * MT], vp[4 * MT], vu[4 * MT], vs[4 * MT], vt[16];
     (void)vs;
@@ -1597,7 +1614,8 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
             const float shared = ratio * (nrm[p] + 1e-30f) * (1.0f / 127.0f) * 1.0000005f;
             if (shared > sx) sx = shared;  // never finer than the row's own scale: nothing clips
         }
-        if (space == kSpaceIp && nrm[p] == nrm[p] && gmax > amax[p]) sx = gmax / 127.0f;  // the group's scale (>= the row's own)
+        // ip, l2: the group's scale (>= the row's own).  (l2 since round 4: the folded admission test needs one scale per lane)
+        if ((space == kSpaceIp || space == kSpaceL2) && nrm[p] == nrm[p] && gmax > amax[p]) sx = gmax / 127.0f;
         const float inv = 1.0f / sx;
         double err2 = 0.0, n2 = 0.0;
         const float4* src = reinterpret_cast<const float4*>(X + panel * (int64_t)(kPanelRows * ld) + lane_group_offset(lane));
@@ -1636,6 +1654,67 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
             reinterpret_cast<float2*>(rp8)[row] = pr;
         }
     }
+}
+
+// l2, once per pass: e[row] = ceil((p_row - P0) / (SQ S)) + 1 (<= 1), the integer that, added to the row's int8 dot product,
+// stands for the difference between the row's own term p = -(1 - slack) |x|^2 and the largest such term P0 among the 8 rows one
+// scan lane holds (rows 4g..4g+3 of both panels of a 32-row slab), in units of one quantum SQ S of the score: SQ = the largest
+// sq = 2 |q| sq8 of the pass's queries (so the bound holds for every query: sq <= SQ and p - P0 <= 0), S = the lane's scale.
+// p, P0, S and SQ are formed by the very float operations the scan uses (tools/gen_scan_asm.py: gen_rowmax_l2ip, the wrapper's
+// preamble); dead rows (NaN pairs) drop out of the maxima and get 0.  One thread per row; a slab's 32 rows are 32 adjacent lanes.
+__global__ __launch_bounds__(256) void filter_l2_offsets_kernel(const FilterArgs a, const int64_t rows) {
+    __shared__ float s_sq[4], s_ke[4];
+    {
+        const int t = threadIdx.x;  // 256 threads = kFilterQueries
+        float sq = t < a.nq ? a.qscale[t] * a.sq8[t] : 0.f;  // (the scan's preamble: sqv * a.sq8[t])
+        if (!(sq == sq)) sq = 0.f;
+        // l2c: one error coefficient for the pass, KE >= sq_q ke'_q = 2 |q| ke_q of every query, with room for the roundings of
+        // sq_q against SQ and of S SQ (each <= 2e-7 relative of 2 |q| |x|)
+        float ke = t < a.nq ? float_above((double)a.qscale[t] * ((double)a.ke[t] * 1.000002 + 1.0e-6)) : 0.f;
+        if (!(ke == ke)) ke = 0.f;
+        for (int off = 32; off > 0; off >>= 1) {
+            sq = __builtin_fmaxf(sq, __shfl_xor(sq, off));
+            ke = __builtin_fmaxf(ke, __shfl_xor(ke, off));
+        }
+        if ((t & 63) == 0) {
+            s_sq[t >> 6] = sq;
+            s_ke[t >> 6] = ke;
+        }
+    }
+    __syncthreads();
+    const float SQ = __builtin_fmaxf(__builtin_fmaxf(s_sq[0], s_sq[1]), __builtin_fmaxf(s_sq[2], s_sq[3]));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // what the l2c scan bodies take as scalars (the kernel boundary publishes them)
+        a.l2c_out[0] = SQ;
+        a.l2c_out[1] = __builtin_fmaxf(__builtin_fmaxf(s_ke[0], s_ke[1]), __builtin_fmaxf(s_ke[2], s_ke[3]));
+    }
+    const float k1 = -(1.0f - kSlack);
+    int32_t* eoff = reinterpret_cast<int32_t*>(const_cast<float*>(a.rp8) + 2 * a.rp8_cap);
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < rows; row += (int64_t)gridDim.x * 256) {
+        const float2 pr = reinterpret_cast<const float2*>(a.rp8)[row];  // {scale, |x|}, NaN = dead
+        float p = pr.y * pr.y;
+        p = k1 * p;
+        float P0 = p, S = pr.x;  // maxima over the lane group: rows r ^ 1, r ^ 2, r ^ 3 (same panel) and r ^ 16 (the other panel)
+        P0 = __builtin_fmaxf(P0, __shfl_xor(P0, 1));
+        P0 = __builtin_fmaxf(P0, __shfl_xor(P0, 2));
+        P0 = __builtin_fmaxf(P0, __shfl_xor(P0, 16));
+        S = __builtin_fmaxf(S, __shfl_xor(S, 1));
+        S = __builtin_fmaxf(S, __shfl_xor(S, 2));
+        S = __builtin_fmaxf(S, __shfl_xor(S, 16));
+        int32_t e = 0;
+        const double quantum = (double)SQ * (double)S;
+        if (p == p && P0 == P0 && quantum > 0.0) {
+            const double d = __builtin_ceil(((double)p - (double)P0) / quantum);  // <= 0
+            e = (int32_t)(d < -1073741824.0 ? -1073741824.0 : d) + 1;
+        }
+        eoff[row] = e;
+    }
+}
+
+hipError_t launch_filter_l2_offsets(const FilterArgs& a, int64_t rows, hipStream_t s) {
+    if (a.rp8_cap <= 0 || rows <= 0) return hipSuccess;
+    const int64_t blocks = std::min<int64_t>(2048, (rows + 255) / 256);
+    filter_l2_offsets_kernel<<<(unsigned)blocks, 256, 0, s>>>(a, rows);
+    return hipGetLastError();
 }
 
 hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float* rp8, float* row_err8, int64_t row_begin,
@@ -1821,8 +1900,17 @@ __global__ __launch_bounds__(256) void filter_prep_fused_kernel(const FilterArgs
         a.overflow[q] = 0;
     }
     if (!want_i8) return;
-    // 3. int8 image, scale and error (filter_prep8_kernel); a.sqmin[] was left initialised by the previous pass's fin kernel
     amax = __builtin_fmaxf(__builtin_fmaxf(fred[0], fred[1]), __builtin_fmaxf(fred[2], fred[3]));
+    if (a.l2c) {
+        // l2 with one quantisation step for the whole pass (round 4: filter_prep8_l2c_kernel builds the images once the pass's
+        // largest raw component is known): here only this query's largest |q_i| = max |q^_i| x |q|, rounded up
+        if (threadIdx.x == 0 && real) {
+            const float rmax = float_above((double)amax * (qaux[q] + 1e-30) * 1.000001);
+            atomicMax(a.sqmin + 2 + (a.l2c & 1), __float_as_uint(rmax));  // (non-negative floats order like their bits)
+        }
+        return;
+    }
+    // 3. int8 image, scale and error (filter_prep8_kernel); a.sqmin[] was left initialised by the previous pass's fin kernel
     const float sq = amax > 0.f ? amax / 127.0f : 1.0f;
     const float isq = 1.0f / sq;
     int8_t* img8 = reinterpret_cast<int8_t*>(a.qimg8);
@@ -1857,12 +1945,58 @@ __global__ __launch_bounds__(256) void filter_prep_fused_kernel(const FilterArgs
     if (want_i8 && a.nq == 1 && q > 0 && threadIdx.x == 0) prep8_fin_query(a, q, 1.0f, 0.0f);  // padded slots (never admitted)
 }
 
+// l2, common query scale (a.l2c = 2 + parity of the pass; round 4).  The l2 score in the scan's units is
+//   s = 2 |q| <q^, x> - |x|^2 ~ sq (S I) - |x|^2,   sq = 2 |q| sq8   (sq8 = the scale of the query's int8 image),
+// and the folded admission test (tools/gen_scan_asm.py, l2c) wants ONE sq for every query of the pass: then the per-row
+// integer offsets are exact for every query and the test needs one per-query constant (the threshold), like cosine's.  So
+// the images are built with sq8_q = SQ / (2 |q|), SQ = 2 QMAX / 127 and QMAX = the largest |q_i| of the pass's raw queries
+// (atomicMax of the fused kernel's blocks): every query is quantised with the same absolute step SQ / 2.  A query whose own
+// largest component is smaller uses fewer of the 255 levels; its measured error eq8 (as always: measured, rounded up) says so.
+// Block q: image, scale, error and the per-query error terms (prep8_fin_query: l2 needs nothing of the other queries).
+__global__ __launch_bounds__(256) void filter_prep8_l2c_kernel(const FilterArgs a) {
+    __shared__ double dred[4];
+    const int q = blockIdx.x;
+    const int ld = a.ld;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool real = q < a.nq;
+    const int par = a.l2c & 1;
+    const float qmax = __uint_as_float(a.sqmin[2 + par]);
+    if (q == 0 && threadIdx.x == 0) a.sqmin[2 + (par ^ 1)] = 0u;  // the next pass's word (nobody reads or adds to it during this one)
+    const float SQ = qmax > 0.f ? float_above((double)qmax * (2.0 / 127.0) * 1.000001) : 1.0f;
+    const double nrm = real ? a.qaux[q] : 0.0;  // l2: qaux = |q|
+    const float invf = (float)(1.0 / (nrm + 1e-30));  // as filter_prep_kernel forms q^ = q / (|q| + 1e-30)
+    const float sq = nrm > 0.0 ? (float)((double)SQ / (2.0 * nrm)) : 1.0f;
+    const float isq = 1.0f / sq;
+    int8_t* img8 = reinterpret_cast<int8_t*>(a.qimg8);
+    const int n16 = q >> 4, c16 = q & 15;
+    double err2 = 0.0;
+    for (int c = threadIdx.x; c < a.ld8; c += 256) {  // (columns ld..ld8 of the image: zeros, like the shadow's)
+        const float v = real && c < ld ? a.Qpad[(int64_t)q * ld + c] * invf : 0.f;
+        float t = __builtin_rintf(v * isq);
+        t = __builtin_fminf(127.f, __builtin_fmaxf(-127.f, t));
+        const double e = (double)v - (double)sq * (double)t;
+        err2 += e * e;
+        const int kc = c >> 7, ks = (c >> 6) & 1, g = (c >> 4) & 3, j = c & 15;
+        img8[((((int64_t)kc * 16 + n16) * 2 + ks) * 64 + (c16 + 16 * g)) * 16 + j] = (int8_t)t;
+    }
+    for (int off = 32; off > 0; off >>= 1) err2 += __shfl_xor(err2, off);
+    if (lane == 0) dred[wave] = err2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double eq8 = __builtin_sqrt(dred[0] + dred[1] + dred[2] + dred[3]) * 1.000001 + 1e-12;
+        a.sq8[q] = sq;
+        a.ke8[q] = real ? float_above(eq8) : 0.f;
+        prep8_fin_query(a, q, 1.0f, 0.0f);  // (l2: the query's own error only; a.ke[q] = the bf16 term the fused kernel left)
+    }
+}
+
 hipError_t launch_filter_prep_fused(const FilterArgs& a, const float* queries, int32_t dim, float* Qpad, double* qaux, float* qerr,
                                     hipStream_t s) {
     const int want_i8 = a.X8 != nullptr;
     if (!want_i8 && !filter_supported(a.ld)) return hipErrorInvalidValue;
     filter_prep_fused_kernel<<<kFilterQueries, 256, 0, s>>>(a, queries, dim, Qpad, qaux, qerr, want_i8);
-    if (want_i8 && a.nq > 1) filter_prep8_fin_kernel<<<1, kFilterQueries, 0, s>>>(a, 1);  // (one query: done inside the kernel above)
+    if (want_i8 && a.l2c) filter_prep8_l2c_kernel<<<kFilterQueries, 256, 0, s>>>(a);
+    else if (want_i8 && a.nq > 1) filter_prep8_fin_kernel<<<1, kFilterQueries, 0, s>>>(a, 1);  // (one query: done inside the kernel above)
     return hipGetLastError();
 }
 
@@ -2628,6 +2762,18 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
             }
             // passes of <= 64 / <= 128 queries: the same body computing 4 / 8 of the 16 query tiles (round 4; SCAN_NQT=16 pads)
             const int nqt = tn.scan_nqt > 0 ? tn.scan_nqt : (a.nq <= 64 ? 4 : (a.nq <= 128 ? 8 : 16));
+            if constexpr (SPACE == kSpaceL2) {  // folded admission test with per-row integer offsets (the pass computed them: api.hip prep_pass)
+                if (a.rp8_cap > 0 && a.l2c) {  // ... and one query scale / error coefficient per pass (the prep built the images so)
+                    if (nqt <= 4 && a.nq <= 64) return launch_scan_asm<SPACE, 4, 8, true, 245, true, 2, true>(a, row_begin, row_end, s, info);
+                    if (nqt <= 8 && a.nq <= 128) return launch_scan_asm<SPACE, 4, 8, true, 244, true, 2, true>(a, row_begin, row_end, s, info);
+                    return launch_scan_asm<SPACE, 4, 8, true, 243, true, 2, true>(a, row_begin, row_end, s, info);
+                }
+                if (a.rp8_cap > 0 && tn.scan_l2e) {
+                    if (nqt <= 4 && a.nq <= 64) return launch_scan_asm<SPACE, 4, 8, true, 248, true, 2, true>(a, row_begin, row_end, s, info);
+                    if (nqt <= 8 && a.nq <= 128) return launch_scan_asm<SPACE, 4, 8, true, 247, true, 2, true>(a, row_begin, row_end, s, info);
+                    return launch_scan_asm<SPACE, 4, 8, true, 246, true, 2, true>(a, row_begin, row_end, s, info);
+                }
+            }
             if (nqt <= 4 && a.nq <= 64) return launch_scan_asm<SPACE, 4, 8, true, 242, true, 2, true>(a, row_begin, row_end, s, info);
             if (nqt <= 8 && a.nq <= 128) return launch_scan_asm<SPACE, 4, 8, true, 241, true, 2, true>(a, row_begin, row_end, s, info);
             return launch_scan_asm<SPACE, 4, 8, true, 211, true, 2, true>(a, row_begin, row_end, s, info);

@@ -61,6 +61,10 @@ QA = False     # generate(): four Q buffers, chunk c+2 staged during chunk c, on
 #                last QD fragments of chunk c, before the barrier (see generate)
 EO = False     # generate(): hit stubs leave at once when none of the 8 exact bounds passes (see gen_hit_stubs)
 FS = False     # generate(): append routine with a straight-line common case (see gen_slow_fast)
+L2E = False    # generate(): l2 with the admission test folded into the last k-step, made sharp by per-row integer offsets that
+#                enter the accumulators through the first k-step's C operand (see generate)
+L2C = False    # generate(): L2E with ONE query scale SQ and ONE error coefficient KE for the whole pass (the prep builds the images
+#                that way): the pre-test is cosine's -- one fma against a threshold held in a register (see generate)
 NQT = 16       # generate(): query tiles (of 16 queries) the body computes: 16 = a full 256-query pass; 8 / 4 (int8 VA bodies, round 4) for
 #                passes of <= 128 / <= 64 queries -- the MFMAs, B-fragment reads, Q staging and admission tests of the empty tiles are
 #                not issued at all, which leaves a pure stream of the shadow (see generate)
@@ -161,14 +165,17 @@ def gen_pretest(s, n, part):
     part 0 / 1: the halves issued after the first / second MFMA of the query tile two steps later."""
     a = s.emit
     regs = [acc_reg(m, n, i) for m in range(MT) for i in range(4)]
-    if I8_SPACE != "cosine":
+    if I8_SPACE != "cosine" and not L2C:
         return gen_pretest_l2ip(s, n, part, regs)
     t0, t1 = (("%[e0]", "%[e1]") if n & 1 == 0 else ("%[e2]", "%[e3]"))
     if part == 0:
         a(f"v_max3_i32 {t0}, {regs[0]}, {regs[1]}, {regs[2]}")
         a(f"v_max3_i32 {t1}, {regs[3]}, {regs[4]}, {regs[5]}")
         a(f"v_max3_i32 {t0}, {t0}, {regs[6]}, {regs[7]}")
-        a(f"v_max3_i32 {t0}, {t0}, {t1}, 0")
+        if L2C:   # (A_j = I_j + e_j times ONE positive factor S SQ: no clamp at 0 needed, and none wanted)
+            a(f"v_max_i32 {t0}, {t0}, {t1}")
+        else:
+            a(f"v_max3_i32 {t0}, {t0}, {t1}, 0")
     else:
         a(f"v_cvt_f32_i32 {t0}, {t0}")
         a(f"v_fma_f32 {t0}, {t0}, %[e10], %[e12]")
@@ -214,7 +221,10 @@ def gen_pretest_l2ip(s, n, part, regs):
         a(f"v_max3_i32 {L2IP_T0}, {regs[0]}, {regs[1]}, {regs[2]}")
         a(f"v_max3_i32 {L2IP_T1}, {regs[3]}, {regs[4]}, {regs[5]}")
         a(f"v_max3_i32 {L2IP_T0}, {L2IP_T0}, {regs[6]}, {regs[7]}")
-        a(f"v_max3_i32 {L2IP_T0}, {L2IP_T0}, {L2IP_T1}, 0")
+        if L2E:   # A_j = I_j + e_j, one scale S for the lane's rows: max_j (A_j S) = (max_j A_j) S whatever the sign
+            a(f"v_max_i32 {L2IP_T0}, {L2IP_T0}, {L2IP_T1}")
+        else:
+            a(f"v_max3_i32 {L2IP_T0}, {L2IP_T0}, {L2IP_T1}, 0")
         if n + 1 < NQT:
             l2ip_fetch(s, n + 1)
     else:
@@ -242,7 +252,8 @@ def gen_rowmax_l2ip(s, part):
             for j in range(NR):
                 a(f"v_mul_f32 %[p{j}], %[k1], %[p{j}]")        # k1 = -(1 - slack)
     else:
-        trees = [(L2IP_SMAX, "s"), (L2IP_NMAX, "r")] + ([(L2IP_PMAX, "p")] if I8_SPACE == "l2" else [])
+        # (L2E: the rows' scales were loaded into the u registers, free until the first stub runs; only their maximum is kept)
+        trees = [(L2IP_SMAX, "u" if L2E else "s"), (L2IP_NMAX, "r")] + ([(L2IP_PMAX, "p")] if I8_SPACE == "l2" else [])
         for dst, src in trees:
             a(f"v_max3_f32 {dst}, %[{src}0], %[{src}1], %[{src}2]")
             for j in range(3, NR - 1, 2):
@@ -252,8 +263,39 @@ def gen_rowmax_l2ip(s, part):
         l2ip_fetch(s, 0)
 
 
+def gen_rowmax_l2c(s, part):
+    """Start of the last k-step, l2c.  Loaded: u_j = the rows' scales (one value per lane group; NaN = dead row), r_j = |x_j|.
+    e10 = S SQ (the factor of the integer A = I + e), r_j becomes c_j = KE N_j + P0 with P0 = max_j -(1 - slack) N_j^2, and
+    e12 = max_j c_j: the pre-test is  float(max_j A_j) e10 + e12 >= thr,  the stubs' per-row test  float(A_j) e10 + c_j >= thr.
+    NaN rows drop out of every v_max; their c_j stays NaN and fails every compare."""
+    a = s.emit
+    NR = 4 * MT
+    assert NR == 8
+
+    def tree(dst, src):
+        a(f"v_max3_f32 {dst}, %[{src}0], %[{src}1], %[{src}2]")
+        a(f"v_max3_f32 {dst}, {dst}, %[{src}3], %[{src}4]")
+        a(f"v_max3_f32 {dst}, {dst}, %[{src}5], %[{src}6]")
+        a(f"v_max_f32 {dst}, {dst}, %[{src}7]")
+
+    if part == 0:
+        tree("%[e10]", "u")
+        a("v_mul_f32 %[e10], %[sqc], %[e10]")
+        for j in range(NR):
+            a(f"v_mul_f32 %[u{j}], %[r{j}], %[r{j}]")
+        for j in range(NR):
+            a(f"v_mul_f32 %[u{j}], 0xbf7fffe0, %[u{j}]")    # -(1 - 2^-19) = -(1.0f - kSlack): the constant of scan_epilogue and of filter_l2_offsets_kernel
+    else:
+        tree("%[e12]", "u")                                 # P0
+        for j in range(NR):
+            a(f"v_fma_f32 %[r{j}], %[kec], %[r{j}], %[e12]")
+        tree("%[e12]", "r")
+
+
 def gen_rowmax(s, part):
     """Start of the last k-step: p_j *= K, then R = max r_j and P = max p_j over this lane's rows (e10, e12)."""
+    if L2C:
+        return gen_rowmax_l2c(s, part)
     if I8_SPACE != "cosine":
         return gen_rowmax_l2ip(s, part)
     a = s.emit
@@ -401,7 +443,7 @@ def gen_chunk(s, R, QD, KQ, NW, step0, zero_first, last, nt, prio=False, dma=Fal
                 s.need_vm(*[("rn", j) for j in range(4 * MT)])
         s.need_lg(("rd", f))
         for m in range(MT):
-            c = "0" if (zero_first and h == 0) else acc(m, n)
+            c = (f"%[eo{m}]" if L2E else "0") if (zero_first and h == 0) else acc(m, n)
             op = "v_mfma_i32_16x16x64_i8" if I8 else "v_mfma_f32_16x16x32_bf16"
             if "nomfma" not in DBG:
                 s.emit(f"{op} {acc(m, n)}, {ring(b, m)}, %[t{f % QD}], {c}")
@@ -489,7 +531,27 @@ def stage_only_chunk(KQ, NW):
     return o
 
 
+def gen_eo_loads(s, next_tile=True):
+    """L2E: the per-row integer offsets of this wave's 32 rows of the NEXT tile (the last tile of a workgroup re-reads its own:
+    harmless) -> the two 4-register tuples eo0 / eo1, which are the C operands of that tile's first k-step.  They live in the
+    same allocation as the row pairs, 8 x capacity bytes further on; the SGPR `eo` holds that distance less 4 x (the wave's
+    first row), so that one descriptor (the row pairs') serves both."""
+    s.emit("v_lshrrev_b32 %[e0], 1, %[rnvoff]")       # 16 g: this lane's 4 rows x 4 bytes inside a panel's 64
+    if next_tile:
+        s.emit("s_lshr_b32 %[st0], %[rnstride], 1")    # the next tile's rows: 4 bytes per row where the pairs have 8
+        s.emit("s_cmp_gt_u32 %[tl], 1")
+        s.emit("s_cselect_b32 %[st0], %[st0], 0")
+        s.emit("s_add_u32 %[st0], %[st0], %[eo]")
+    for m in range(MT):
+        so = "%[st0]" if next_tile else "%[eo]"
+        s.vmem(f"buffer_load_dwordx4 %[eo{m}], %[e0], {RNS}, {so} offen" + (f" offset:{64 * m}" if m else ""), ("eo", m))
+
+
 def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False, dma=False):
+    if last and L2E and not first:
+        # issued before the row-pair loads below: in-order completion makes the wait for those a wait for these too.  (The
+        # offsets in the registers now were last read in this tile's FIRST k-step, which is not in this body.)
+        gen_eo_loads(s)
     if last:
         # |x| of this lane's 4*MT rows (rows 4g..4g+3 of every panel) for the admission test
         for j in range(4 * MT):
@@ -500,16 +562,19 @@ def gen_body(s, R, QD, KQ, NW, first, last, nt, prio=False, dma=False):
                     s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{2 * off}" if off else ""), ("rn", j))
                     s.vmem(f"buffer_load_dword %[p{j}], %[rnvoff], {RNS}, 0 offen offset:{2 * off + 4}", ("rn", j))
                 else:
-                    s.vmem(f"buffer_load_dword %[s{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{2 * off}" if off else ""), ("rn", j))
+                    sreg = f"u{j}" if L2E else f"s{j}"
+                    s.vmem(f"buffer_load_dword %[{sreg}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{2 * off}" if off else ""), ("rn", j))
                     s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen offset:{2 * off + 4}", ("rn", j))
                 continue
             s.vmem(f"buffer_load_dword %[r{j}], %[rnvoff], {RNS}, 0 offen" + (f" offset:{off}" if off else ""),
                    ("rn", j))
     for ch in range(R // 2):
+        if last and L2E and first and ch == 1:   # a one-body tile: its own offsets were read in chunk 0's first k-step
+            gen_eo_loads(s)
         gen_chunk(s, R, QD, KQ, NW, 2 * ch, first and ch == 0, last, nt, prio, dma, FUSE and last and ch == R // 2 - 1,
                   sync=not Q4 or ch % 2 == 1, ch=ch)
     if last:
-        s.need_vm(*[("rn", j) for j in range(4 * MT)])
+        s.need_vm(*([("rn", j) for j in range(4 * MT)] + ([("eo", m) for m in range(MT)] if L2E else [])))
 
 
 def body_lines(R, QD, KQ, NW, first, last, nt, prio=False, label0=0, dma=False):
@@ -646,11 +711,11 @@ def gen_hit_stubs(copy=""):
     out = []
     for n in range(NQT):
         out.append(f".Lhit{n}{copy}_%=:")
-        if FUSE and I8_SPACE == "cosine":   # the pre-test let a lane through: the 8 exact bounds of this query tile (gen_admission's arithmetic)
+        if FUSE and (I8_SPACE == "cosine" or L2C):   # the pre-test let a lane through: the 8 exact bounds of this query tile (gen_admission's arithmetic)
             for j in range(4 * MT):
                 out.append(f"v_cvt_f32_i32 %[u{j}], {acc_reg(j >> 2, n, j & 3)}")
-            for j in range(4 * MT):
-                out.append(f"v_fma_f32 %[u{j}], %[u{j}], %[r{j}], %[p{j}]")
+            for j in range(4 * MT):   # (l2c: float(A_j) S SQ + c_j, the pre-test's own arithmetic per row: gen_rowmax_l2c)
+                out.append(f"v_fma_f32 %[u{j}], %[u{j}], " + ("%[e10], %[r" + str(j) + "]" if L2C else f"%[r{j}], %[p{j}]"))
             if EO and MT == 2:
                 # Most calls are false alarms of the pre-test (it tests a row that dominates the lane's 8): one max tree
                 # and one compare send those straight back, instead of through the append routine's 8 compares and 8
@@ -663,14 +728,20 @@ def gen_hit_stubs(copy=""):
             thr, ke, sq = l2ip_consts(n)
             for j in range(4 * MT):
                 out.append(f"v_cvt_f32_i32 %[u{j}], {acc_reg(j >> 2, n, j & 3)}")
+            # (L2E: the pre-test's own arithmetic per row -- A_j = I_j + e_j, the lane's scale S, the lane's P0 -- is an upper
+            # bound of the row's score and is what gets appended: no offset has to be recovered here)
             for j in range(4 * MT):
-                out.append(f"v_mul_f32 %[u{j}], %[u{j}], %[s{j}]")
+                out.append(f"v_mul_f32 %[u{j}], %[u{j}], " + (L2IP_SMAX if L2E else f"%[s{j}]"))
             for j in range(4 * MT):
                 out.append(f"v_fma_f32 %[u{j}], {ke}, %[r{j}], %[u{j}]")
             if I8_SPACE == "l2":
                 for j in range(4 * MT):
-                    out.append(f"v_fma_f32 %[u{j}], {sq}, %[u{j}], %[p{j}]")
-        thr_src = (f"%[tq{n}]" if I8_SPACE == "cosine" else l2ip_consts(n)[0]) if FUSE else f"%[e{n & 1}]"
+                    out.append(f"v_fma_f32 %[u{j}], {sq}, %[u{j}], " + (L2IP_PMAX if L2E else f"%[p{j}]"))
+            if EO and L2E and MT == 2:   # false alarms of the pre-test leave at once (as the cosine stubs do)
+                out += ["v_max3_f32 %[e7], %[u0], %[u1], %[u2]", "v_max3_f32 %[e5], %[u3], %[u4], %[u5]",
+                        "v_max3_f32 %[e7], %[u6], %[u7], %[e7]", "v_max_f32 %[e7], %[e7], %[e5]",
+                        f"v_cmp_ge_f32 vcc, %[e7], {thr}", f"s_cbranch_vccz .Lback{n}{copy}_%="]
+        thr_src = (f"%[tq{n}]" if (I8_SPACE == "cosine" or L2C) else l2ip_consts(n)[0]) if FUSE else f"%[e{n & 1}]"
         out += [f"v_mov_b32 %[e6], {thr_src}",          # the threshold of this query tile
                 f"s_movk_i32 %[sn64], 0x{n * 16:x}",      # first query of this tile
                 f"s_getpc_b64 {RET}",
@@ -816,7 +887,7 @@ def gen_flush(NW):
 
 
 def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False, i8=False, va=False, q4=False, place=None, burst=0, q3d=False,
-             qa=False, eo=False, fs=False, nqt=16):
+             qa=False, eo=False, fs=False, nqt=16, l2e=False, l2c=False):
     """stag: both waves of a SIMD reach the admission test (VALU only) together and leave the MFMA pipe idle for it.
     With the stagger the later-dispatched half of a workgroup's waves (wtype 1) runs half a tile behind: it sits out
     the first nkc/2 chunk periods (staging only), starts every row tile at column ld/2 (k origin rotated by xrot,
@@ -845,7 +916,22 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     # (l2 keeps the serial test after the k-loop: its row term -|x|^2 differs too much between the 8 rows of a lane for the
     # dominating-row pre-test -- measured on 10M x 768: scan 2.002 ms per wave folded against 1.895 for round 1's body,
     # profiles/r02/scan_ab_l2_ip_folded_pretest_tried.txt; "fuse_l2" in DBG regenerates that variant)
-    FUSE = va and "noadm" not in DBG and (space in ("cosine", "ip") or "fuse_l2" in DBG)
+    # l2e (round 4): l2 folded too.  The exact test of row j is  sq (I_j S + ke N_j) + p_j >= thr,  p_j = -(1 - slack) N_j^2; the
+    # dominating-row pre-test with P0 = max_j p_j was loose by the spread of the norms inside a lane (one sigma of the score).
+    # With e_j = ceil((p_j - P0) / (SQ S)) + 1 (SQ = the pass's largest sq; <= 0; filter_l2_offsets_kernel, once per pass)
+    # added to the integer dot product -- the first k-step's MFMAs take the lane's e_j as their C operand instead of 0 --
+    #   u'_j = sq ((I_j + e_j) S + ke N_j) + P0  >=  sq (I_j S + ke N_j) + p_j      for every query of the pass (sq <= SQ),
+    # an upper bound of the row's score that differs from the exact test's by ~two quanta sq S; it is what the pre-test
+    # dominates (one scale S per lane: the shadow builder groups l2 rows like ip's) and what the stubs append.
+    # l2c: l2e where the prep quantises every query of the pass with one step, so that sq = SQ for all of them, and one
+    # error coefficient KE = max_q 2 |q| ke_q stands for every query's: u'_j = float(I_j + e_j) (S SQ) + (KE N_j + P0).  The
+    # per-query constants shrink to the threshold, kept in registers for the launch like cosine's; S SQ and KE N_j + P0 are
+    # formed once per row tile (gen_rowmax_l2c).  SQ, KE: scalars of the pass (filter_l2_offsets_kernel).
+    global L2E, L2C
+    L2C = bool(l2c)
+    L2E = bool(l2e) or L2C
+    assert not L2E or (space == "l2" and va and R == 4)
+    FUSE = va and "noadm" not in DBG and (space in ("cosine", "ip") or "fuse_l2" in DBG or L2E)
     # q4: four 32 KiB Q buffers (128 KiB), chunk c + 2 is staged while chunk c is consumed, and the workgroup meets at
     # ONE barrier per two chunks (after the odd ones) instead of one per chunk: half the parking, half the refills of
     # the software pipeline.  Needs the DMA staging and a ring of 4 k-steps (one loop body = one pair of chunks).
@@ -890,7 +976,11 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     a("s_mov_b32 s87, s83")
     a("s_mov_b32 s88, %[rnlo]")
     a("s_mov_b32 s89, %[rnhi]")
-    a(f"s_movk_i32 s90, 0x{16 * MT * (8 if i8 else 4):x}")   # this wave's rows x 4 B (int8 shadow: pairs)
+    if L2E:   # the offsets are read through the same descriptor, 8 x capacity bytes further on: no range to check against
+        a("s_mov_b32 s90, -1")
+        a("s_mov_b32 %[eo], %[eo0in]")
+    else:
+        a(f"s_movk_i32 s90, 0x{16 * MT * (8 if i8 else 4):x}")   # this wave's rows x 4 B (int8 shadow: pairs)
     a("s_mov_b32 s91, s83")
     a("s_mov_b32 %[tl], %[ntiles]")
     a("s_mov_b32 %[trow], %[row0]")
@@ -949,6 +1039,10 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
                 a(f"s_movk_i32 %[st0], 0x{b * 1024:x}" if m == 0 else
                   f"s_add_u32 %[st0], {'%[pb]' if m == 1 else '%[st0]'}, 0x{b * 1024:x}")
                 a(f"buffer_load_dwordx4 {ring(b, m)}, %[lane16], {XCUR}, %[st0] offen")
+    if L2E:   # the first tile's offsets (every later tile's are fetched a tile ahead: gen_eo_loads)
+        a("v_lshrrev_b32 %[e0], 1, %[rnvoff]")
+        for m in range(MT):
+            a(f"buffer_load_dwordx4 %[eo{m}], %[e0], {RNS}, %[eo] offen" + (f" offset:{64 * m}" if m else ""))
     a("s_waitcnt vmcnt(0)")
     if not dma:
         for const, setname, i in pieces:
@@ -958,7 +1052,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
             a(f"buffer_load_dwordx4 %[{setname}{i}], %[qvoff], %[qsrd], %[st0] offen")
     a("s_waitcnt vmcnt(0) lgkmcnt(0)")   # counted waits below assume the steady-state issue pattern
     a("s_barrier")
-    if FUSE and space == "cosine":   # the thresholds of this lane's query column in the 16 query tiles: constant for the whole launch
+    if FUSE and (space == "cosine" or L2C):   # the thresholds of this lane's query column in the 16 query tiles: constant for the whole launch
         for n in range(NQT):
             a(f"ds_read_b32 %[tq{n}], %[thra]" + (f" offset:{n * 64}" if n else ""))
         a("s_waitcnt lgkmcnt(0)")
@@ -1015,6 +1109,9 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     a("s_mov_b32 s81, s85")
     a("s_add_u32 s88, s88, %[rnstride]")
     a("s_addc_u32 s89, s89, 0")
+    if L2E:   # the pairs' base moved on by 8 bytes per row, the offsets' by 4: the distance shrinks by the difference
+        a("s_lshr_b32 %[st0], %[rnstride], 1")
+        a("s_sub_u32 %[eo], %[eo], %[st0]")
     a("s_add_u32 %[trow], %[trow], %[rowstride]")
     a("s_sub_u32 %[tl], %[tl], 1")
     a("s_cmp_lg_u32 %[tl], 0")
@@ -1064,18 +1161,22 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
         ops_out.append(f'[t{i}] "=&{opc}"(qt[{i}])')
     for j in range(4 * MT):
         ops_out.append(f'[r{j}] "=&v"(vr[{j}])')
-    if space == "l2" or (i8 and space == "cosine"):
+    if (space == "l2" and not L2C) or (i8 and space == "cosine"):
         for j in range(4 * MT):
             ops_out.append(f'[p{j}] "=&v"(vp[{j}])')
-    if i8 and space != "cosine":
+    if i8 and space != "cosine" and not L2E:
         for j in range(4 * MT):
             ops_out.append(f'[s{j}] "=&v"(vs[{j}])')
+    if L2E:
+        for m in range(MT):
+            ops_out.append(f'[eo{m}] "=&v"(veo[{m}])')
+        ops_out.append('[eo] "=&s"(s_eo)')
     for j in range(4 * MT):
         ops_out.append(f'[u{j}] "=&v"(vu[{j}])')
     for j in range(13):
         ops_out.append(f'[e{j}] "=&v"(ve[{j}])')
     if FUSE:
-        for n in range(NQT if space == "cosine" else L2IP_TQ):
+        for n in range(NQT if (space == "cosine" or L2C) else L2IP_TQ):
             ops_out.append(f'[tq{n}] "=&v"(vt[{n}])')
     ops_out += ['[ldr] "=&v"(ldr)'] + (['[sldw] "=&s"(s_sldw)'] if dma else ['[ldw] "=&v"(ldw)'])
     for name in [f"xso{m}" for m in range(MT)] + ["qcur", "cnt", "st0", "tl", "trow", "sn64", "wcnt", "sacc0", "sacc1"]:
@@ -1088,10 +1189,14 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
                '[pb] "s"(pb)', '[qbytes] "s"(qbytes)', '[nb] "s"(nb)', '[qcur0] "s"(qcur0)', '[qc1] "s"(qc1)',
                '[wtype] "s"(wtype)', '[wgbu] "s"(wgbu)', '[wgbr] "s"(wgbr)', '[wgbq] "s"(wgbq)', '[wgcp] "s"(wgcp)',
                '[ovfb] "s"(ovfb)']
-    if space == "l2" or (i8 and space == "cosine"):
+    if (space == "l2" and not L2C) or (i8 and space == "cosine"):
         ops_in.append('[k1] "s"(k1)')
+    if L2C:
+        ops_in += ['[sqc] "s"(sqc)', '[kec] "s"(kec)']
     if dma:
         ops_in.append('[wave2k] "s"(wave2k)')
+    if L2E:
+        ops_in.append('[eo0in] "s"(eo0)')
     if stag:
         ops_in += ['[xrot] "s"(xrot)', '[pbrot] "s"(pbrot)', '[pb2] "s"(pb2)', '[hc] "s"(hc)']
     clobbers = ['"memory"', '"scc"', '"vcc"'] + (['"m0"'] if dma else []) + [f'"s{i}"' for i in range(60, 80)] + [f'"s{i}"' for i in range(80, 94)] + (
@@ -1152,6 +1257,16 @@ def entries():
         for code, nqt in ((241, 8), (242, 4)):
             E.append((f"scan_asm_{sp}_i8_va_nqt{nqt}.inc", cond(sp, 8, 4, True, code, True, 2, True, False),
                       (lambda sp=sp, nqt=nqt: with_dbg((), sp, 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True, nqt=nqt)), "default"))
+    # 246 / 247 / 248 (round 4): l2 with the admission test folded into the last k-step (per-row integer offsets through the
+    # first k-step's C operand), for 16 / 8 / 4 query tiles.  The l2 body of slot 211 (serial test) stays: indexes whose row
+    # pairs + offsets would not fit one buffer descriptor use it, and it is the A/B reference
+    for code, nqt in ((246, 16), (247, 8), (248, 4)):
+        E.append((f"scan_asm_l2_i8_va_e_nqt{nqt}.inc", cond("l2", 8, 4, True, code, True, 2, True, False),
+                  (lambda nqt=nqt: with_dbg((), "l2", 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True, nqt=nqt, l2e=True)), "default"))
+    # 243 / 244 / 245 (round 4): l2c -- l2e with one query scale and one error coefficient per pass (cosine's one-constant test)
+    for code, nqt in ((243, 16), (244, 8), (245, 4)):
+        E.append((f"scan_asm_l2_i8_va_c_nqt{nqt}.inc", cond("l2", 8, 4, True, code, True, 2, True, False),
+                  (lambda nqt=nqt: with_dbg((), "l2", 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True, nqt=nqt, l2c=True)), "default"))
     # 237: round 2's default body (append routine with eight skipped row blocks, stubs without the early out): the A/B reference
     E.append(("scan_asm_cosine_i8_va_r2.inc", cond("cosine", 8, 4, True, 237, True, 2, True, False),
               lambda: with_dbg((), "cosine", 4, 4, 8, True, True, 2, True, False, True, True), "default"))
