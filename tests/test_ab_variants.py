@@ -53,3 +53,42 @@ def test_ab_scan_variants_agree_with_oracle(variant, space, d, monkeypatch):
         eng.close()
     assert stats["strategy_used"] == 2 and stats["fallback_queries"] == 0
     assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"ab variant {variant}/{space}/d{d}")
+
+
+SMALL_KNOBS = [
+    {"MLVDB_SMALL_SEED": "0"},          # dense int8 seeding pass + refine, fused finish
+    {"MLVDB_SMALL_FINISH": "0"},        # prefix seed, the three finishing kernels
+    {"MLVDB_SMALL_NQ": "0"},            # round 2's structure
+    {"MLVDB_SMALL_NQ": "8"},            # both steps for up to 8 queries
+    {"MLVDB_NARROW_I8_MAX": "8"},       # the int8 narrow kernel (round 3's scan for 1-8 queries) instead of the 4-tile assembly body
+    {"MLVDB_SCAN_NQT": "16"},           # every pass padded to 16 query tiles (round 3)
+    {"MLVDB_SCAN_L2C": "0"},            # l2: per-query scales, per-row offsets only (l2e)
+    {"MLVDB_SCAN_L2E": "0"},            # l2: the serial admission test (round 3's body)
+]
+SMALL_CASES = [
+    ("cosine", 768, 1, 70_003, 10, 0.05), ("cosine", 768, 2, 70_003, 10, 0.05), ("l2", 768, 1, 40_001, 10, 0.3),
+    ("ip", 256, 2, 150_001, 1, 0.0), ("l2", 1536, 1, 33_001, 64, 0.05), ("cosine", 256, 1, 150_001, 33, 0.9),
+    ("ip", 768, 1, 3_000, 10, 0.05), ("l2", 256, 2, 9_000, 64, 0.995), ("cosine", 768, 5, 70_003, 10, 0.05), ("l2", 768, 40, 40_001, 10, 0.05),
+]
+
+
+@pytest.mark.parametrize("knobs", SMALL_KNOBS, ids=lambda v: ",".join(f"{k[6:]}={x}" for k, x in v.items()))
+@pytest.mark.parametrize("space,d,nq,n,k,frac", SMALL_CASES)
+def test_alternative_small_batch_and_l2_paths_agree_with_oracle(space, d, nq, n, k, frac, knobs, monkeypatch):
+    from mlvectordb_amd.engine import HipScanEngine
+
+    for key, val in knobs.items():
+        monkeypatch.setenv(key, val)
+    rows, qs = make_case(900 + d + nq + k, n, d, nq, dup=True)
+    deleted = deleted_mask(13, n, frac)
+    eng = HipScanEngine(d, space, device=0, strategy="filter")
+    try:
+        for part in (rows[: n // 2], rows[n // 2:]):
+            eng.append(part)
+        eng.tombstone(deleted.nonzero()[0])
+        got = eng.search(qs, k)
+        stats = eng.last_stats()
+    finally:
+        eng.close()
+    assert stats["strategy_used"] == 2 and stats["fallback_queries"] == 0 and stats["bound_dtype"] == 2
+    assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"alt {knobs}/{space}/d{d}/nq{nq}/k{k}")

@@ -446,8 +446,7 @@ NARROW_CASES = [
 ]
 
 
-@pytest.mark.parametrize("narrow", ["1", "0"])
-@pytest.mark.parametrize("space,d,nq,n", NARROW_CASES)
+@pytest.mark.parametrize("space,d,nq,n,narrow", [c + (nw,) for c in NARROW_CASES for nw in (("1", "0") if c[1] in (64, 128) else ("1",))])
 def test_small_batches_through_the_filter_agree_with_oracle(space, d, nq, n, narrow, monkeypatch):
     """Batches of 1..64 queries forced through the filter: the narrow kernel (MLVDB_SCAN_NARROW=1, default) and the
     same batch padded into a 256-query pass (=0) return the oracle's ids; ragged tiles, tombstones, duplicates."""
@@ -460,12 +459,12 @@ def test_small_batches_through_the_filter_agree_with_oracle(space, d, nq, n, nar
 
 
 @pytest.mark.parametrize("space", ["cosine", "l2", "ip"])
-@pytest.mark.parametrize("nq", [9, 33, 64, 65, 100, 128, 129])
+@pytest.mark.parametrize("nq", [9, 64, 65, 128, 129])
 def test_passes_of_9_to_128_queries_compute_only_their_query_tiles(space, nq):
     """a pass of <= 64 / <= 128 queries runs the int8 body generated for 4 / 8 of the 16 query tiles (no MFMAs,
     B reads, Q transfers or admission tests for the empty ones).  Same ids as the oracle and as the padded 16-tile body
     (SCAN_NQT=16); ragged tiles, tombstones, duplicates, appends in pieces."""
-    d, n = 768, 70_003
+    d, n = 768, (70_003 if space != "l2" else 30_001)  # (l2: the NumPy oracle is element-wise, not a GEMM)
     rows, qs = make_case(2100 + nq, n, d, nq, dup=True)
     deleted = deleted_mask(31, n, 0.05)
     eng = HipScanEngine(d, space, device=0, strategy="filter")
@@ -498,12 +497,10 @@ def test_wide_rows_through_the_filter_agree_with_oracle(space, d, nq):
     assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"wide/{space}/d{d}/nq{nq}")
 
 
+# (the default structure only: each step switched off in turn -- SMALL_SEED=0, SMALL_FINISH=0, SMALL_NQ=0 / 8 -- is in
+# tests/test_ab_variants.py, marked `ab`: alternative paths, not live ones)
 SMALL_KNOBS = [
     {},                                 # round 3's default for 1-2 queries: exact prefix seed + fused last refine / rescoring / ranking
-    {"MLVDB_SMALL_SEED": "0"},          # dense int8 seeding pass + refine, fused finish
-    {"MLVDB_SMALL_FINISH": "0"},        # prefix seed, the three finishing kernels
-    {"MLVDB_SMALL_NQ": "0"},            # round 2's structure
-    {"MLVDB_SMALL_NQ": "8"},            # both steps for up to 8 queries
 ]
 SMALL_CASES = [
     # space, d, nq, n, k, deleted_frac  (d % 256 == 0: the int8 shadow, which the small-batch steps need)
@@ -547,8 +544,12 @@ def test_one_query_among_thousands_of_equal_rows(copies, expect_fallback):
     assert np.array_equal(got[0][0], np.sort(where)[:k])
 
 
-@pytest.mark.parametrize("variant", SCAN_VARIANTS, ids=lambda v: ",".join(f"{k[6:]}={x}" for k, x in v.items()) or "default")
-@pytest.mark.parametrize("space,d", [("cosine", 128), ("l2", 192), ("ip", 64), ("cosine", 768), ("l2", 1536), ("ip", 768), ("l2", 256)])
+VARIANT_SHAPES = [("cosine", 128), ("l2", 192), ("ip", 64), ("cosine", 768), ("l2", 1536), ("ip", 768), ("l2", 256)]
+
+
+@pytest.mark.parametrize("variant,space,d", [(v, sp, d) for i, v in enumerate(SCAN_VARIANTS)
+                                             for j, (sp, d) in enumerate(VARIANT_SHAPES) if i == 0 or (i + j) % 2 == 0],
+                         ids=lambda v: (",".join(f"{k[6:]}={x}" for k, x in v.items()) or "default") if isinstance(v, dict) else str(v))
 def test_scan_kernel_variants_agree_with_oracle(variant, space, d, monkeypatch):
     """Every generated geometry of the filter scan (the variable is read per launch), on corpora with more
     tiles than resident workgroups (persistent tile loop, prefetch across tile boundaries), ragged last

@@ -14,7 +14,7 @@ if [ "$1" = "--ab" ]; then
     export MLVDB_HIP_LIBRARY=$PWD/mlvectordb_amd/csrc/libmlvdb_hip_ab.so
     sel="ab"
 fi
-timeout -k 10 ${GPU_SUITE_TIMEOUT:-900} python -X faulthandler -m pytest tests -m "$sel" ${GPU_SUITE_X--x} -q --durations=25 "$@" > "$out/pytest.log" 2> "$out/pytest.err"
+timeout -k 10 ${GPU_SUITE_TIMEOUT:-900} python -X faulthandler -m pytest tests -m "$sel" ${GPU_SUITE_X--x} -q --durations=60 "$@" > "$out/pytest.log" 2> "$out/pytest.err"
 rc=$?
 echo "pytest rc=$rc" >> "$out/pytest.log"
 tail -5 "$out/pytest.log"
