@@ -429,13 +429,14 @@ int update_i8_shadow(mlvdb_index* h, hipStream_t s) {
     if (h->x8.bytes < need_x8 || h->rp8.bytes < need_rp || !h->rowerr8.p) {
         HIP_TRY(h, h->x8.ensure(need_x8));
         HIP_TRY(h, h->rp8.ensure(need_rp));
-        HIP_TRY(h, h->rowerr8.ensure(sizeof(float)));
+        HIP_TRY(h, h->rowerr8.ensure(2 * sizeof(float)));  // {largest relative row error, smallest row norm}
         h->i8_rows = 0;
     }
     if (h->i8_rows == 0) {
         HIP_TRY(h, hipMemsetAsync(h->x8.p, 0, need_x8, s));
         HIP_TRY(h, hipMemsetAsync(h->rp8.p, 0xff, need_rp, s));  // NaN: not a row
         HIP_TRY(h, hipMemsetAsync(h->rowerr8.p, 0, sizeof(float), s));
+        HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->rowerr8.as<float>() + 1), 0x7f800000, 1, s));  // +inf
     }
     if (h->i8_rows < h->total) {
         HIP_TRY(h, launch_shadow8_rows(h->X, h->rn, h->x8.p, h->rp8.as<float>(), h->rowerr8.as<float>(), h->i8_rows, h->total,

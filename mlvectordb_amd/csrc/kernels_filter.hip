@@ -617,6 +617,20 @@ constexpr bool scan_code_i8(int qd) { return qd >= 208 && qd <= 249; }
 constexpr int scan_code_nqt(int qd) { return (qd == 241 || qd == 247 || qd == 244) ? 8 : ((qd == 242 || qd == 248 || qd == 245) ? 4 : 16); }
 // 246 / 247 / 248 (round 4): l2 with the folded admission test, per-row integer offsets through the first k-step's C operand
 constexpr bool scan_code_l2e(int qd) { return qd >= 243 && qd <= 248; }  // 243-245: l2c (+ one query scale, one error coefficient per pass)
+constexpr bool scan_code_l2c(int qd) { return qd >= 243 && qd <= 245; }
+
+// l2c: what the pass's common error coefficient KE = max_q KE_q costs query q, taken back.  The body's bound of row j is
+//   u'_j = (per-query bound with q's own KE_q) + (KE - KE_q) N_j   and   N_j >= Nmin  (the smallest row norm the index ever held),
+// so testing  u'_j >= thr_q + delta_q  with delta_q = (KE - KE_q) Nmin (rounded down) admits every row the per-query bound
+// admits, and  u'_j - delta_q  (rounded up) is still an upper bound of the row's score: the thresholds the body sees are
+// raised by delta_q (the wrapper's preamble), the appended bounds lowered by it (its tail).  KE_q: the offsets kernel's formula.
+__device__ __forceinline__ float l2c_delta(const FilterArgs& a, int q) {
+    const double keq = (double)float_above((double)a.qscale[q] * ((double)a.ke[q] * 1.000002 + 1.0e-6));
+    const double nmin = (double)a.row_err8[1];
+    const double d = ((double)a.l2c_out[1] - keq) * nmin * 0.999999;
+    if (!(d > 0.0) || !(nmin < 3.0e38)) return 0.f;
+    return float_below(d);
+}
 constexpr int scan_code_qd(int qd) { return qd == 215 ? 8 : (qd > 8 ? 4 : qd); }
 constexpr bool scan_code_q4(int qd) { return qd == 219 || qd == 229 || qd == 231 || qd == 233; }  // four Q chunk buffers
 constexpr int scan_code_qbufs(int qd) { return scan_code_q4(qd) ? 4 : 2; }
@@ -673,6 +687,8 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
             } else {  // l2: sq' (w + ke' |x|) + p1 >= thr with sq' = 2|q| sq8
                 kev = float_above((double)kev / sq8);
                 sqv = sqv * a.sq8[t];
+                if (scan_code_l2c(QD) && t < a.nq && thr > -1.0e30f && thr < 1.0e30f)
+                    thr = float_below((double)thr + (double)l2c_delta(a, t));  // (see l2c_delta)
             }
         }
         thr_l[t] = thr;
@@ -861,6 +877,7 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
                     CandEntry e;
                     // int8 scan: the stored value is in units of the query's scale (cosine: w, ip: w + ke' |x|)
                     e.u = kI8Mode == 1 ? __builtin_fmaf(u, a.sq8[q], a.ke8[q]) : (kI8Mode == 2 ? u * a.sq8[q] : u);
+                    if (scan_code_l2c(QD)) e.u = float_above((double)u - (double)l2c_delta(a, (int)q));
                     e.row = row;
                     a.cand[(size_t)q * a.cand_cap + slot] = e;
                 }
@@ -1647,6 +1664,7 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
                 rel = __uint_as_float(__float_as_uint(rel) + 1u);
                 atomicMax(row_err8, __float_as_uint(rel));  // non-negative floats order like their bits
             }
+            if (nrm[p] == nrm[p]) atomicMin(row_err8 + 1, __float_as_uint(nrm[p]));  // smallest norm of a row ever held (l2c_delta)
             // per-row pair: cosine {sx/(|x|+1e-30), this row's error}, l2 / ip {sx, |x|}; NaN marks a tombstone
             float2 pr;
             if (space == kSpaceCosine) pr = make_float2(sx / (nrm[p] + 1e-30f), nrm[p] == nrm[p] ? rel : nrm[p]);

@@ -14,8 +14,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=60)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--max-rows", type=int, default=200_000)
-ap.add_argument("--batches", default="1,3,8,9,40,256,300", help="batch sizes drawn from")
-ap.add_argument("--dims", default="256,512,768,1024,320,128", help="dimensions drawn from")
+ap.add_argument("--batches", default="1,3,8,9,40,70,130,256,300", help="batch sizes drawn from")
+ap.add_argument("--dims", default="256,512,768,1024,320,128,100,300,384,1000", help="dimensions drawn from (round 4: any dim >= 64 runs the int8 body on a zero-padded shadow)")
+ap.add_argument("--ks", default="1,5,10,64,100,300", help="top_k drawn from (round 4: > 64 = big-k passes)")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 
@@ -48,8 +49,9 @@ for case in range(args.cases):
     kind, qkind = KINDS[rng.integers(len(KINDS))], KINDS[rng.integers(len(KINDS))]
     d = int(rng.choice([int(x) for x in args.dims.split(",")]))
     n = int(rng.integers(20_000, args.max_rows))
+    n = max(n, 2 * 300)
     nq = int(rng.choice([int(x) for x in args.batches.split(",")]))
-    k = int(rng.choice([1, 5, 10, 64]))
+    k = int(rng.choice([int(x) for x in args.ks.split(",")]))
     space = str(rng.choice(["cosine", "l2", "ip"]))
     rows = draw(kind, n, d)
     qs = draw(qkind, nq, d)
