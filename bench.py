@@ -500,7 +500,7 @@ def main() -> None:
     # N = 1 times the K steps twice, each region bracketed by barrier + synchronize: once with the waves enqueued back to back
     # (the host never waits inside the region) and once with the host synchronising after every wave, as a caller that consumes
     # each wave's answer does.  The synchronised loop is the FASTER one on this hardware -- the ~30 us the GPU idles between waves
-    # let its clock recover, the MFMA-heavy scan then runs 5-6 % shorter (DESIGN.md 5) -- and it is the line's `ms_per_step` /
+    # let its clock recover, the MFMA-heavy scan then runs 5-6 % shorter (DESIGN.md 6) -- and it is the line's `ms_per_step` /
     # `value` (--wave-mode back_to_back swaps the two); the other region's figure stays beside it, scan-kernel events included.
     host_enqueue_s = None
     other = None
@@ -603,7 +603,7 @@ def main() -> None:
         scan_s = scan_ms * 1e-3
         filt = stats0["strategy_used"] == 2
         i8 = filt and stats0.get("bound_dtype") == 2  # the int8 shadow computed the bounds (dim % 256 == 0)
-        # Two physical floors of the scan kernel as built (DESIGN 5): the matrix-core time of 2*rows*d*256 multiply-adds
+        # Two physical floors of the scan kernel as built (DESIGN.md 6): the matrix-core time of 2*rows*d*256 multiply-adds
         # at the dense peak of the operand type, and the HBM time of the bytes the kernel has to move -- the shadow it
         # streams (1 B / 2 B per element) + 8 B / 4 B of row constants per row + the query image.  The roof that binds
         # is the slower floor; `frac` = that floor / measured time (<= 1 by construction).  SURVEY 8d's accounting (the

@@ -2786,11 +2786,13 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
                     if (nqt <= 8 && a.nq <= 128) return launch_scan_asm<SPACE, 4, 8, true, 244, true, 2, true>(a, row_begin, row_end, s, info);
                     return launch_scan_asm<SPACE, 4, 8, true, 243, true, 2, true>(a, row_begin, row_end, s, info);
                 }
+#ifdef MLVDB_AB  // l2e: offsets with per-query scales (SCAN_L2C=0); the default library goes on to the serial-test body instead
                 if (a.rp8_cap > 0 && tn.scan_l2e) {
                     if (nqt <= 4 && a.nq <= 64) return launch_scan_asm<SPACE, 4, 8, true, 248, true, 2, true>(a, row_begin, row_end, s, info);
                     if (nqt <= 8 && a.nq <= 128) return launch_scan_asm<SPACE, 4, 8, true, 247, true, 2, true>(a, row_begin, row_end, s, info);
                     return launch_scan_asm<SPACE, 4, 8, true, 246, true, 2, true>(a, row_begin, row_end, s, info);
                 }
+#endif
             }
             if (nqt <= 4 && a.nq <= 64) return launch_scan_asm<SPACE, 4, 8, true, 242, true, 2, true>(a, row_begin, row_end, s, info);
             if (nqt <= 8 && a.nq <= 128) return launch_scan_asm<SPACE, 4, 8, true, 241, true, 2, true>(a, row_begin, row_end, s, info);

@@ -1258,11 +1258,12 @@ def entries():
             E.append((f"scan_asm_{sp}_i8_va_nqt{nqt}.inc", cond(sp, 8, 4, True, code, True, 2, True, False),
                       (lambda sp=sp, nqt=nqt: with_dbg((), sp, 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True, nqt=nqt)), "default"))
     # 246 / 247 / 248 (round 4): l2 with the admission test folded into the last k-step (per-row integer offsets through the
-    # first k-step's C operand), for 16 / 8 / 4 query tiles.  The l2 body of slot 211 (serial test) stays: indexes whose row
-    # pairs + offsets would not fit one buffer descriptor use it, and it is the A/B reference
+    # first k-step's C operand), per-query scales: the step before l2c (243-245), kept as an AB variant (SCAN_L2C=0).  The l2
+    # body of slot 211 (serial test) stays in the default library: indexes whose row pairs + offsets would not fit one
+    # buffer descriptor use it, and it is the A/B reference
     for code, nqt in ((246, 16), (247, 8), (248, 4)):
         E.append((f"scan_asm_l2_i8_va_e_nqt{nqt}.inc", cond("l2", 8, 4, True, code, True, 2, True, False),
-                  (lambda nqt=nqt: with_dbg((), "l2", 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True, nqt=nqt, l2e=True)), "default"))
+                  (lambda nqt=nqt: with_dbg((), "l2", 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True, nqt=nqt, l2e=True)), "ab"))
     # 243 / 244 / 245 (round 4): l2c -- l2e with one query scale and one error coefficient per pass (cosine's one-constant test)
     for code, nqt in ((243, 16), (244, 8), (245, 4)):
         E.append((f"scan_asm_l2_i8_va_c_nqt{nqt}.inc", cond("l2", 8, 4, True, code, True, 2, True, False),
