@@ -192,7 +192,8 @@ __global__ __launch_bounds__(kMidWaves * 64) void mid_score_flat_kernel(const Fi
         const int32_t row = have ? (int32_t)((uint32_t)e.row & ~kRefinedBit) : 0;
         const uint4* rp = reinterpret_cast<const uint4*>(m.X16 + (int64_t)row * ld16) + l8;
         double acc = 0.0;
-        constexpr int G = 6;  // pieces in flight per lane (d = 768: 12 pieces in two rounds)
+        constexpr int G = 12;  // pieces in flight per lane: a whole 768-column row in one round trip (the gather is a chain of
+                               // dependent round trips per wave, each a page walk per random row: 6 in flight made it two chains)
         for (int s0 = 0; s0 < nsteps; s0 += G) {
             uint4 v[G];
 #pragma unroll

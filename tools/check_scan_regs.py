@@ -22,6 +22,8 @@ LLVM = Path("/opt/rocm/lib/llvm/bin")
 # default library dispatches to (kernels_filter.hip, launch_scan_space)
 VA_CODES = {211, 237} | set(range(214, 223)) | {228, 229, 231, 232, 233, 235, 236} | set(range(241, 250))
 WANT = {".vgpr_count": 240, ".vgpr_spill_count": 0, ".private_segment_fixed_size": 0}
+# AB variants that use all 64 AccVGPRs (ring of 6 k-steps, or B fragments read 8 ahead): 192 + 64 registers
+WIDE_CODES = {214, 215, 228, 229}
 
 
 def kernel_records(obj: Path):
@@ -53,6 +55,8 @@ def main(argv):
             continue
         checked += 1
         for key, want in WANT.items():
+            if key == ".vgpr_count" and int(m.group(4)) in WIDE_CODES:
+                want = 256
             if f.get(key) != want:
                 bad.append(f"{name}: {key} = {f.get(key)} (want {want})")
     if checked < 3:
