@@ -410,9 +410,13 @@ int collect_overflow(mlvdb_index* h, hipStream_t s, const FilterArgs& fa, int32_
 // int8 shadow of a cosine index (kernels_filter.hip, "int8 shadow"): kept current lazily -- rows appended since the
 // last pass are converted here, tombstones are patched in by mlvdb_index_tombstone, compaction / reset / regrowth
 // start it over.  MLVDB_I8=0 keeps the pass on the bf16 shadow.
-__global__ void tombstone_rp8_kernel(const int64_t* labels, int64_t n, float* rp8, int64_t rows) {
+// (l2: only the |x| slot -- the x-slot of an l2 pair holds its group's scale or error and must survive the row: shadow8_rows_kernel)
+__global__ void tombstone_rp8_kernel(const int64_t* labels, int64_t n, float* rp8, int64_t rows, int l2) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && labels[i] >= 0 && labels[i] < rows) rp8[2 * labels[i]] = rp8[2 * labels[i] + 1] = __builtin_nanf("");
+    if (i < n && labels[i] >= 0 && labels[i] < rows) {
+        rp8[2 * labels[i] + 1] = __builtin_nanf("");
+        if (!l2) rp8[2 * labels[i]] = __builtin_nanf("");
+    }
 }
 
 bool i8_bounds_usable(const mlvdb_index* h);
@@ -465,8 +469,8 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
     fa.X8 = h->x8.p;
     fa.rp8 = h->mask_active ? h->rp8_masked.as<float>() : h->rp8.as<float>();  // a masked-out row is a NaN pair: "not a row"
     // l2: pairs + offsets through one buffer descriptor (32-bit offsets): 12 bytes per row must stay below 4 GB
-    fa.rp8_cap = h->space == kSpaceL2 && h->tn.scan_l2e && (uint64_t)h->capacity * 12ull < 0xfff00000ull ? h->capacity : 0;
-    if (fa.rp8_cap > 0 && h->tn.scan_l2c) fa.l2c = 2 + (int32_t)((h->l2c_passes++) & 1);
+    fa.rp8_cap = h->space == kSpaceL2 ? h->capacity : 0;  // (l2_int8_ok held: i8_bounds_usable)
+    if (fa.rp8_cap > 0) fa.l2c = 2 + (int32_t)((h->l2c_passes++) & 1);
     fa.row_err8 = h->rowerr8.as<float>();
     fa.qimg8 = h->qimg8.p;
     fa.sq8 = h->sq8.as<float>();
@@ -993,7 +997,12 @@ __global__ void range_resolve_kernel(uint32_t* overflow, const uint32_t* cnt, co
     overflow[q] = cnt[q] > cap ? 1u : 0u;
 }
 
-bool i8_bounds_usable(const mlvdb_index* h) { return h->i8_err <= (h->space == kSpaceCosine ? 0.5f : 0.03f); }
+// (l2: the int8 bodies are the l2c ones -- folded test, per-row integer offsets read through the row pairs' descriptor, which needs
+// pairs + offsets, 12 bytes per row, below 4 GB; SCAN_L2C=0 / SCAN_L2E=0 take l2 off the int8 shadow: bf16 / fp32 / exact paths)
+bool l2_int8_ok(const mlvdb_index* h) {
+    return h->space != kSpaceL2 || (h->tn.scan_l2e && h->tn.scan_l2c && (uint64_t)h->capacity * 12ull < 0xfff00000ull);
+}
+bool i8_bounds_usable(const mlvdb_index* h) { return h->i8_err <= (h->space == kSpaceCosine ? 0.5f : 0.03f) && l2_int8_ok(h); }
 
 // Is a filter body available for this index right now?  ld % 64 == 0: always (bf16 shadow, int8 shadow, or the fp32 rows
 // converted in registers).  Any other ld has only the int8 body: the (zero-padded) int8 shadow is brought up to date here
@@ -1227,7 +1236,7 @@ int mlvdb_index_tombstone(mlvdb_index* h, const int64_t* labels, int64_t n, int6
                                 h->stream));
     if (h->rp8.p && h->i8_rows > 0) {  // the int8 shadow's row constants carry the tombstones too (before the sync below:
                                        // a search on another stream may follow this call at once)
-        tombstone_rp8_kernel<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(h->labels_in.as<int64_t>(), n, h->rp8.as<float>(), h->i8_rows);
+        tombstone_rp8_kernel<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(h->labels_in.as<int64_t>(), n, h->rp8.as<float>(), h->i8_rows, h->space == kSpaceL2 ? 1 : 0);
         HIP_TRY(h, hipGetLastError());
     }
     unsigned long long changed = 0;
@@ -1570,7 +1579,7 @@ int mlvdb_search_batch_ex(mlvdb_index* h, const float* queries, int64_t nq, int3
         if (rc) return rc;
         HIP_TRY(h, h->rp8_masked.ensure((size_t)h->capacity * (h->space == kSpaceL2 ? 3 : 2) * sizeof(float)));
         HIP_TRY(h, launch_mask_pairs(h->rp8.as<float>(), h->row_mask.as<uint8_t>(), h->rp8_masked.as<float>(), h->total,
-                                     h->capacity, h->stream));
+                                     h->capacity, h->space == kSpaceL2 ? 1 : 0, h->stream));
         h->mask_pairs_ready = true;
     }
     float* const all_rows = h->rn;  // every kernel of the call reads the masked norms instead

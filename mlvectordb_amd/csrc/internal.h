@@ -118,7 +118,8 @@ hipError_t launch_compact_rows(const float* X, float* nX, const void* Xb, void* 
 // out[i] = mask[i] ? rn[i] : NaN (i < total), NaN up to capacity: a masked-out row looks tombstoned to every scan
 hipError_t launch_mask_norms(const float* rn, const uint8_t* mask, float* out, int64_t total, int64_t capacity, hipStream_t s);
 // the same for the int8 shadow's row pairs [rows][2]
-hipError_t launch_mask_pairs(const float* rp8, const uint8_t* mask, float* out, int64_t total, int64_t capacity, hipStream_t s);
+hipError_t launch_mask_pairs(const float* rp8, const uint8_t* mask, float* out, int64_t total, int64_t capacity, int l2,
+                             hipStream_t s);
 // Qpad[q][0..ld) = queries[q][0..dim) zero padded; qaux[q] = 1/(|q|+1e-30) (cosine) or |q| (l2, ip)
 // qerr (optional): |q^ - bf16 image of q^| per query, rounded up
 hipError_t launch_query_prep(const float* queries, int32_t nq, int32_t dim, int32_t ld, int32_t space, float* Qpad,
@@ -231,7 +232,7 @@ struct FilterArgs {
     int64_t rp8_cap;        // l2: rows the rp8 array was allocated for; behind its pairs (float index 2 * rp8_cap) lies the plane of
                             // per-row int32 offsets of the folded l2 admission test (filter_l2_offsets_kernel).  0 = none
     int32_t l2c;            // l2, common query scale for the pass: 0 = off, else 2 + (parity of the pass: which of sqmin[2..3] holds its QMAX)
-    float* l2c_out;         // l2: {SQ, KE} of the pass, written by filter_l2_offsets_kernel, read by the l2c scan bodies
+    float* l2c_out;         // l2: {SQ, KEq, KEr} of the pass, written by filter_l2_offsets_kernel, read by the l2c scan bodies
     const float* row_err8;  // device scalar: max over rows of |x - scale * x8| / |x| (rounded up)
     void* qimg8;            // int8 query image
     float* sq8;             // [256] scale of the query image

@@ -552,6 +552,7 @@ __global__ __launch_bounds__(NW * 64) void filter_scan_narrow_kernel(const Filte
                 const float4 lo = buf_load_f4(rn_rsrc, g * 32, m * 128), hi = buf_load_f4(rn_rsrc, g * 32 + 16, m * 128);
                 rnv[m] = make_float4(lo.x, lo.z, hi.x, hi.z);
                 rbv[m] = make_float4(lo.y * kq, lo.w * kq, hi.y * kq, hi.w * kq);  // the rows' own errors x K
+                if (SPACE == kSpaceL2 && m == 1) rnv[1] = rnv[0];  // l2 pairs: the second panel's x-slot holds the group's error, the scale is the first's
             } else {
                 rnv[m] = buf_load_f4(rn_rsrc, g * 16, m * 64);
             }
@@ -625,7 +626,7 @@ constexpr bool scan_code_l2c(int qd) { return qd >= 243 && qd <= 245; }
 // admits, and  u'_j - delta_q  (rounded up) is still an upper bound of the row's score: the thresholds the body sees are
 // raised by delta_q (the wrapper's preamble), the appended bounds lowered by it (its tail).  KE_q: the offsets kernel's formula.
 __device__ __forceinline__ float l2c_delta(const FilterArgs& a, int q) {
-    const double keq = (double)float_above((double)a.qscale[q] * ((double)a.ke[q] * 1.000002 + 1.0e-6));
+    const double keq = (double)float_above((double)a.qscale[q] * ((double)a.ke8[q] * 1.000002 + 1.0e-6));
     const double nmin = (double)a.row_err8[1];
     const double d = ((double)a.l2c_out[1] - keq) * nmin * 0.999999;
     if (!(d > 0.0) || !(nmin < 3.0e38)) return 0.f;
@@ -793,8 +794,10 @@ __global__ __launch_bounds__(NW * 64, MT == 4 ? 1 : 2) void filter_scan_asm_kern
     // l2c bodies: the pass's common query scale SQ and error coefficient KE (filter_l2_offsets_kernel; SGPR operands)
     const float sqc = scan_code_l2e(QD) ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a.l2c_out[0]))) : 0.f;
     const float kec = scan_code_l2e(QD) ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a.l2c_out[1]))) : 0.f;
+    const float krc = scan_code_l2e(QD) ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(a.l2c_out[2]))) : 0.f;
     (void)sqc;
     (void)kec;
+    (void)krc;
     u32x4s veo[MT];
     uint32_t s_eo;
     (void)veo;
@@ -1622,6 +1625,7 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
     ratio = __builtin_fmaxf(ratio, __shfl_xor(ratio, 2));
     gmax = __builtin_fmaxf(gmax, __shfl_xor(gmax, 1));
     gmax = __builtin_fmaxf(gmax, __shfl_xor(gmax, 2));
+    float bg = 0.f;  // l2: the largest relative error among the group's live rows
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int64_t panel = slab * 2 + p;
@@ -1656,20 +1660,36 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
         err2 += __shfl_xor(err2, 32);
         n2 += __shfl_xor(n2, 16);
         n2 += __shfl_xor(n2, 32);
+        float rel = 0.f;  // (every lane of the row holds the reduced sums)
+        if (n2 > 0.0) {
+            rel = (float)(__builtin_sqrt(err2 / n2) * 1.000001);
+            rel = __uint_as_float(__float_as_uint(rel) + 1u);
+        }
+        if (nrm[p] == nrm[p]) bg = __builtin_fmaxf(bg, rel);
         if (g == 0) {
             const int64_t row = panel * kPanelRows + r;
-            float rel = 0.f;
-            if (n2 > 0.0) {
-                rel = (float)(__builtin_sqrt(err2 / n2) * 1.000001);
-                rel = __uint_as_float(__float_as_uint(rel) + 1u);
-                atomicMax(row_err8, __float_as_uint(rel));  // non-negative floats order like their bits
-            }
+            if (n2 > 0.0) atomicMax(row_err8, __float_as_uint(rel));  // non-negative floats order like their bits
             if (nrm[p] == nrm[p]) atomicMin(row_err8 + 1, __float_as_uint(nrm[p]));  // smallest norm of a row ever held (l2c_delta)
-            // per-row pair: cosine {sx/(|x|+1e-30), this row's error}, l2 / ip {sx, |x|}; NaN marks a tombstone
-            float2 pr;
-            if (space == kSpaceCosine) pr = make_float2(sx / (nrm[p] + 1e-30f), nrm[p] == nrm[p] ? rel : nrm[p]);
-            else pr = make_float2(nrm[p] == nrm[p] ? sx : nrm[p], nrm[p]);
-            reinterpret_cast<float2*>(rp8)[row] = pr;
+            // per-row pair: cosine {sx/(|x|+1e-30), this row's error}, ip {sx, |x|}; NaN marks a tombstone.  (l2: below)
+            if (space != kSpaceL2) {
+                float2 pr;
+                if (space == kSpaceCosine) pr = make_float2(sx / (nrm[p] + 1e-30f), nrm[p] == nrm[p] ? rel : nrm[p]);
+                else pr = make_float2(nrm[p] == nrm[p] ? sx : nrm[p], nrm[p]);
+                reinterpret_cast<float2*>(rp8)[row] = pr;
+            }
+        }
+    }
+    if (space == kSpaceL2) {
+        // l2 pairs (round 4): {x-slot, |x|} with |x| = NaN for a dead row and the x-slot NEVER NaN: the group's scale S in the
+        // rows of the slab's first panel, the group's largest relative row error Bg in the rows of its second panel -- a scan
+        // lane holds the 8 rows of a group and reads S from its first row, Bg from its fifth.  Both panels of the slab are
+        // written even when the second lies beyond the last row (the capacity is a whole number of slabs): all dead there.
+        bg = __builtin_fmaxf(bg, __shfl_xor(bg, 1));
+        bg = __builtin_fmaxf(bg, __shfl_xor(bg, 2));
+        const float sg = gmax > 0.f ? gmax / 127.0f : 1.0f;  // (= the sx every live row of the group was quantised with)
+        if (g == 0) {
+            reinterpret_cast<float2*>(rp8)[(slab * 2) * kPanelRows + r] = make_float2(sg, nrm[0]);
+            reinterpret_cast<float2*>(rp8)[(slab * 2 + 1) * kPanelRows + r] = make_float2(bg, nrm[1]);
         }
     }
 }
@@ -1681,22 +1701,28 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
 // p, P0, S and SQ are formed by the very float operations the scan uses (tools/gen_scan_asm.py: gen_rowmax_l2ip, the wrapper's
 // preamble); dead rows (NaN pairs) drop out of the maxima and get 0.  One thread per row; a slab's 32 rows are 32 adjacent lanes.
 __global__ __launch_bounds__(256) void filter_l2_offsets_kernel(const FilterArgs a, const int64_t rows) {
-    __shared__ float s_sq[4], s_ke[4];
+    __shared__ float s_sq[4], s_ke[4], s_kr[4];
     {
         const int t = threadIdx.x;  // 256 threads = kFilterQueries
         float sq = t < a.nq ? a.qscale[t] * a.sq8[t] : 0.f;  // (the scan's preamble: sqv * a.sq8[t])
         if (!(sq == sq)) sq = 0.f;
         // l2c: one error coefficient for the pass, KE >= sq_q ke'_q = 2 |q| ke_q of every query, with room for the roundings of
         // sq_q against SQ and of S SQ (each <= 2e-7 relative of 2 |q| |x|)
-        float ke = t < a.nq ? float_above((double)a.qscale[t] * ((double)a.ke[t] * 1.000002 + 1.0e-6)) : 0.f;
+        // per-row-group errors (round 4): the bound's error term is 2 |q| (eq8_q + (1 + eq8_q) Bg) N_j = (KEq + KEr Bg) N_j with
+        // KEq >= 2 |q| eq8_q (a.ke8: the query's own measured error + roundings + slack) and KEr >= 2 |q| (1 + eq8_q)
+        float ke = t < a.nq ? float_above((double)a.qscale[t] * ((double)a.ke8[t] * 1.000002 + 1.0e-6)) : 0.f;
+        float kr = t < a.nq ? float_above((double)a.qscale[t] * (1.0 + (double)a.ke8[t]) * 1.000002) : 0.f;
         if (!(ke == ke)) ke = 0.f;
+        if (!(kr == kr)) kr = 0.f;
         for (int off = 32; off > 0; off >>= 1) {
             sq = __builtin_fmaxf(sq, __shfl_xor(sq, off));
             ke = __builtin_fmaxf(ke, __shfl_xor(ke, off));
+            kr = __builtin_fmaxf(kr, __shfl_xor(kr, off));
         }
         if ((t & 63) == 0) {
             s_sq[t >> 6] = sq;
             s_ke[t >> 6] = ke;
+            s_kr[t >> 6] = kr;
         }
     }
     __syncthreads();
@@ -1704,6 +1730,7 @@ __global__ __launch_bounds__(256) void filter_l2_offsets_kernel(const FilterArgs
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // what the l2c scan bodies take as scalars (the kernel boundary publishes them)
         a.l2c_out[0] = SQ;
         a.l2c_out[1] = __builtin_fmaxf(__builtin_fmaxf(s_ke[0], s_ke[1]), __builtin_fmaxf(s_ke[2], s_ke[3]));
+        a.l2c_out[2] = __builtin_fmaxf(__builtin_fmaxf(s_kr[0], s_kr[1]), __builtin_fmaxf(s_kr[2], s_kr[3]));
     }
     const float k1 = -(1.0f - kSlack);
     int32_t* eoff = reinterpret_cast<int32_t*>(const_cast<float*>(a.rp8) + 2 * a.rp8_cap);
@@ -1711,7 +1738,9 @@ __global__ __launch_bounds__(256) void filter_l2_offsets_kernel(const FilterArgs
         const float2 pr = reinterpret_cast<const float2*>(a.rp8)[row];  // {scale, |x|}, NaN = dead
         float p = pr.y * pr.y;
         p = k1 * p;
-        float P0 = p, S = pr.x;  // maxima over the lane group: rows r ^ 1, r ^ 2, r ^ 3 (same panel) and r ^ 16 (the other panel)
+        // maxima over the lane group: rows r ^ 1, r ^ 2, r ^ 3 (same panel) and r ^ 16 (the other panel); the group's scale is the
+        // x-slot of its first-panel rows (the second panel's holds the group's error: shadow8_rows_kernel)
+        float P0 = p, S = (row & 16) ? 0.f : pr.x;
         P0 = __builtin_fmaxf(P0, __shfl_xor(P0, 1));
         P0 = __builtin_fmaxf(P0, __shfl_xor(P0, 2));
         P0 = __builtin_fmaxf(P0, __shfl_xor(P0, 16));
@@ -2750,9 +2779,11 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
             }
 #endif
 #ifdef MLVDB_AB
-            if (!tn.scan_va) {  // round 1: AccVGPR accumulators, serial admission phase; with / without wave priorities
-                if (tn.scan_prio != 0) return launch_scan_asm<SPACE, 4, 8, true, 208, true, 2, true>(a, row_begin, row_end, s, info);
-                return launch_scan_asm<SPACE, 4, 8, true, 208, false, 2, true>(a, row_begin, row_end, s, info);
+            if constexpr (SPACE != kSpaceL2) {  // round 1: AccVGPR accumulators, serial admission phase; with / without wave priorities
+                if (!tn.scan_va) {
+                    if (tn.scan_prio != 0) return launch_scan_asm<SPACE, 4, 8, true, 208, true, 2, true>(a, row_begin, row_end, s, info);
+                    return launch_scan_asm<SPACE, 4, 8, true, 208, false, 2, true>(a, row_begin, row_end, s, info);
+                }
             }
             if constexpr (SPACE == kSpaceCosine) {  // tuning variants of the folded body
                 const int var = tn.scan_var;
@@ -2781,22 +2812,15 @@ static hipError_t launch_scan_space(const FilterArgs& a, int64_t row_begin, int6
             // passes of <= 64 / <= 128 queries: the same body computing 4 / 8 of the 16 query tiles (round 4; SCAN_NQT=16 pads)
             const int nqt = tn.scan_nqt > 0 ? tn.scan_nqt : (a.nq <= 64 ? 4 : (a.nq <= 128 ? 8 : 16));
             if constexpr (SPACE == kSpaceL2) {  // folded admission test with per-row integer offsets (the pass computed them: api.hip prep_pass)
-                if (a.rp8_cap > 0 && a.l2c) {  // ... and one query scale / error coefficient per pass (the prep built the images so)
-                    if (nqt <= 4 && a.nq <= 64) return launch_scan_asm<SPACE, 4, 8, true, 245, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (nqt <= 8 && a.nq <= 128) return launch_scan_asm<SPACE, 4, 8, true, 244, true, 2, true>(a, row_begin, row_end, s, info);
-                    return launch_scan_asm<SPACE, 4, 8, true, 243, true, 2, true>(a, row_begin, row_end, s, info);
-                }
-#ifdef MLVDB_AB  // l2e: offsets with per-query scales (SCAN_L2C=0); the default library goes on to the serial-test body instead
-                if (a.rp8_cap > 0 && tn.scan_l2e) {
-                    if (nqt <= 4 && a.nq <= 64) return launch_scan_asm<SPACE, 4, 8, true, 248, true, 2, true>(a, row_begin, row_end, s, info);
-                    if (nqt <= 8 && a.nq <= 128) return launch_scan_asm<SPACE, 4, 8, true, 247, true, 2, true>(a, row_begin, row_end, s, info);
-                    return launch_scan_asm<SPACE, 4, 8, true, 246, true, 2, true>(a, row_begin, row_end, s, info);
-                }
-#endif
+                // (the only int8 bodies of l2: api.hip attaches the int8 shadow to an l2 pass only with rp8_cap and l2c set)
+                if (nqt <= 4 && a.nq <= 64) return launch_scan_asm<SPACE, 4, 8, true, 245, true, 2, true>(a, row_begin, row_end, s, info);
+                if (nqt <= 8 && a.nq <= 128) return launch_scan_asm<SPACE, 4, 8, true, 244, true, 2, true>(a, row_begin, row_end, s, info);
+                return launch_scan_asm<SPACE, 4, 8, true, 243, true, 2, true>(a, row_begin, row_end, s, info);
+            } else {
+                if (nqt <= 4 && a.nq <= 64) return launch_scan_asm<SPACE, 4, 8, true, 242, true, 2, true>(a, row_begin, row_end, s, info);
+                if (nqt <= 8 && a.nq <= 128) return launch_scan_asm<SPACE, 4, 8, true, 241, true, 2, true>(a, row_begin, row_end, s, info);
+                return launch_scan_asm<SPACE, 4, 8, true, 211, true, 2, true>(a, row_begin, row_end, s, info);
             }
-            if (nqt <= 4 && a.nq <= 64) return launch_scan_asm<SPACE, 4, 8, true, 242, true, 2, true>(a, row_begin, row_end, s, info);
-            if (nqt <= 8 && a.nq <= 128) return launch_scan_asm<SPACE, 4, 8, true, 241, true, 2, true>(a, row_begin, row_end, s, info);
-            return launch_scan_asm<SPACE, 4, 8, true, 211, true, 2, true>(a, row_begin, row_end, s, info);
         }
         // everything below streams the bf16 shadow (an int8-only index without usable int8 bounds has none: its
         // fp32 rows are converted in registers by the compiler-scheduled kernel)

@@ -361,18 +361,22 @@ __global__ __launch_bounds__(256) void mask_norms_kernel(const float* __restrict
 }
 
 // the same for the int8 shadow's row pairs (NaN pair = not a row)
+// (l2 pairs keep their x-slot -- the group's scale / error, which the other rows of the group need -- and lose only |x|)
 __global__ __launch_bounds__(256) void mask_pairs_kernel(const float2* __restrict__ rp, const uint8_t* __restrict__ mask,
-                                                         float2* __restrict__ out, int64_t total, int64_t capacity) {
+                                                         float2* __restrict__ out, int64_t total, int64_t capacity, int l2) {
     const float nan = __builtin_nanf("");
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = (i < total && mask[i]) ? rp[i] : make_float2(nan, nan);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < capacity; i += (int64_t)gridDim.x * blockDim.x) {
+        const float2 pr = rp[i];
+        out[i] = (i < total && mask[i]) ? pr : make_float2(l2 ? pr.x : nan, nan);
+    }
 }
 
-hipError_t launch_mask_pairs(const float* rp8, const uint8_t* mask, float* out, int64_t total, int64_t capacity, hipStream_t s) {
+hipError_t launch_mask_pairs(const float* rp8, const uint8_t* mask, float* out, int64_t total, int64_t capacity, int l2,
+                             hipStream_t s) {
     if (capacity == 0) return hipSuccess;
     const int64_t blocks = std::min<int64_t>((capacity + 255) / 256, 256 * 16);
     mask_pairs_kernel<<<(unsigned)blocks, 256, 0, s>>>(reinterpret_cast<const float2*>(rp8), mask, reinterpret_cast<float2*>(out),
-                                                       total, capacity);
+                                                       total, capacity, l2);
     return hipGetLastError();
 }
 

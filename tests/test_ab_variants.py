@@ -62,8 +62,6 @@ SMALL_KNOBS = [
     {"MLVDB_SMALL_NQ": "8"},            # both steps for up to 8 queries
     {"MLVDB_NARROW_I8_MAX": "8"},       # the int8 narrow kernel (round 3's scan for 1-8 queries) instead of the 4-tile assembly body
     {"MLVDB_SCAN_NQT": "16"},           # every pass padded to 16 query tiles (round 3)
-    {"MLVDB_SCAN_L2C": "0"},            # l2: per-query scales, per-row offsets only (l2e: an AB body)
-    {"MLVDB_SCAN_L2E": "0"},            # l2: the serial admission test (round 3's body)
 ]
 SMALL_CASES = [
     ("cosine", 768, 1, 70_003, 10, 0.05), ("cosine", 768, 2, 70_003, 10, 0.05), ("l2", 768, 1, 40_001, 10, 0.3),

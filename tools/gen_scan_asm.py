@@ -264,10 +264,12 @@ def gen_rowmax_l2ip(s, part):
 
 
 def gen_rowmax_l2c(s, part):
-    """Start of the last k-step, l2c.  Loaded: u_j = the rows' scales (one value per lane group; NaN = dead row), r_j = |x_j|.
-    e10 = S SQ (the factor of the integer A = I + e), r_j becomes c_j = KE N_j + P0 with P0 = max_j -(1 - slack) N_j^2, and
-    e12 = max_j c_j: the pre-test is  float(max_j A_j) e10 + e12 >= thr,  the stubs' per-row test  float(A_j) e10 + c_j >= thr.
-    NaN rows drop out of every v_max; their c_j stays NaN and fails every compare."""
+    """Start of the last k-step, l2c.  Loaded: u_j = the x-slots of the lane's 8 row pairs -- the group's scale S in the first
+    panel's rows (u0..u3), the group's largest relative row error Bg in the second panel's (u4..u7), never NaN -- and r_j =
+    |x_j| (NaN = dead row).  e10 = S SQ (the factor of the integer A = I + e); KEg = KEq + KEr Bg (the lane's error
+    coefficient: the query part + the row part); r_j becomes c_j = KEg N_j + P0 with P0 = max_j -(1 - slack) N_j^2; e12 =
+    max_j c_j.  Pre-test: float(max_j A_j) e10 + e12 >= thr; per row (stubs): float(A_j) e10 + c_j >= thr.  NaN rows drop out of
+    every v_max; their c_j stays NaN and fails every compare."""
     a = s.emit
     NR = 4 * MT
     assert NR == 8
@@ -279,8 +281,9 @@ def gen_rowmax_l2c(s, part):
         a(f"v_max_f32 {dst}, {dst}, %[{src}7]")
 
     if part == 0:
-        tree("%[e10]", "u")
-        a("v_mul_f32 %[e10], %[sqc], %[e10]")
+        a("v_mul_f32 %[e10], %[sqc], %[u0]")                 # S SQ
+        a("v_mov_b32 %[e4], %[kec]")                         # (one SGPR per VALU instruction: the constant-bus limit)
+        a("v_fma_f32 %[e4], %[krc], %[u4], %[e4]")           # KEg = KEr Bg + KEq
         for j in range(NR):
             a(f"v_mul_f32 %[u{j}], %[r{j}], %[r{j}]")
         for j in range(NR):
@@ -288,7 +291,7 @@ def gen_rowmax_l2c(s, part):
     else:
         tree("%[e12]", "u")                                 # P0
         for j in range(NR):
-            a(f"v_fma_f32 %[r{j}], %[kec], %[r{j}], %[e12]")
+            a(f"v_fma_f32 %[r{j}], %[e4], %[r{j}], %[e12]")
         tree("%[e12]", "r")
 
 
@@ -1192,7 +1195,7 @@ def generate(space, R, QD, NW, nt=False, prio=False, mt=2, dma=False, stag=False
     if (space == "l2" and not L2C) or (i8 and space == "cosine"):
         ops_in.append('[k1] "s"(k1)')
     if L2C:
-        ops_in += ['[sqc] "s"(sqc)', '[kec] "s"(kec)']
+        ops_in += ['[sqc] "s"(sqc)', '[kec] "s"(kec)', '[krc] "s"(krc)']
     if dma:
         ops_in.append('[wave2k] "s"(wave2k)')
     if L2E:
@@ -1232,8 +1235,11 @@ def inc_name(space, nw, r, nt, qd, prio, mt, dma, stag=False):
 
 
 def default_i8_body(space):
-    """The int8 body the library runs by default for `space` (ArchVGPR accumulators, wave priorities): scan_asm_<space>_i8_va.inc."""
+    """The int8 body the library runs by default for `space` (ArchVGPR accumulators, wave priorities): scan_asm_<space>_i8_va.inc;
+    l2: the 16-tile l2c body, scan_asm_l2_i8_va_c_nqt16.inc."""
     DBG.clear()
+    if space == "l2":
+        return generate("l2", 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True, nqt=16, l2c=True)
     # round 3: straight-line append routine (all spaces) and early-out hit stubs (cosine): gen_slow_fast / gen_hit_stubs
     return generate(space, 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True)
 
@@ -1250,21 +1256,17 @@ def with_dbg(knobs, *args, **kw):
 def entries():
     E = []
     # ---- default library
-    for sp in SPACES:   # the int8 bodies with ArchVGPR accumulators (wave priorities on): QD slot 211
+    for sp in ("cosine", "ip"):   # the int8 bodies with ArchVGPR accumulators (wave priorities on): QD slot 211.  (l2: 243-245 below)
         E.append((f"scan_asm_{sp}_i8_va.inc", cond(sp, 8, 4, True, 211, True, 2, True, False), (lambda sp=sp: default_i8_body(sp)), "default"))
     # 241 / 242 (round 4): the default body computing 8 / 4 of the 16 query tiles: passes of <= 128 / <= 64 queries
-    for sp in SPACES:
+    for sp in ("cosine", "ip"):
         for code, nqt in ((241, 8), (242, 4)):
             E.append((f"scan_asm_{sp}_i8_va_nqt{nqt}.inc", cond(sp, 8, 4, True, code, True, 2, True, False),
                       (lambda sp=sp, nqt=nqt: with_dbg((), sp, 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True, nqt=nqt)), "default"))
-    # 246 / 247 / 248 (round 4): l2 with the admission test folded into the last k-step (per-row integer offsets through the
-    # first k-step's C operand), per-query scales: the step before l2c (243-245), kept as an AB variant (SCAN_L2C=0).  The l2
-    # body of slot 211 (serial test) stays in the default library: indexes whose row pairs + offsets would not fit one
-    # buffer descriptor use it, and it is the A/B reference
-    for code, nqt in ((246, 16), (247, 8), (248, 4)):
-        E.append((f"scan_asm_l2_i8_va_e_nqt{nqt}.inc", cond("l2", 8, 4, True, code, True, 2, True, False),
-                  (lambda nqt=nqt: with_dbg((), "l2", 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True, nqt=nqt, l2e=True)), "ab"))
-    # 243 / 244 / 245 (round 4): l2c -- l2e with one query scale and one error coefficient per pass (cosine's one-constant test)
+    # 243 / 244 / 245 (round 4): l2 -- admission test folded into the last k-step by per-row integer offsets through the first
+    # k-step's C operand, one query scale per pass, per-row-group errors (cosine's one-constant test); 16 / 8 / 4 query tiles.
+    # (The l2 pairs carry the group's scale / error in their x-slots: no other int8 body reads them -- the round-3 l2 bodies,
+    # serial test or AccVGPR accumulators, are gone; their A/Bs are in profiles/r04/scan_ab_l2_*.txt.)
     for code, nqt in ((243, 16), (244, 8), (245, 4)):
         E.append((f"scan_asm_l2_i8_va_c_nqt{nqt}.inc", cond("l2", 8, 4, True, code, True, 2, True, False),
                   (lambda nqt=nqt: with_dbg((), "l2", 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True, nqt=nqt, l2c=True)), "default"))
@@ -1284,7 +1286,7 @@ def entries():
     for c in ab_cfgs:
         E.append((inc_name(*c), cond(*c), (lambda c=c: with_dbg((), c[0], c[2], c[4], c[1], c[3], c[5], c[6], c[7], c[8])), "ab"))
     # int8 bodies with AccVGPR accumulators and the serial admission phase (round 1; QD slot 208), with / without wave priorities
-    for sp in SPACES:
+    for sp in ("cosine", "ip"):
         for pr in (False, True):
             E.append((f"scan_asm_{sp}_i8{'_pr' if pr else ''}.inc", cond(sp, 8, 4, True, 208, pr, 2, True, False),
                       (lambda sp=sp, pr=pr: with_dbg((), sp, 4, 4, 8, True, pr, 2, True, False, True)), "ab"))
