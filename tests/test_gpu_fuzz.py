@@ -32,7 +32,7 @@ def draw(seed):
     return n, d, nq, k, space, frac, chunks
 
 
-@pytest.mark.parametrize("seed", range(100, 120))
+@pytest.mark.parametrize("seed", range(100, 117))
 def test_fuzzed_shapes_match_oracle(seed):
     n, d, nq, k, space, frac, chunks = draw(seed)
     rows, qs = make_case(seed, n, d, nq, dup=n > 50)

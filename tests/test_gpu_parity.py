@@ -162,7 +162,7 @@ def test_topk_65_to_1000_stays_on_the_filter_path(space, k):
         eng.close()
 
 
-@pytest.mark.parametrize("space,d,n,k", [("cosine", 100, 80_001, 100), ("l2", 128, 80_001, 100), ("ip", 768, 70_003, 200),
+@pytest.mark.parametrize("space,d,n,k", [("cosine", 100, 80_001, 100), ("l2", 128, 40_001, 100), ("ip", 768, 70_003, 200),
                                          ("l2", 768, 40_001, 100), ("cosine", 1000, 33_001, 65)])
 def test_bigk_on_other_shapes_masks_and_fallbacks(space, d, n, k, monkeypatch):
     """Big-k passes on a padded int8 shadow (d = 100, 1000), on the bf16 shadow (d = 128), on a corpus smaller than the dense
@@ -215,8 +215,7 @@ def test_filter_without_bf16_shadow_matches_oracle(space, monkeypatch):
         assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"noshadow/{space}/n{n}d{d}")
 
 
-@pytest.mark.parametrize("shadow", ["default", "bf16"])
-@pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
+@pytest.mark.parametrize("space,shadow", [("l2", "default"), ("cosine", "default"), ("ip", "default"), ("cosine", "bf16")])
 def test_int8_only_shadow_matches_oracle(space, shadow, monkeypatch):
     """dim % 256 == 0: by default (round 3) the index keeps NO bf16 shadow in HBM (1.25x instead of 1.75x the corpus): seeding
     pass, small batches of every space, scans, range and row-mask searches all run on the int8 shadow.  MLVDB_SHADOW=bf16 keeps
@@ -548,7 +547,7 @@ VARIANT_SHAPES = [("cosine", 128), ("l2", 192), ("ip", 64), ("cosine", 768), ("l
 
 
 @pytest.mark.parametrize("variant,space,d", [(v, sp, d) for i, v in enumerate(SCAN_VARIANTS)
-                                             for j, (sp, d) in enumerate(VARIANT_SHAPES) if i == 0 or (i + j) % 2 == 0],
+                                             for j, (sp, d) in enumerate(VARIANT_SHAPES) if i == 0 or (i + j) % 3 == 0],
                          ids=lambda v: (",".join(f"{k[6:]}={x}" for k, x in v.items()) or "default") if isinstance(v, dict) else str(v))
 def test_scan_kernel_variants_agree_with_oracle(variant, space, d, monkeypatch):
     """Every generated geometry of the filter scan (the variable is read per launch), on corpora with more
