@@ -39,3 +39,26 @@ def test_bench_hash_of_the_default_bodies_needs_no_built_tree():
     assert body.count("asm volatile(") == 1 and "v_mfma_i32_16x16x64_i8" in body
     if (CSRC / "scan_asm_cosine_i8_va.inc").exists():
         assert (CSRC / "scan_asm_cosine_i8_va.inc").read_text() == body
+
+
+def test_query_tile_and_l2_bodies_have_the_structure_they_claim():
+    """Round 4 bodies, by their text: the 4- / 8-tile bodies issue a quarter / half of the 16-tile body's MFMAs (nothing for the
+    empty query tiles); the l2 body takes its first k-step's C operand from the offset registers, prefetches them a tile ahead
+    through the row pairs' descriptor and keeps its thresholds in registers (one compare per query tile, like cosine's)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("gen2", ROOT / "tools" / "gen_scan_asm.py")
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    mf = {}
+    for nqt in (16, 8, 4):
+        gen.DBG.clear()
+        body = gen.generate("cosine", 4, 4, 8, True, True, 2, True, False, True, True, eo=True, fs=True, nqt=nqt)
+        mf[nqt] = body.count("v_mfma_i32_16x16x64_i8 v[")
+        assert body.count("asm volatile(") == 1 and f".Lhit{nqt - 1}c200" in body and f".Lhit{nqt}c200" not in body
+    assert mf[16] == 4 * 128 and mf[8] * 2 == mf[16] and mf[4] * 4 == mf[16]  # 4 copies of the 4-k-step body x 2 * NQT * 2 x 2
+    l2 = gen.default_i8_body("l2")
+    assert "v_mfma_i32_16x16x64_i8 v[64:67], %[x0], %[t0], %[eo0]" in l2      # first k-step: C = the lane's offsets
+    assert l2.count("buffer_load_dwordx4 %[eo0]") == 3                          # prologue + the two last-body copies (.Llast, .Lsingle)
+    assert "%[tq15]" in l2 and "%[kec]" in l2 and "%[krc]" in l2 and "%[sqc]" in l2 and "%[k1]" not in l2
+    assert l2.count("ds_read_b32 %[tq") == 16                                  # thresholds: once per launch, not per row tile
