@@ -100,7 +100,6 @@ struct mlvdb_index {
     int64_t i8_rows = 0;      // rows [0, i8_rows) of the int8 shadow are current (0 after compact / reset / regrowth)
     float i8_err = 0.f;       // host copy of rowerr8 (read back whenever rows were converted)
     bool sqmin_fresh = false;  // fmisc was just (re)allocated: FilterArgs::sqmin[] not initialised yet
-    uint64_t l2c_passes = 0;   // l2c passes so far: their parity picks the QMAX word (the other one is being zeroed for the next pass)
     bool mask_active = false;  // h->rn is a masked copy (mlvdb_search_batch_filtered)
     bool mask_pairs_ready = false;  // ... and rp8_masked holds the masked copy of the int8 shadow's row pairs
     DevBuf rp8_masked;
@@ -346,7 +345,7 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     HIP_TRY(h, h->qimg.ensure(filter_qimg_bytes((h->ld + 63) / 64 * 64)));
     {
         const void* before = h->fmisc.p;
-        HIP_TRY(h, h->fmisc.ensure(8 * kFilterQueries * sizeof(uint32_t)));
+        HIP_TRY(h, h->fmisc.ensure(9 * kFilterQueries * sizeof(uint32_t)));
         if (h->fmisc.p != before) h->sqmin_fresh = true;  // the two scalars the fused prep's atomics start from: see run_filter_pass
     }
     HIP_TRY(h, h->cand.ensure((size_t)kFilterQueries * kCandCap * sizeof(CandEntry)));
@@ -380,6 +379,7 @@ int setup_filter_ws(mlvdb_index* h, FilterArgs& fa, const float* Qpad, const dou
     fa.ke8 = h->fmisc.as<float>() + 6 * kFilterQueries;  // 257 floats
     fa.sqmin = h->fmisc.as<uint32_t>() + 7 * kFilterQueries + 128;  // [0..1] smallest scale / largest error (cosine); [2..3] l2c QMAX by parity
     fa.l2c_out = h->fmisc.as<float>() + 7 * kFilterQueries + 132;
+    fa.rmaxq = h->fmisc.as<float>() + 8 * kFilterQueries;
     fa.rs = h->rescr.as<RangeHit>();
     fa.cand = h->cand.as<CandEntry>();
     fa.cand_cap = kCandCap;
@@ -470,7 +470,7 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
     fa.rp8 = h->mask_active ? h->rp8_masked.as<float>() : h->rp8.as<float>();  // a masked-out row is a NaN pair: "not a row"
     // l2: pairs + offsets through one buffer descriptor (32-bit offsets): 12 bytes per row must stay below 4 GB
     fa.rp8_cap = h->space == kSpaceL2 ? h->capacity : 0;  // (l2_int8_ok held: i8_bounds_usable)
-    if (fa.rp8_cap > 0) fa.l2c = 2 + (int32_t)((h->l2c_passes++) & 1);
+    if (fa.rp8_cap > 0) fa.l2c = 1;
     fa.row_err8 = h->rowerr8.as<float>();
     fa.qimg8 = h->qimg8.p;
     fa.sq8 = h->sq8.as<float>();
@@ -485,7 +485,7 @@ int finish_filter_pass(mlvdb_index* h, hipStream_t s, FilterArgs& fa, int32_t q0
 int prep_pass(mlvdb_index* h, hipStream_t s, const FilterArgs& fa, const float* queries_raw, float* Qpad, double* qaux, float* qerr) {
     if (h->sqmin_fresh) {  // what the fused prep's atomicMin / atomicMax start from; afterwards every fin kernel restores it
         HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fa.sqmin), 0x7f7f7f7f, 1, s));
-        HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fa.sqmin + 1), 0, 3, s));  // ... and the two l2c QMAX words
+        HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(fa.sqmin + 1), 0, 1, s));
         h->sqmin_fresh = false;
     }
     HIP_TRY(h, launch_filter_prep_fused(fa, queries_raw, h->dim, Qpad, qaux, qerr, s));

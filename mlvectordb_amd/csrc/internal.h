@@ -231,8 +231,9 @@ struct FilterArgs {
     const float* rp8;       // [rows][2] cosine {scale/(|x|+1e-30), row error}, l2 / ip {scale, |x|}; NaN = tombstoned
     int64_t rp8_cap;        // l2: rows the rp8 array was allocated for; behind its pairs (float index 2 * rp8_cap) lies the plane of
                             // per-row int32 offsets of the folded l2 admission test (filter_l2_offsets_kernel).  0 = none
-    int32_t l2c;            // l2, common query scale for the pass: 0 = off, else 2 + (parity of the pass: which of sqmin[2..3] holds its QMAX)
+    int32_t l2c;            // l2, common query scale for the pass: 0 = off
     float* l2c_out;         // l2: {SQ, KEq, KEr} of the pass, written by filter_l2_offsets_kernel, read by the l2c scan bodies
+    float* rmaxq;           // l2: [256] largest raw component of each query of the pass (fused prep -> filter_prep8_l2c_kernel)
     const float* row_err8;  // device scalar: max over rows of |x - scale * x8| / |x| (rounded up)
     void* qimg8;            // int8 query image
     float* sq8;             // [256] scale of the query image

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void filter_prep_kernel(const FilterArgs a) {
 // thr[q] from the exact distance of the k-th nearest seed row
 __global__ __launch_bounds__(256) void filter_seed_thr_kernel(const FilterArgs a, const double* seed_d64, int32_t k) {
     const int q = threadIdx.x;
-    if (q >= a.nq) return;
+    if (q >= a.nq || a.overflow[q]) return;
     const double dk = seed_d64[(int64_t)q * k + (k - 1)];
     if (!(dk < 1.0e300)) return;  // fewer than k seeds (inf) or NaN
     const double aux = a.qaux[q];
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void filter_seed_thr_kernel(const FilterArgs a
 // thr[q] for a range query: every row with dist <= radius has s >= s(radius)
 __global__ __launch_bounds__(256) void filter_range_thr_kernel(const FilterArgs a, float radius) {
     const int q = threadIdx.x;
-    if (q >= a.nq) return;
+    if (q >= a.nq || a.overflow[q]) return;  // (a query the pass took off the filter keeps its +inf threshold: filter_l2_offsets_kernel)
     const double aux = a.qaux[q];
     const double r = (double)radius;
     double s;
@@ -1702,16 +1702,37 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
 // preamble); dead rows (NaN pairs) drop out of the maxima and get 0.  One thread per row; a slab's 32 rows are 32 adjacent lanes.
 __global__ __launch_bounds__(256) void filter_l2_offsets_kernel(const FilterArgs a, const int64_t rows) {
     __shared__ float s_sq[4], s_ke[4], s_kr[4];
+    __shared__ float s_e8[kFilterQueries];
+    __shared__ float s_med;
     {
         const int t = threadIdx.x;  // 256 threads = kFilterQueries
         float sq = t < a.nq ? a.qscale[t] * a.sq8[t] : 0.f;  // (the scan's preamble: sqv * a.sq8[t])
         if (!(sq == sq)) sq = 0.f;
+        // Odd queries out.  The coefficients below are maxima over the pass's queries: one query whose image is useless (it clipped,
+        // or it is tiny beside the others: eq8 ~ 1) would loosen every query's bounds.  A query whose measured error exceeds 4 x the
+        // pass's median (and 0.03) is taken off the filter here -- flagged like a list overflow, threshold +inf so that no scan admits
+        // anything for it -- and served by the exact fallback; the maxima run over the others.  (Every block computes this; block 0 writes.)
+        const float e8 = t < a.nq ? a.ke8[t] : -1.f;
+        s_e8[t] = e8;
+        __syncthreads();
+        int below = 0;
+        for (int j = 0; j < kFilterQueries; ++j) {
+            const float o = s_e8[j];
+            below += (o >= 0.f && (o < e8 || (o == e8 && j < t))) ? 1 : 0;
+        }
+        if (e8 >= 0.f && below == (a.nq - 1) / 2) s_med = e8;
+        __syncthreads();
+        const bool odd = t < a.nq && e8 > __builtin_fmaxf(0.03f, 4.0f * s_med);
+        if (odd && blockIdx.x == 0) {
+            a.overflow[t] = 1u;
+            a.thr[t] = 3.4e38f;
+        }
         // l2c: one error coefficient for the pass, KE >= sq_q ke'_q = 2 |q| ke_q of every query, with room for the roundings of
         // sq_q against SQ and of S SQ (each <= 2e-7 relative of 2 |q| |x|)
         // per-row-group errors (round 4): the bound's error term is 2 |q| (eq8_q + (1 + eq8_q) Bg) N_j = (KEq + KEr Bg) N_j with
         // KEq >= 2 |q| eq8_q (a.ke8: the query's own measured error + roundings + slack) and KEr >= 2 |q| (1 + eq8_q)
-        float ke = t < a.nq ? float_above((double)a.qscale[t] * ((double)a.ke8[t] * 1.000002 + 1.0e-6)) : 0.f;
-        float kr = t < a.nq ? float_above((double)a.qscale[t] * (1.0 + (double)a.ke8[t]) * 1.000002) : 0.f;
+        float ke = t < a.nq && !odd ? float_above((double)a.qscale[t] * ((double)a.ke8[t] * 1.000002 + 1.0e-6)) : 0.f;
+        float kr = t < a.nq && !odd ? float_above((double)a.qscale[t] * (1.0 + (double)a.ke8[t]) * 1.000002) : 0.f;
         if (!(ke == ke)) ke = 0.f;
         if (!(kr == kr)) kr = 0.f;
         for (int off = 32; off > 0; off >>= 1) {
@@ -1951,10 +1972,7 @@ __global__ __launch_bounds__(256) void filter_prep_fused_kernel(const FilterArgs
     if (a.l2c) {
         // l2 with one quantisation step for the whole pass (round 4: filter_prep8_l2c_kernel builds the images once the pass's
         // largest raw component is known): here only this query's largest |q_i| = max |q^_i| x |q|, rounded up
-        if (threadIdx.x == 0 && real) {
-            const float rmax = float_above((double)amax * (qaux[q] + 1e-30) * 1.000001);
-            atomicMax(a.sqmin + 2 + (a.l2c & 1), __float_as_uint(rmax));  // (non-negative floats order like their bits)
-        }
+        if (threadIdx.x == 0) a.rmaxq[q] = real ? float_above((double)amax * (qaux[q] + 1e-30) * 1.000001) : 0.f;
         return;
     }
     // 3. int8 image, scale and error (filter_prep8_kernel); a.sqmin[] was left initialised by the previous pass's fin kernel
@@ -1996,9 +2014,10 @@ __global__ __launch_bounds__(256) void filter_prep_fused_kernel(const FilterArgs
 //   s = 2 |q| <q^, x> - |x|^2 ~ sq (S I) - |x|^2,   sq = 2 |q| sq8   (sq8 = the scale of the query's int8 image),
 // and the folded admission test (tools/gen_scan_asm.py, l2c) wants ONE sq for every query of the pass: then the per-row
 // integer offsets are exact for every query and the test needs one per-query constant (the threshold), like cosine's.  So
-// the images are built with sq8_q = SQ / (2 |q|), SQ = 2 QMAX / 127 and QMAX = the largest |q_i| of the pass's raw queries
-// (atomicMax of the fused kernel's blocks): every query is quantised with the same absolute step SQ / 2.  A query whose own
-// largest component is smaller uses fewer of the 255 levels; its measured error eq8 (as always: measured, rounded up) says so.
+// the images are built with sq8_q = SQ / (2 |q|), SQ = 2 QMAX / 127 and QMAX = the largest |q_i| of the pass's typical raw
+// queries (a.rmaxq, left by the fused kernel's blocks; see below): every query is quantised with the same absolute step SQ / 2.
+// A query whose own largest component is smaller uses fewer of the 255 levels, one whose is larger clips; its measured error
+// eq8 (as always: measured, rounded up) says so.
 // Block q: image, scale, error and the per-query error terms (prep8_fin_query: l2 needs nothing of the other queries).
 __global__ __launch_bounds__(256) void filter_prep8_l2c_kernel(const FilterArgs a) {
     __shared__ double dred[4];
@@ -2006,9 +2025,34 @@ __global__ __launch_bounds__(256) void filter_prep8_l2c_kernel(const FilterArgs 
     const int ld = a.ld;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool real = q < a.nq;
-    const int par = a.l2c & 1;
-    const float qmax = __uint_as_float(a.sqmin[2 + par]);
-    if (q == 0 && threadIdx.x == 0) a.sqmin[2 + (par ^ 1)] = 0u;  // the next pass's word (nobody reads or adds to it during this one)
+    // The pass's common step follows the largest raw component of its TYPICAL queries: every block finds, from the 256 per-query
+    // maxima the fused kernel left in a.sq8, the median m of the real queries' and takes QMAX = the largest maximum <= 4 m.  One
+    // query 100x the others would otherwise leave the other 255 with a handful of levels each; this way only the odd one clips
+    // (its measured error eq8 says so: looser bounds, at worst its own exact fallback).  Identical in every block: no atomics.
+    __shared__ float s_rmax[kFilterQueries];
+    __shared__ float s_q[2];
+    s_rmax[threadIdx.x] = (int)threadIdx.x < a.nq ? a.rmaxq[threadIdx.x] : -1.f;  // 256 threads = kFilterQueries; -1: not a query
+    __syncthreads();
+    {
+        const float mine = s_rmax[threadIdx.x];
+        int below = 0;  // real queries ordered before this one (ties by index): rank == (nq - 1) / 2 is the (lower) median
+        for (int j = 0; j < kFilterQueries; ++j) {
+            const float o = s_rmax[j];
+            below += (o >= 0.f && (o < mine || (o == mine && j < (int)threadIdx.x))) ? 1 : 0;
+        }
+        if (mine >= 0.f && below == (a.nq - 1) / 2) s_q[0] = mine;
+    }
+    __syncthreads();
+    {
+        const float cap = s_q[0] > 0.f ? 4.0f * s_q[0] : 3.0e38f;
+        float v = s_rmax[threadIdx.x];
+        v = (v >= 0.f && v <= cap) ? v : 0.f;
+        for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off));
+        if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = (double)v;
+    }
+    __syncthreads();
+    const float qmax = (float)__builtin_fmax(__builtin_fmax(dred[0], dred[1]), __builtin_fmax(dred[2], dred[3]));
+    __syncthreads();  // (dred is reused below)
     const float SQ = qmax > 0.f ? float_above((double)qmax * (2.0 / 127.0) * 1.000001) : 1.0f;
     const double nrm = real ? a.qaux[q] : 0.0;  // l2: qaux = |q|
     const float invf = (float)(1.0 / (nrm + 1e-30));  // as filter_prep_kernel forms q^ = q / (|q| + 1e-30)
@@ -2138,6 +2182,7 @@ __global__ __launch_bounds__(256) void filter_prefix_thr_kernel(const FilterArgs
     __shared__ uint32_t s_n[4];
     const int q = blockIdx.x;
     const double aux = a.qaux[q];
+    if (a.overflow[q]) return;  // (taken off the filter by the pass: its threshold stays +inf)
     if (a.space == kSpaceIp && !(aux > 0.0)) return;  // |q| = 0: every distance is 1 (block-uniform)
     uint32_t key[kPer], best = 0;
     double dk[kPer];

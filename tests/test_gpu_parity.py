@@ -285,6 +285,27 @@ def test_any_dim_runs_on_the_zero_padded_int8_shadow(space, d):
         eng.close()
 
 
+def test_l2_batch_with_odd_query_norms_keeps_the_rest_on_the_filter():
+    """l2 quantises every query of a pass with one step (the folded admission test needs one query scale).  The step follows the
+    largest component of the pass's TYPICAL queries (<= 4 x the median of the per-query maxima): one query 100 x the others
+    clips, one 1000 x smaller gets few levels -- their own bounds loosen (measured errors), the other 38 are untouched; the
+    answer is the oracle's for all 40."""
+    n, d = 120_001, 256
+    rows, qs = make_case(3131, n, d, 40, dup=True)
+    qs[7] *= 100.0
+    qs[21] *= 1e-3
+    eng = HipScanEngine(d, "l2", device=0, strategy="filter")
+    try:
+        eng.append(rows)
+        got = eng.search(qs, 10)
+        st = eng.last_stats()
+        assert st["strategy_used"] == 2 and st["bound_dtype"] == 2 and st["fallback_queries"] <= 2, st
+        assert st["candidates_rescored"] < 40 * 400, st   # the typical queries keep their tight bounds
+        assert_knn_matches(got, oracle_knn(qs, rows, 10, "l2"), "l2 odd norms")
+    finally:
+        eng.close()
+
+
 def test_k_larger_than_live_rows_pads():
     rows, qs = make_case(51, 6, 64, 2)
     got, _ = run_hip(rows, qs, 10, "l2", "exact", deleted_mask(51, 6, 0.4))
