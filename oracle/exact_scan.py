@@ -56,9 +56,16 @@ def exact_distances(queries, rows, space: str) -> np.ndarray:
         if space == "l2":
             # direct (q - x)^2 form: exact zero for a stored vector queried back,
             # never negative (reference tests/test_index.py:39 pins score >= 0)
-            for i in range(nq):
-                diff = xc - q[i]
-                out[i, s:s + xc.shape[0]] = np.einsum("ij,ij->i", diff, diff)
+            # (row blocks of ~2 MB and one reused buffer: the same subtraction and the same per-row summation as on the whole
+            # chunk -- a row's sum does not depend on how many rows stand beside it -- without a chunk-sized temporary per query)
+            step = max(1, (1 << 18) // max(1, xc.shape[1]))
+            buf = np.empty((step, xc.shape[1]), dtype=np.float64)
+            for b in range(0, xc.shape[0], step):
+                xb = xc[b:b + step]
+                diff = buf[:xb.shape[0]]
+                for i in range(nq):
+                    np.subtract(xb, q[i], out=diff)
+                    out[i, s + b:s + b + xb.shape[0]] = np.einsum("ij,ij->i", diff, diff)
         else:
             dots = q @ xc.T
             if space == "cosine":

@@ -134,13 +134,21 @@ def test_config3_10m_cosine_all_256_queries_equal_the_exact_scan(engine_10m_cosi
 
     sub = np.concatenate([np.arange(len(PLANT)), [200]])
     parts_l, parts_d = [], []
-    for off, rows in synth.iter_corpus(0, N10, D, threads=16):
-        for lo in range(0, rows.shape[0], 50_000):  # (cache-sized blocks: the fp64 copy of a block stays out of DRAM)
-            d64 = exact_scan.exact_distances(qs[sub], rows[lo:lo + 50_000], "cosine")
-            part = np.argpartition(d64, K - 1, axis=1)[:, :K]
-            parts_l.append(part + off + lo)
-            parts_d.append(np.take_along_axis(d64, part, axis=1))
-        del d64, rows
+
+    def block_topk(rows, base):  # (cache-sized blocks: the fp64 copy of a block stays out of DRAM)
+        d64 = exact_scan.exact_distances(qs[sub], rows, "cosine")
+        part = np.argpartition(d64, K - 1, axis=1)[:, :K]
+        return part + base, np.take_along_axis(d64, part, axis=1)
+
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(8) as pool:  # (NumPy releases the GIL in the conversions and products: eight blocks at a time)
+        for off, rows in synth.iter_corpus(0, N10, D, threads=16):
+            los = range(0, rows.shape[0], 50_000)
+            for pl, pd in pool.map(lambda lo: block_topk(rows[lo:lo + 50_000], off + lo), los):
+                parts_l.append(pl)
+                parts_d.append(pd)
+            del rows
     from mlvectordb_amd.sharded import merge_topk
 
     ol, od, _ = merge_topk(parts_l, parts_d, K)
