@@ -286,10 +286,11 @@ def test_any_dim_runs_on_the_zero_padded_int8_shadow(space, d):
 
 
 def test_l2_batch_with_odd_query_norms_keeps_the_rest_on_the_filter():
-    """l2 quantises every query of a pass with one step (the folded admission test needs one query scale).  The step follows the
-    largest component of the pass's TYPICAL queries (<= 4 x the median of the per-query maxima): one query 100 x the others
-    clips, one 1000 x smaller gets few levels -- their own bounds loosen (measured errors), the other 38 are untouched; the
-    answer is the oracle's for all 40."""
+    """l2 quantises every query of a pass with one step and bounds every lane with one pair of error coefficients (the folded
+    admission test needs them in registers).  The step follows the largest component of the pass's TYPICAL queries (<= 4 x the
+    median of the per-query maxima); a query whose image then measures an error > 4 x the pass's median (one 100 x the others
+    clips, one 1000 x smaller has no levels left) is taken off the filter before the scans and answered by the exact fallback,
+    so the other 38 keep their bounds.  kNN at k = 10, k = 100 (big-k pass) and a range query: the oracle's answer for all 40."""
     n, d = 120_001, 256
     rows, qs = make_case(3131, n, d, 40, dup=True)
     qs[7] *= 100.0
@@ -302,6 +303,23 @@ def test_l2_batch_with_odd_query_norms_keeps_the_rest_on_the_filter():
         assert st["strategy_used"] == 2 and st["bound_dtype"] == 2 and st["fallback_queries"] <= 2, st
         assert st["candidates_rescored"] < 40 * 400, st   # the typical queries keep their tight bounds
         assert_knn_matches(got, oracle_knn(qs, rows, 10, "l2"), "l2 odd norms")
+        got = eng.search(qs, 100)
+        st = eng.last_stats()
+        assert st["strategy_used"] == 2 and st["fallback_queries"] <= 2, st
+        assert_knn_matches(got, oracle_knn(qs, rows, 100, "l2"), "l2 odd norms, k = 100")
+        dmat = exact_scan.exact_distances(qs, rows, "l2")
+        typical = np.delete(np.arange(40), [7, 21])
+        radius = float(np.float32(np.sort(dmat[typical], axis=1)[:, 9].mean()))
+        hits = eng.range(qs, radius, 256)
+        st = eng.last_stats()
+        assert st["strategy_used"] == 2, st
+        want = exact_scan.range_query(qs, rows, radius, "l2")
+        assert sum(len(w[0]) for w in want) > 100
+        for i, ((gl, gd), (wl, wd)) in enumerate(zip(hits, want)):
+            # (the tiny query is within the radius of EVERY row: one call ranks at most 16384 hits per query, the nearest)
+            assert len(gl) == min(len(wl), 16384), (i, len(gl), len(wl))
+            assert np.array_equal(gl, wl[:len(gl)]), f"range, odd norms, query {i}: {gl} vs {wl}"
+            assert np.abs(gd - wd[:len(gl)]).max(initial=0.0) <= SCORE_ATOL * max(1.0, float(np.abs(wd).max(initial=0.0)))
     finally:
         eng.close()
 
@@ -363,6 +381,19 @@ def test_device_pointer_entry_runs_the_exact_fallback_for_overflowed_queries():
         got = eng.search(qs, k)  # host-pointer entry: the same decision, taken on the host after its own sync
         assert eng.last_stats()["fallback_queries"] == stats["fallback_queries"]
         assert_knn_matches(got, oracle_knn(qs, rows, k, "cosine"), "host-entry/fallback")
+        # the same entry again with 24, 13 and 1 queries (full and partly filled query tiles of the fallback scan), fp64 distances
+        # asked for: every call leaves the flags, the selected-query list and the partial lists ready for the next one
+        want_all = oracle_knn(qs, rows, k, "cosine")
+        d64 = torch.empty((nq, k), dtype=torch.float64, device="cuda")
+        for m in (nq, 13, 1, nq):
+            lab.fill_(-7)
+            eng.search_device(t_q.data_ptr(), m, k, lab.data_ptr(), dist.data_ptr(), cnt.data_ptr(), d64.data_ptr(), stream)
+            torch.cuda.synchronize()
+            st = eng.last_stats()
+            assert 1 <= st["fallback_queries"] <= m, (m, st)
+            got_m = (lab[:m].cpu().numpy(), dist[:m].cpu().numpy(), cnt[:m].cpu().numpy())
+            assert_knn_matches(got_m, tuple(w[:m] for w in want_all), f"device-entry/fallback m={m}")
+            assert np.abs(d64[:m].cpu().numpy() - got_m[1]).max() < 1e-6
     finally:
         eng.close()
 
