@@ -1694,6 +1694,25 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
     }
 }
 
+// Median machinery for the 256 per-query values of a pass (non-negative floats; negative = not a query).  A value's order key is
+// its bit pattern (monotone for non-negative floats) with the query index below it -- distinct 64-bit integers, so the ranks of the
+// real queries are a permutation and one u64 compare per pair decides (the float compares with index tie-break compiled to ~50
+// instructions per pair: 25 us per launch); non-queries get the largest key and order after everything.
+__device__ __forceinline__ unsigned long long rank_key_256(const float v, const int t) {
+    return v >= 0.f ? ((unsigned long long)__float_as_uint(v) << 8) | (unsigned long long)t : ~0ull;
+}
+__device__ __forceinline__ int rank_among_256(const unsigned long long* keys, const unsigned long long mine) {
+    const ulonglong2* k2 = reinterpret_cast<const ulonglong2*>(keys);  // (16-byte aligned LDS: two keys per read)
+    int below = 0;
+#pragma unroll 16
+    for (int j = 0; j < kFilterQueries / 2; ++j) {
+        const ulonglong2 o = k2[j];
+        below += o.x < mine ? 1 : 0;
+        below += o.y < mine ? 1 : 0;
+    }
+    return below;
+}
+
 // l2, once per pass: e[row] = ceil((p_row - P0) / (SQ S)) + 1 (<= 1), the integer that, added to the row's int8 dot product,
 // stands for the difference between the row's own term p = -(1 - slack) |x|^2 and the largest such term P0 among the 8 rows one
 // scan lane holds (rows 4g..4g+3 of both panels of a 32-row slab), in units of one quantum SQ S of the score: SQ = the largest
@@ -1702,28 +1721,28 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
 // preamble); dead rows (NaN pairs) drop out of the maxima and get 0.  One thread per row; a slab's 32 rows are 32 adjacent lanes.
 __global__ __launch_bounds__(256) void filter_l2_offsets_kernel(const FilterArgs a, const int64_t rows) {
     __shared__ float s_sq[4], s_ke[4], s_kr[4];
-    __shared__ float s_e8[kFilterQueries];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_key[kFilterQueries];
     __shared__ float s_med;
+    const int t = threadIdx.x;  // 256 threads = kFilterQueries
     {
-        const int t = threadIdx.x;  // 256 threads = kFilterQueries
         float sq = t < a.nq ? a.qscale[t] * a.sq8[t] : 0.f;  // (the scan's preamble: sqv * a.sq8[t])
         if (!(sq == sq)) sq = 0.f;
+        for (int off = 32; off > 0; off >>= 1) sq = __builtin_fmaxf(sq, __shfl_xor(sq, off));
+        if ((t & 63) == 0) s_sq[t >> 6] = sq;
+    }
+    if (blockIdx.x == 0) {  // (block-uniform) the pass's scalars for the l2c scan bodies; every block needs only SQ
         // Odd queries out.  The coefficients below are maxima over the pass's queries: one query whose image is useless (it clipped,
         // or it is tiny beside the others: eq8 ~ 1) would loosen every query's bounds.  A query whose measured error exceeds 4 x the
         // pass's median (and 0.03) is taken off the filter here -- flagged like a list overflow, threshold +inf so that no scan admits
-        // anything for it -- and served by the exact fallback; the maxima run over the others.  (Every block computes this; block 0 writes.)
+        // anything for it -- and served by the exact fallback; the maxima run over the others.
         const float e8 = t < a.nq ? a.ke8[t] : -1.f;
-        s_e8[t] = e8;
+        const unsigned long long key = rank_key_256(e8, t);
+        s_key[t] = key;
         __syncthreads();
-        int below = 0;
-        for (int j = 0; j < kFilterQueries; ++j) {
-            const float o = s_e8[j];
-            below += (o >= 0.f && (o < e8 || (o == e8 && j < t))) ? 1 : 0;
-        }
-        if (e8 >= 0.f && below == (a.nq - 1) / 2) s_med = e8;
+        if (e8 >= 0.f && rank_among_256(s_key, key) == (a.nq - 1) / 2) s_med = e8;  // the (lower) median of the pass's errors
         __syncthreads();
         const bool odd = t < a.nq && e8 > __builtin_fmaxf(0.03f, 4.0f * s_med);
-        if (odd && blockIdx.x == 0) {
+        if (odd) {
             a.overflow[t] = 1u;
             a.thr[t] = 3.4e38f;
         }
@@ -1736,12 +1755,10 @@ __global__ __launch_bounds__(256) void filter_l2_offsets_kernel(const FilterArgs
         if (!(ke == ke)) ke = 0.f;
         if (!(kr == kr)) kr = 0.f;
         for (int off = 32; off > 0; off >>= 1) {
-            sq = __builtin_fmaxf(sq, __shfl_xor(sq, off));
             ke = __builtin_fmaxf(ke, __shfl_xor(ke, off));
             kr = __builtin_fmaxf(kr, __shfl_xor(kr, off));
         }
         if ((t & 63) == 0) {
-            s_sq[t >> 6] = sq;
             s_ke[t >> 6] = ke;
             s_kr[t >> 6] = kr;
         }
@@ -2029,23 +2046,20 @@ __global__ __launch_bounds__(256) void filter_prep8_l2c_kernel(const FilterArgs 
     // maxima the fused kernel left in a.sq8, the median m of the real queries' and takes QMAX = the largest maximum <= 4 m.  One
     // query 100x the others would otherwise leave the other 255 with a handful of levels each; this way only the odd one clips
     // (its measured error eq8 says so: looser bounds, at worst its own exact fallback).  Identical in every block: no atomics.
-    __shared__ float s_rmax[kFilterQueries];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_key[kFilterQueries];
     __shared__ float s_q[2];
-    s_rmax[threadIdx.x] = (int)threadIdx.x < a.nq ? a.rmaxq[threadIdx.x] : -1.f;  // 256 threads = kFilterQueries; -1: not a query
-    __syncthreads();
+    const float rmax_t = (int)threadIdx.x < a.nq ? a.rmaxq[threadIdx.x] : -1.f;  // 256 threads = kFilterQueries; -1: not a query
     {
-        const float mine = s_rmax[threadIdx.x];
-        int below = 0;  // real queries ordered before this one (ties by index): rank == (nq - 1) / 2 is the (lower) median
-        for (int j = 0; j < kFilterQueries; ++j) {
-            const float o = s_rmax[j];
-            below += (o >= 0.f && (o < mine || (o == mine && j < (int)threadIdx.x))) ? 1 : 0;
-        }
-        if (mine >= 0.f && below == (a.nq - 1) / 2) s_q[0] = mine;
+        const unsigned long long key = rank_key_256(rmax_t, (int)threadIdx.x);
+        s_key[threadIdx.x] = key;
+        __syncthreads();
+        // real queries ordered before this one: rank == (nq - 1) / 2 is the (lower) median
+        if (rmax_t >= 0.f && rank_among_256(s_key, key) == (a.nq - 1) / 2) s_q[0] = rmax_t;
     }
     __syncthreads();
     {
         const float cap = s_q[0] > 0.f ? 4.0f * s_q[0] : 3.0e38f;
-        float v = s_rmax[threadIdx.x];
+        float v = rmax_t;
         v = (v >= 0.f && v <= cap) ? v : 0.f;
         for (int off = 32; off > 0; off >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, off));
         if ((threadIdx.x & 63) == 0) dred[threadIdx.x >> 6] = (double)v;

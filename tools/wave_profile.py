@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--waves", type=int, default=12)
     ap.add_argument("--tune", default="", help="KEY=VAL,KEY=VAL tuning of the handle")
     ap.add_argument("--check", action="store_true", help="compare with the exact scan")
+    ap.add_argument("--host", action="store_true", help="kNN through the host-pointer entry (queries in, results out over PCIe) as well")
     args = ap.parse_args()
     import torch
 
@@ -72,6 +73,15 @@ def main():
             torch.cuda.synchronize()
             t.append(time.perf_counter() - ts)
         st = eng.last_stats()
+        if args.host:
+            th = []
+            for i in range(args.waves + 3):
+                ts = time.perf_counter()
+                eng.search(qh[i % 4], k)
+                th.append(time.perf_counter() - ts)
+            th = np.array(th[3:]) * 1e3
+            print(f"host-pointer entry: wave p50 {np.median(th):.3f} ms, min {th.min():.3f} ms")
+            eng.last_stats()
         if args.check:
             eng.search_device(qd[0].data_ptr(), args.batch, k, lab.data_ptr(), dst.data_ptr(), cnt.data_ptr(), 0, 0)
             torch.cuda.synchronize()
