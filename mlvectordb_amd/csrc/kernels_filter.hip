@@ -2196,7 +2196,7 @@ __global__ __launch_bounds__(256) void filter_prefix_thr_kernel(const FilterArgs
     __shared__ uint32_t s_n[4];
     const int q = blockIdx.x;
     const double aux = a.qaux[q];
-    if (a.overflow[q]) return;  // (taken off the filter by the pass: its threshold stays +inf)
+    if (a.l2c && a.overflow[q]) return;  // (l2: taken off the filter by the pass, its threshold stays +inf; others: no flag is set yet)
     if (a.space == kSpaceIp && !(aux > 0.0)) return;  // |q| = 0: every distance is 1 (block-uniform)
     uint32_t key[kPer], best = 0;
     double dk[kPer];
