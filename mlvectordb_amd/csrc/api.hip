@@ -520,7 +520,7 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
     // ~3,500 candidates per query it leaves cost the ranking kernel 31 us -- more than the three 15 us refines it saves.
     {
         const bool small = fa.X8 && nq <= 8 && !h->mask_active && h->total <= (int64_t)2500000 && filter_narrow_ok(fa) &&
-                           h->tn.small_batch == 1;
+                           h->tn.small_batch == 1;  // (2: the round-4 variant below)
         if (small) {
             const int64_t units = std::max<int64_t>(1, h->tn.small_batch_units);  // x 768 rows
             const int64_t n_exact = std::min<int64_t>(h->total, units * kFilterTile);
@@ -541,6 +541,40 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
             h->stats.scan_launches += 1;
             h->stats.rows_scanned += h->total;
             return finish_filter_pass(h, s, fa, q0, nq, k, out_labels, out_dist, out_counts, out_d64, defer_fallback);
+        }
+    }
+    // ---- one round for single queries on small corpora (round 4; SMALL_BATCH=0: the rounds below): the exact k-th best of an
+    // 11,520-row prefix (prefix_exact_kernel all over the chip + the one-block selection) puts the threshold at quantile
+    // k / 11,520; ONE scan launch over every row then appends ~total (k / 11,520) x band entries per query -- 1M x 768, k = 10:
+    // 870 x band (~4 on N(0,1) rows) of the list's 8,192 -- and the fused finish prunes, rescores and ranks: five launches instead
+    // of seven (no 65k-row first round, no refine after it): 0.197-0.199 vs 0.206-0.212 ms at batch 1
+    // (profiles/r04/small_batch_one_round_vs_rounds_1m.txt).  Taken only while the estimate with band = 6 stays inside the list;
+    // a list that overflows all the same sends its query to the exact scan, as everywhere.
+    {
+        const int small_nq1 = std::max(0, std::min(1, h->tn.small_nq));  // (two queries: 0.214-0.220 vs 0.211-0.219 ms -- no gain)
+        const int64_t m = 3 * kSeedRows;
+        const bool one_round = h->tn.small_batch == 2 && fa.X8 && nq <= small_nq1 && k <= 64 && !h->mask_active &&
+                               filter_refine_can_fuse(fa) && h->tn.small_finish != 0 && h->tn.small_seed != 0 && h->total > 4 * m &&
+                               (double)h->total * k * 6.0 <= 6000.0 * (double)m;
+        if (one_round) {
+            HIP_TRY(h, h->seed_d64.ensure(((size_t)kFilterQueries * 64 + (size_t)8 * kSeedRows) * sizeof(double)));
+            double* d64 = h->seed_d64.as<double>();
+            HIP_TRY(h, launch_prefix_exact(h->X, fa.rn, fa.Qpad, fa.qaux, nq, (int32_t)m, h->ld, h->space, d64, h->tn, s));
+            HIP_TRY(h, launch_filter_prefix_thr(fa, d64, (int32_t)m, k, s));
+            rc = scan_event(h, s, true);
+            if (rc) return rc;
+            ScanInfo info;
+            HIP_TRY(h, launch_filter_scan(fa, 0, h->total, s, &info));
+            rc = scan_event(h, s, false);
+            if (rc) return rc;
+            h->stats.scan_launches += 1;
+            h->stats.rows_scanned += h->total;
+            HIP_TRY(h, h->qsel.ensure(kFilterQueries * sizeof(int32_t)));
+            unsigned long long* stats = h->counters.as<unsigned long long>();
+            HIP_TRY(h, launch_filter_finish_small(fa, k, q0, out_labels, out_dist, out_counts, out_d64, stats,
+                                                  defer_fallback ? nullptr : h->qsel.as<int32_t>(),
+                                                  reinterpret_cast<int32_t*>(stats + 2), s));
+            return finish_filter_pass(h, s, fa, q0, nq, k, out_labels, out_dist, out_counts, out_d64, defer_fallback, true);
         }
     }
     // seed: a dense pass of the filter kernel over the first rows puts every bound into the lists,

@@ -39,7 +39,7 @@ inline hipError_t ensure_dynamic_lds(std::atomic<uint64_t>& done, const void* ke
     X(no_shadow, "NO_SHADOW", 0)       /* creation: no shadow at all (the filter converts fp32 rows in registers) */   \
     X(shadow_bf16, "SHADOW_BF16", 0)   /* creation: keep the bf16 shadow beside the int8 one (MLVDB_SHADOW=bf16) */    \
     X(i8_pad, "I8_PAD", 1)             /* creation: int8 shadow zero-padded to a multiple of 256 columns for any dim */\
-    X(small_batch, "SMALL_BATCH", 0)   /* single-round path for <= 8 queries (measured slower) */                      \
+    X(small_batch, "SMALL_BATCH", 2)   /* 1: single-round path for <= 8 queries (round 3, slower); 2: one round after an 11,520-row exact prefix (one query, small corpora) */ \
     X(small_batch_units, "SMALL_BATCH_UNITS", 16)                                                                       \
     X(small_seed, "SMALL_SEED", 1)     /* 1-2 queries: exact prefix seed */                                             \
     X(small_finish, "SMALL_FINISH", 1) /* 1-2 queries: fused last refine + rescoring + ranking */                       \
@@ -251,7 +251,7 @@ hipError_t launch_filter_prep(const FilterArgs& a, hipStream_t s);
 hipError_t launch_filter_prep_fused(const FilterArgs& a, const float* queries, int32_t dim, float* Qpad, double* qaux, float* qerr,
                                     hipStream_t s);
 // seed thresholds from exact kNN distances of a prefix of the corpus: seed_d64[q][k]
-// thr[q] from the k-th smallest of d64[q][0..m) (m <= kSeedRows; fewer than k finite values: thr stays as it is)
+// thr[q] from the k-th smallest of d64[q][0..m) (m <= 3 kSeedRows; fewer than k finite values: thr stays as it is)
 hipError_t launch_filter_prefix_thr(const FilterArgs& a, const double* d64, int32_t m, int32_t k, hipStream_t s);
 hipError_t launch_filter_seed_thr(const FilterArgs& a, const double* seed_d64, int32_t k, hipStream_t s);
 // What a scan launch reports back (tuning aids).  The assembly scan stages its hits per wave in LDS and its own tail

@@ -2188,9 +2188,9 @@ __device__ __forceinline__ uint32_t radix_select_atleast256(const uint32_t* keys
 // took 14 us here, per-wave sorted lists with fp64 shuffles 34): every thread keeps its <= 15 keys in registers; L = the
 // k-th largest of the 256 per-thread maxima is at most the k-th largest key (k keys are >= L), the few keys >= L (about k,
 // unless many are equal) are collected and ranked by counting.
+template <int kPer>  // keys per thread: 15 (m <= kSeedRows) or 45 (m <= 3 kSeedRows: the one-round path of small corpora)
 __global__ __launch_bounds__(256) void filter_prefix_thr_kernel(const FilterArgs a, const double* __restrict__ d64, const int32_t m,
                                                                 const int32_t k) {
-    constexpr int kPer = kSeedRows / 256;  // 15
     __shared__ __attribute__((aligned(16))) uint32_t tmax[256];
     __shared__ uint32_t sel[256];
     __shared__ uint32_t s_n[4];
@@ -2266,8 +2266,9 @@ __global__ __launch_bounds__(256) void filter_prefix_thr_kernel(const FilterArgs
 }
 
 hipError_t launch_filter_prefix_thr(const FilterArgs& a, const double* d64, int32_t m, int32_t k, hipStream_t s) {
-    if (m < 1 || m > kSeedRows || k < 1 || k > 256) return hipErrorInvalidValue;
-    filter_prefix_thr_kernel<<<a.nq, 256, 0, s>>>(a, d64, m, k);
+    if (m < 1 || m > 3 * kSeedRows || k < 1 || k > 256) return hipErrorInvalidValue;
+    if (m <= kSeedRows) filter_prefix_thr_kernel<kSeedRows / 256><<<a.nq, 256, 0, s>>>(a, d64, m, k);
+    else filter_prefix_thr_kernel<3 * kSeedRows / 256><<<a.nq, 256, 0, s>>>(a, d64, m, k);
     return hipGetLastError();
 }
 

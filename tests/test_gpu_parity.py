@@ -551,7 +551,9 @@ def test_wide_rows_through_the_filter_agree_with_oracle(space, d, nq):
 # (the default structure only: each step switched off in turn -- SMALL_SEED=0, SMALL_FINISH=0, SMALL_NQ=0 / 8 -- is in
 # tests/test_ab_variants.py, marked `ab`: alternative paths, not live ones)
 SMALL_KNOBS = [
-    {},                                 # round 3's default for 1-2 queries: exact prefix seed + fused last refine / rescoring / ranking
+    {},                                 # 1-2 queries: exact prefix seed + fused last refine / rescoring / ranking; one query on a corpus
+                                        # of <= 11.5M / k rows: ONE scan round after an 11,520-row exact prefix (round 4)
+    {"MLVDB_SMALL_BATCH": "0"},         # the scan rounds for every corpus size (what 10M rows take)
 ]
 SMALL_CASES = [
     # space, d, nq, n, k, deleted_frac  (d % 256 == 0: the int8 shadow, which the small-batch steps need)
@@ -560,6 +562,7 @@ SMALL_CASES = [
     ("ip", 768, 1, 3_000, 10, 0.05),     # fewer rows than the seed prefix
     ("l2", 256, 2, 9_000, 64, 0.995),    # fewer than k live rows in the prefix (and 45 in all)
     ("cosine", 768, 5, 70_003, 10, 0.05), ("l2", 768, 8, 40_001, 10, 0.05),  # 3-8 queries: default structure unless SMALL_NQ=8
+    ("l2", 768, 1, 70_003, 10, 0.05), ("ip", 512, 1, 120_001, 64, 0.5),       # one round: l2 offsets, k = 64 with half the rows dead
 ]
 
 
@@ -575,6 +578,8 @@ def test_batches_of_one_or_two_queries_agree_with_oracle(space, d, nq, n, k, fra
     deleted = deleted_mask(13, n, frac)
     got, stats = run_hip(rows, qs, k, space, "filter", deleted, append_chunks=3)
     assert stats["strategy_used"] == 2 and stats["fallback_queries"] == 0 and stats["bound_dtype"] == 2
+    one_round = not knobs and nq == 1 and n > 4 * 11_520 and n * k * 6 <= 6000 * 11_520  # (api.hip run_filter_pass)
+    assert (stats["scan_launches"] == 1) == (one_round or n <= 65_280), stats  # (<= 65,280 rows are one round anyway)
     assert_knn_matches(got, oracle_knn(qs, rows, k, space, deleted), f"small {knobs}/{space}/d{d}/nq{nq}/k{k}")
 
 
