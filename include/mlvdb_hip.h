@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MLVDB_ABI_VERSION 5
+#define MLVDB_ABI_VERSION 6
 
 /* status codes */
 #define MLVDB_OK 0
@@ -181,6 +181,21 @@ int mlvdb_search_batch_ex(mlvdb_index* h, const float* queries, int64_t nq, int3
  */
 int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float radius, int64_t capacity,
                       int64_t* out_labels, float* out_dist, int64_t* out_counts);
+
+/*
+ * The same query with packed outputs (ABI version 6): hit counts differ by orders of magnitude between queries, so the dense
+ * [nq, capacity] arrays of mlvdb_range_batch are mostly padding.  Here the hits of query i are the entries
+ * out_offsets[i] .. out_offsets[i + 1] of out_labels / out_dist (nearest first), at most `capacity` per query.
+ *   total_capacity  entries available in out_labels / out_dist (both may be NULL when it is 0: a counting call)
+ *   out_offsets     [nq + 1] int64, always written: out_offsets[nq] = the entries the hits need in all
+ *   out_counts      [nq] int64 exact number of hits per query, even when > capacity
+ * Returns MLVDB_ERR_OVERFLOW when the hits need more than total_capacity entries (nothing is written to out_labels /
+ * out_dist; call again with out_offsets[nq] entries) or when a query had more hits than `capacity` (outputs hold the nearest
+ * `capacity` of each), MLVDB_ERR_UNSUPPORTED as mlvdb_range_batch.
+ */
+int mlvdb_range_batch_packed(mlvdb_index* h, const float* queries, int64_t nq, float radius, int64_t capacity,
+                             int64_t total_capacity, int64_t* out_labels, float* out_dist, int64_t* out_offsets,
+                             int64_t* out_counts);
 
 /*
  * Exact distances of given (query, row) pairs, in the index's space: out_dist64[q*m + j] = distance of queries[q] to the

@@ -18,7 +18,7 @@ SPACE_CODES = {"l2": 0, "cosine": 1, "ip": 2}
 STRATEGY_CODES = {"auto": 0, "exact": 1, "filter": 2}
 MAX_TOPK = 64
 MAX_TOPK_PAGED = 16384
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class Stats(C.Structure):
@@ -57,6 +57,7 @@ SIGNATURES = {
     "mlvdb_search_batch_ex": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
     "mlvdb_search_batch_device": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
     "mlvdb_range_batch": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int64, _P, _P, _P]),
+    "mlvdb_range_batch_packed": (C.c_int, [_P, _P, C.c_int64, C.c_float, C.c_int64, C.c_int64, _P, _P, _P, _P]),
     "mlvdb_pair_distances": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, _P]),
     "mlvdb_index_set_strategy": (C.c_int, [_P, C.c_int32]),
     "mlvdb_index_set_tuning": (C.c_int, [_P, C.c_char_p]),

@@ -1641,20 +1641,29 @@ int mlvdb_search_batch_filtered(mlvdb_index* h, const float* queries, int64_t nq
     });
 }
 
-int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float radius, int64_t capacity,
-                      int64_t* out_labels, float* out_dist, int64_t* out_counts) {
-    return guarded(h, [&]() -> int {
+// Both range entries.  out_offsets == nullptr: the dense form (out_labels / out_dist are [nq, capacity]); otherwise the packed
+// form: the hits of query i are entries out_offsets[i] .. out_offsets[i + 1] of out_labels / out_dist (total_capacity entries).
+static int range_batch_impl(mlvdb_index* h, const float* queries, int64_t nq, float radius, int64_t capacity, int64_t* out_labels,
+                            float* out_dist, int64_t* out_counts, int64_t* out_offsets, int64_t total_capacity, bool packed) {
     int rc = check_handle(h);
     if (rc) return rc;
+    if (packed && !out_offsets) return fail(h, MLVDB_ERR_INVALID_ARG, "null buffer");
     if (nq < 0 || nq > (1 << 24)) return fail(h, MLVDB_ERR_INVALID_ARG, "nq out of range");
     if (capacity < 1) return fail(h, MLVDB_ERR_INVALID_ARG, "capacity must be >= 1");
-    if (nq == 0) return MLVDB_OK;
-    if (!queries || !out_labels || !out_dist || !out_counts) return fail(h, MLVDB_ERR_INVALID_ARG, "null buffer");
+    if (out_offsets && total_capacity < 0) return fail(h, MLVDB_ERR_INVALID_ARG, "total_capacity must be >= 0");
+    if (nq == 0) {
+        if (out_offsets) out_offsets[0] = 0;
+        return MLVDB_OK;
+    }
+    if (!queries || !out_counts || ((!out_labels || !out_dist) && (!out_offsets || total_capacity > 0)))
+        return fail(h, MLVDB_ERR_INVALID_ARG, "null buffer");
     hipStream_t s = h->stream;
     rc = begin_call(h, s);
     if (rc) return rc;
     if (h->total == 0 || h->total == h->deleted) {
         for (int64_t i = 0; i < nq; ++i) out_counts[i] = 0;
+        if (out_offsets)
+            for (int64_t i = 0; i <= nq; ++i) out_offsets[i] = 0;
         return end_call(h, s);
     }
     HIP_TRY(h, h->io_q.ensure((size_t)nq * h->dim * sizeof(float)));
@@ -1783,6 +1792,53 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
     std::vector<int64_t> offsets((size_t)nq + 1, 0);
     for (int64_t i = 0; i < nq; ++i) offsets[(size_t)i + 1] = offsets[(size_t)i] + std::min<int64_t>(std::max<int64_t>(counts[i], 0), cap_eff);
     const int64_t total_hits = offsets[(size_t)nq];
+    if (out_offsets) {
+        // packed form: offsets and counts always; the hits when they fit (one packing kernel, one DMA, two copies out of pinned memory)
+        std::memcpy(out_offsets, offsets.data(), ((size_t)nq + 1) * sizeof(int64_t));
+        bool hard_p = false;
+        for (int64_t i = 0; i < nq; ++i) {
+            out_counts[i] = counts[i];
+            hard_p |= counts[i] > cap_eff && capacity > cap_eff;
+        }
+        const bool fits = total_hits <= total_capacity;
+        if (fits && total_hits > 0) {
+            HIP_TRY(h, h->labels_in.ensure(((size_t)nq + 1) * sizeof(int64_t)));
+            const size_t plab = (size_t)total_hits * sizeof(int64_t), pdst = (size_t)total_hits * sizeof(float);
+            HIP_TRY(h, h->seed_lab.ensure(plab + pdst));
+            const bool pinned = plab + pdst <= ((size_t)16 << 20);  // (pinned staging only while it stays small: search_host)
+            if (pinned) HIP_TRY(h, h->pin_out.ensure(plab + pdst));
+            int64_t* d_pl = h->seed_lab.as<int64_t>();
+            float* d_pd = reinterpret_cast<float*>(h->seed_lab.as<char>() + plab);
+            std::memcpy(h->pin_in.p, offsets.data(), ((size_t)nq + 1) * sizeof(int64_t));
+            HIP_TRY(h, hipMemcpyAsync(h->labels_in.p, h->pin_in.p, ((size_t)nq + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            range_pack_kernel<<<(unsigned)nq, 256, 0, s>>>(h->io_lab.as<int64_t>(), h->io_dist.as<float>(), h->labels_in.as<int64_t>(),
+                                                           cap_eff, d_pl, d_pd);
+            HIP_TRY(h, hipGetLastError());
+            if (pinned) {
+                HIP_TRY(h, hipMemcpyAsync(h->pin_out.p, d_pl, plab + pdst, hipMemcpyDeviceToHost, s));
+                HIP_TRY(h, hipStreamSynchronize(s));
+                std::memcpy(out_labels, h->pin_out.p, plab);
+                std::memcpy(out_dist, static_cast<const char*>(h->pin_out.p) + plab, pdst);
+            } else {
+                HIP_TRY(h, hipMemcpyAsync(out_labels, d_pl, plab, hipMemcpyDeviceToHost, s));
+                HIP_TRY(h, hipMemcpyAsync(out_dist, d_pd, pdst, hipMemcpyDeviceToHost, s));
+                HIP_TRY(h, hipStreamSynchronize(s));
+            }
+        }
+        rc = end_call(h, s);
+        if (rc) return rc;
+        if (!fits)
+            return fail(h, MLVDB_ERR_OVERFLOW, "range query: more hits in all than total_capacity; out_counts / out_offsets hold "
+                                               "the exact counts and the layout the hits need, out_labels / out_dist nothing");
+        if (hard_p)
+            return fail(h, MLVDB_ERR_UNSUPPORTED,
+                        "range query: a query has more than MLVDB_MAX_TOPK_PAGED hits; out_counts holds the exact counts, the "
+                        "outputs the nearest MLVDB_MAX_TOPK_PAGED");
+        for (int64_t i = 0; i < nq; ++i)
+            if (counts[i] > capacity)
+                return fail(h, MLVDB_ERR_OVERFLOW, "some query has more hits than `capacity`; out_counts holds the exact counts");
+        return MLVDB_OK;
+    }
     if (total_hits * 4 < nq * cap_eff) {
         if (total_hits > 0) {
             HIP_TRY(h, h->labels_in.ensure(((size_t)nq + 1) * sizeof(int64_t)));
@@ -1828,6 +1884,20 @@ int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float ra
                     "outputs the nearest MLVDB_MAX_TOPK_PAGED");
     if (over) return fail(h, MLVDB_ERR_OVERFLOW, "some query has more hits than `capacity`; out_counts holds the exact counts");
     return MLVDB_OK;
+}
+
+int mlvdb_range_batch(mlvdb_index* h, const float* queries, int64_t nq, float radius, int64_t capacity,
+                      int64_t* out_labels, float* out_dist, int64_t* out_counts) {
+    return guarded(h, [&]() -> int {
+    return range_batch_impl(h, queries, nq, radius, capacity, out_labels, out_dist, out_counts, nullptr, 0, false);
+    });
+}
+
+int mlvdb_range_batch_packed(mlvdb_index* h, const float* queries, int64_t nq, float radius, int64_t capacity,
+                             int64_t total_capacity, int64_t* out_labels, float* out_dist, int64_t* out_offsets,
+                             int64_t* out_counts) {
+    return guarded(h, [&]() -> int {
+    return range_batch_impl(h, queries, nq, radius, capacity, out_labels, out_dist, out_counts, out_offsets, total_capacity, true);
     });
 }
 

@@ -8,6 +8,7 @@ CPU engine in this package: tests inject the oracle's engine through ``Index(eng
 from __future__ import annotations
 
 import ctypes as C
+from collections.abc import Sequence
 from typing import List, Protocol, Tuple
 
 import numpy as np
@@ -42,6 +43,32 @@ class ScanEngine(Protocol):
               ) -> List[Tuple[np.ndarray, np.ndarray]]: ...
 
     def close(self) -> None: ...
+
+
+class RangeHits(Sequence):
+    """The answer of a range call: ``hits[i]`` is ``(labels int64[n_i], distances float32[n_i])`` of query i, nearest first --
+    views of the packed arrays ``labels`` / ``dist`` between ``offsets[i]`` and ``offsets[i + 1]`` (what the C ABI's packed
+    entry returns; nothing is copied per query)."""
+
+    __slots__ = ("labels", "dist", "offsets", "_off")
+
+    def __init__(self, labels: np.ndarray, dist: np.ndarray, offsets: np.ndarray) -> None:
+        self.labels, self.dist, self.offsets = labels, dist, offsets
+        self._off = offsets.tolist()
+
+    def __len__(self) -> int:
+        return len(self._off) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError("query index out of range")
+        a, b = self._off[i], self._off[i + 1]
+        return self.labels[a:b], self.dist[a:b]
 
 
 class HipScanEngine:
@@ -209,29 +236,38 @@ class HipScanEngine:
             C.c_void_p(counts_ptr), C.c_void_p(dist64_ptr or None), C.c_void_p(stream or None)), "search_batch_device")
 
     def range(self, queries: np.ndarray, radius: float, capacity: int, truncate: bool = False):
-        """Per query (labels, fp32 distances) of the live rows within ``radius``, nearest first.
+        """Per query (labels, fp32 distances) of the live rows within ``radius``, nearest first: a ``RangeHits`` sequence
+        (``hits[i]`` -> the two arrays of query i, views of the call's packed outputs).
 
         ``truncate=False``: ``capacity`` is an initial size; the call is repeated once with the exact largest count,
         so every hit comes back (up to MLVDB_MAX_TOPK_PAGED = 16384 per query, the most one call can rank: beyond
-        that the nearest 16384 are returned).  ``truncate=True``: at most ``capacity`` hits per query, the nearest."""
+        that the nearest 16384 are returned).  ``truncate=True``: at most ``capacity`` hits per query, the nearest.
+        Through ``mlvdb_range_batch_packed``: hit counts differ by orders of magnitude between queries, the packed arrays
+        hold the hits and nothing else (a first call with room for 256 hits per query on average; when the hits need
+        more, the call is repeated with the size the first one reported)."""
         queries = np.ascontiguousarray(queries, dtype=np.float32)
         if queries.ndim != 2 or queries.shape[1] != self.dim:
             raise RuntimeError(f"Wrong dimensionality of the vectors: got {queries.shape}, index dim {self.dim}")
         nq = queries.shape[0]
         capacity = max(1, min(int(capacity), _native.MAX_TOPK_PAGED))
+        total = min(nq * capacity, max(65_536, 256 * nq))
         while True:
-            labels = np.empty((nq, capacity), dtype=np.int64)
-            dist = np.empty((nq, capacity), dtype=np.float32)
-            counts = np.empty(nq, dtype=np.int64)
-            rc = self._check(self._lib.mlvdb_range_batch(self._h, queries.ctypes.data, nq, float(radius), capacity,
-                                                         labels.ctypes.data, dist.ctypes.data, counts.ctypes.data),
-                             "range_batch", allow=(_native.ERR_OVERFLOW,))
-            if rc == _native.OK or truncate or capacity == _native.MAX_TOPK_PAGED:
+            labels = np.empty(total, dtype=np.int64)
+            dist = np.empty(total, dtype=np.float32)
+            offsets = np.zeros(nq + 1, dtype=np.int64)
+            counts = np.zeros(nq, dtype=np.int64)
+            rc = self._check(self._lib.mlvdb_range_batch_packed(self._h, queries.ctypes.data, nq, float(radius), capacity, total,
+                                                                labels.ctypes.data, dist.ctypes.data, offsets.ctypes.data,
+                                                                counts.ctypes.data),
+                             "range_batch_packed", allow=(_native.ERR_OVERFLOW,))
+            if rc == _native.OK:
                 break
-            # exact hit counts are reported even on overflow: retry once, sized
-            capacity = min(int(counts.max()), _native.MAX_TOPK_PAGED)
-        got = np.minimum(counts, capacity)
-        return [(labels[i, :got[i]].copy(), dist[i, :got[i]].copy()) for i in range(nq)]
+            need_cap = capacity if truncate else min(max(int(counts.max(initial=0)), capacity), _native.MAX_TOPK_PAGED)
+            need_total = int(np.minimum(counts, need_cap).sum())
+            if need_cap == capacity and need_total <= total:
+                break  # per-query truncation was asked for (or the engine's limit reached): the outputs hold the nearest
+            capacity, total = need_cap, max(need_total, 1)
+        return RangeHits(labels, dist, offsets)
 
     def close(self) -> None:
         if getattr(self, "_h", None):

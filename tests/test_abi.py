@@ -107,6 +107,7 @@ def test_every_handle_entry_refuses_a_null_handle_with_a_status_code():
         "mlvdb_search_batch_ex": (null, buf, 1, 1, buf, buf, buf, buf, buf),
         "mlvdb_search_batch_device": (null, buf, 1, 1, buf, buf, buf, buf, None),
         "mlvdb_range_batch": (null, buf, 1, 1.0, 1, buf, buf, buf),
+        "mlvdb_range_batch_packed": (null, buf, 1, 1.0, 1, 1, buf, buf, buf, buf),
         "mlvdb_pair_distances": (null, buf, 1, buf, 1, buf, buf),
         "mlvdb_index_set_strategy": (null, 0),
         "mlvdb_index_set_profiling": (null, 0),

@@ -463,6 +463,67 @@ def test_range_with_more_hits_than_candidate_slots(strategy, d):
         assert np.abs(gd - wd).max(initial=0.0) <= SCORE_ATOL
 
 
+def test_range_packed_entry_equals_the_dense_one_and_reports_the_sizes_it_needs():
+    """mlvdb_range_batch_packed (ABI 6) against mlvdb_range_batch on the same queries: same hits, packed; a total_capacity that is
+    too small writes nothing but the counts and the layout (out_offsets[nq] = entries needed); a counting call passes NULL
+    outputs; a per-query capacity below a query's count returns its nearest hits and MLVDB_ERR_OVERFLOW."""
+    import ctypes as C
+
+    from mlvectordb_amd import _native
+
+    rows, qs = make_case(97, 50_000, 128, 24, dup=True)
+    dmat = exact_scan.exact_distances(qs, rows, "l2")
+    radius = float(np.float32(np.sort(dmat, axis=1)[:, 40].mean()))
+    want = exact_scan.range_query(qs, rows, radius, "l2")
+    sizes = np.array([len(w[0]) for w in want])
+    assert sizes.max() > 3 * max(1, sizes.min()) and sizes.sum() > 500
+    eng = HipScanEngine(128, "l2", device=0, strategy="filter")
+    try:
+        eng.append(rows)
+        lib, h, nq = eng._lib, eng.handle, qs.shape[0]
+        cap = int(sizes.max())
+        dl = np.full((nq, cap), -9, dtype=np.int64)
+        dd = np.zeros((nq, cap), dtype=np.float32)
+        dc = np.zeros(nq, dtype=np.int64)
+        assert lib.mlvdb_range_batch(h, qs.ctypes.data, nq, C.c_float(radius), cap, dl.ctypes.data, dd.ctypes.data, dc.ctypes.data) == 0
+        assert np.array_equal(dc, sizes)
+        total = int(sizes.sum())
+        pl = np.full(total, -9, dtype=np.int64)
+        pd = np.zeros(total, dtype=np.float32)
+        po = np.zeros(nq + 1, dtype=np.int64)
+        pc = np.zeros(nq, dtype=np.int64)
+        rc = lib.mlvdb_range_batch_packed(h, qs.ctypes.data, nq, C.c_float(radius), cap, total, pl.ctypes.data, pd.ctypes.data,
+                                          po.ctypes.data, pc.ctypes.data)
+        assert rc == 0 and np.array_equal(pc, sizes) and np.array_equal(po, np.concatenate([[0], np.cumsum(sizes)]))
+        for i in range(nq):
+            assert np.array_equal(pl[po[i]:po[i + 1]], dl[i, :sizes[i]]) and np.array_equal(pd[po[i]:po[i + 1]], dd[i, :sizes[i]])
+            assert np.array_equal(pl[po[i]:po[i + 1]], want[i][0])
+        # too small in all: nothing written, the layout reported
+        pl[:] = -9
+        po[:] = -1
+        rc = lib.mlvdb_range_batch_packed(h, qs.ctypes.data, nq, C.c_float(radius), cap, total - 1, pl.ctypes.data, pd.ctypes.data,
+                                          po.ctypes.data, pc.ctypes.data)
+        assert rc == _native.ERR_OVERFLOW and (pl == -9).all() and po[nq] == total and np.array_equal(pc, sizes)
+        # counting call
+        po[:] = -1
+        rc = lib.mlvdb_range_batch_packed(h, qs.ctypes.data, nq, C.c_float(radius), cap, 0, None, None, po.ctypes.data, pc.ctypes.data)
+        assert rc == _native.ERR_OVERFLOW and po[nq] == total and np.array_equal(pc, sizes)
+        # per-query capacity 5: the nearest 5 of each, exact counts, overflow status
+        rc = lib.mlvdb_range_batch_packed(h, qs.ctypes.data, nq, C.c_float(radius), 5, total, pl.ctypes.data, pd.ctypes.data,
+                                          po.ctypes.data, pc.ctypes.data)
+        assert rc == _native.ERR_OVERFLOW and np.array_equal(pc, sizes) and np.array_equal(np.diff(po), np.minimum(sizes, 5))
+        for i in range(nq):
+            assert np.array_equal(pl[po[i]:po[i + 1]], want[i][0][:5])
+        # the engine wrapper: every hit (it resizes by itself), and truncated
+        hits = eng.range(qs, radius, 3)
+        assert len(hits) == nq and all(np.array_equal(a[0], b[0]) for a, b in zip(hits, want))
+        cut = eng.range(qs, radius, 3, truncate=True)
+        assert all(np.array_equal(a[0], b[0][:3]) for a, b in zip(cut, want)) and cut[-1][0].size == min(3, sizes[-1])
+        assert [len(x[0]) for x in hits[2:5]] == sizes[2:5].tolist()
+    finally:
+        eng.close()
+
+
 def test_range_capacity_overflow_is_reported_then_resolved():
     rows, qs = make_case(91, 3000, 64, 4)
     eng = HipScanEngine(64, "l2", device=0)
