@@ -97,6 +97,7 @@ struct mlvdb_index {
     DevBuf qerr, rowerr;         // rounding errors of the bf16 images: per query / maximum over the rows (device scalar)
     // experimental int8 shadow (MLVDB_I8=1, cosine, ld % 256 == 0): built lazily at search time, rebuilt after any mutation
     DevBuf x8, rp8, rowerr8, qimg8, sq8;
+    DevBuf l2tag;  // l2: which pass scale the offsets plane behind rp8 ([0..3]) / rp8_masked ([4..7]) was computed for: filter_l2_offsets_kernel
     int64_t i8_rows = 0;      // rows [0, i8_rows) of the int8 shadow are current (0 after compact / reset / regrowth)
     float i8_err = 0.f;       // host copy of rowerr8 (read back whenever rows were converted)
     bool sqmin_fresh = false;  // fmisc was just (re)allocated: FilterArgs::sqmin[] not initialised yet
@@ -425,6 +426,19 @@ bool i8_eligible(const mlvdb_index* h) {
     return h->tn.i8 != 0 && (h->Xb || h->i8_only) && h->ld8 > 0;  // (tools/scan_ab.py switches I8 inside one process: set_tuning)
 }
 
+// The l2 offsets plane of a pair buffer is valid for the pairs it was computed from: whatever rewrites pairs forgets the tag
+// (slot 0: rp8, slot 1: rp8_masked); the next pass's filter_l2_offsets_kernel then recomputes the plane.
+int forget_l2_offsets(mlvdb_index* h, int slot, hipStream_t s) {
+    if (h->space != kSpaceL2) return MLVDB_OK;
+    if (!h->l2tag.p) {
+        HIP_TRY(h, h->l2tag.ensure(8 * sizeof(uint32_t)));
+        HIP_TRY(h, hipMemsetAsync(h->l2tag.p, 0, 8 * sizeof(uint32_t), s));
+        return MLVDB_OK;
+    }
+    HIP_TRY(h, hipMemsetAsync(h->l2tag.as<uint32_t>() + 4 * slot, 0, 4 * sizeof(uint32_t), s));
+    return MLVDB_OK;
+}
+
 // Bring the int8 shadow up to date (rows appended since the last pass).  Must run with the index's own norms in h->rn
 // (a row-mask search swaps them for a masked copy afterwards).
 int update_i8_shadow(mlvdb_index* h, hipStream_t s) {
@@ -439,10 +453,12 @@ int update_i8_shadow(mlvdb_index* h, hipStream_t s) {
     if (h->i8_rows == 0) {
         HIP_TRY(h, hipMemsetAsync(h->x8.p, 0, need_x8, s));
         HIP_TRY(h, hipMemsetAsync(h->rp8.p, 0xff, need_rp, s));  // NaN: not a row
+        if (int rc = forget_l2_offsets(h, 0, s)) return rc;
         HIP_TRY(h, hipMemsetAsync(h->rowerr8.p, 0, sizeof(float), s));
         HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->rowerr8.as<float>() + 1), 0x7f800000, 1, s));  // +inf
     }
     if (h->i8_rows < h->total) {
+        if (int rc = forget_l2_offsets(h, 0, s)) return rc;
         HIP_TRY(h, launch_shadow8_rows(h->X, h->rn, h->x8.p, h->rp8.as<float>(), h->rowerr8.as<float>(), h->i8_rows, h->total,
                                        h->ld, h->ld8, h->space, s));
         h->i8_rows = h->total;
@@ -470,7 +486,14 @@ int attach_i8(mlvdb_index* h, hipStream_t s, FilterArgs& fa) {
     fa.rp8 = h->mask_active ? h->rp8_masked.as<float>() : h->rp8.as<float>();  // a masked-out row is a NaN pair: "not a row"
     // l2: pairs + offsets through one buffer descriptor (32-bit offsets): 12 bytes per row must stay below 4 GB
     fa.rp8_cap = h->space == kSpaceL2 ? h->capacity : 0;  // (l2_int8_ok held: i8_bounds_usable)
-    if (fa.rp8_cap > 0) fa.l2c = 1;
+    if (fa.rp8_cap > 0) {
+        fa.l2c = 1;
+        if (!h->l2tag.p) {
+            int rc = forget_l2_offsets(h, 0, s);  // (allocates, zeroed)
+            if (rc) return rc;
+        }
+        fa.l2tag = h->tn.l2_offset_cache != 0 ? h->l2tag.as<uint32_t>() + (h->mask_active ? 4 : 0) : nullptr;
+    }
     fa.row_err8 = h->rowerr8.as<float>();
     fa.qimg8 = h->qimg8.p;
     fa.sq8 = h->sq8.as<float>();
@@ -1272,6 +1295,7 @@ int mlvdb_index_tombstone(mlvdb_index* h, const int64_t* labels, int64_t n, int6
                                        // a search on another stream may follow this call at once)
         tombstone_rp8_kernel<<<(unsigned)((n + 255) / 256), 256, 0, h->stream>>>(h->labels_in.as<int64_t>(), n, h->rp8.as<float>(), h->i8_rows, h->space == kSpaceL2 ? 1 : 0);
         HIP_TRY(h, hipGetLastError());
+        if (int rc2 = forget_l2_offsets(h, 0, h->stream)) return rc2;  // (a dead row changes its lane group's P0)
     }
     unsigned long long changed = 0;
     HIP_TRY(h, hipMemcpyAsync(&changed, h->counters.p, sizeof changed, hipMemcpyDeviceToHost, h->stream));
@@ -1614,6 +1638,8 @@ int mlvdb_search_batch_ex(mlvdb_index* h, const float* queries, int64_t nq, int3
         HIP_TRY(h, h->rp8_masked.ensure((size_t)h->capacity * (h->space == kSpaceL2 ? 3 : 2) * sizeof(float)));
         HIP_TRY(h, launch_mask_pairs(h->rp8.as<float>(), h->row_mask.as<uint8_t>(), h->rp8_masked.as<float>(), h->total,
                                      h->capacity, h->space == kSpaceL2 ? 1 : 0, h->stream));
+        rc = forget_l2_offsets(h, 1, h->stream);
+        if (rc) return rc;
         h->mask_pairs_ready = true;
     }
     float* const all_rows = h->rn;  // every kernel of the call reads the masked norms instead

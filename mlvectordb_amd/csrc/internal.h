@@ -78,6 +78,7 @@ inline hipError_t ensure_dynamic_lds(std::atomic<uint64_t>& done, const void* ke
     X(scan_dma, "SCAN_DMA", 1)         /* [AB] */                                                                       \
     X(scan_stag, "SCAN_STAG", 0)       /* [AB] */                                                                       \
     X(scan_diag, "SCAN_DIAG", 0)       /* make DIAG=1 builds */                                                         \
+    X(l2_offset_cache, "L2_OFFSET_CACHE", 1) /* l2: keep the offsets plane across passes of the same scale (0: recompute per pass) */ \
     X(exact_nt, "EXACT_NT", 1)                                                                                          \
     X(exact_nblk, "EXACT_NBLK", 0)                                                                                      \
     X(prefix_pf, "PREFIX_PF", 24)                                                                                       \
@@ -233,6 +234,7 @@ struct FilterArgs {
                             // per-row int32 offsets of the folded l2 admission test (filter_l2_offsets_kernel).  0 = none
     int32_t l2c;            // l2, common query scale for the pass: 0 = off
     float* l2c_out;         // l2: {SQ, KEq, KEr} of the pass, written by filter_l2_offsets_kernel, read by the l2c scan bodies
+    uint32_t* l2tag;        // l2: {pass scale the offsets plane behind rp8 holds (float bits), its rows, block counter, -} or nullptr
     float* rmaxq;           // l2: [256] largest raw component of each query of the pass (fused prep -> filter_prep8_l2c_kernel)
     const float* row_err8;  // device scalar: max over rows of |x - scale * x8| / |x| (rounded up)
     void* qimg8;            // int8 query image

@@ -324,6 +324,58 @@ def test_l2_batch_with_odd_query_norms_keeps_the_rest_on_the_filter():
         eng.close()
 
 
+def test_l2_offsets_plane_is_reused_across_passes_and_forgotten_on_every_mutation():
+    """The l2 offsets plane (filter_l2_offsets_kernel) is kept from one pass to the next while the pass scale stays in its grid
+    bin and the row pairs are untouched.  One engine, a sequence that would expose a stale plane: other queries of the same scale,
+    tombstones of current winners (a dead row changes its lane group's P0), queries at other scales (up, down, back), a row-mask
+    search between unmasked ones, appends, compaction -- every answer against the oracle, and the same sequence once more with
+    the plane recomputed per pass (L2_OFFSET_CACHE=0)."""
+    n, d, k = 90_001, 256, 10
+    rows, qs = make_case(5150, n, d, 48, dup=True)
+    extra = np.random.default_rng(5151).standard_normal((4_000, d)).astype(np.float32)
+    more_q = np.random.default_rng(5152).standard_normal((48, d)).astype(np.float32)
+    for cache in (1, 0):
+        eng = HipScanEngine(d, "l2", device=0, strategy="filter")
+        try:
+            eng.set_tuning(L2_OFFSET_CACHE=cache)
+            eng.append(rows)
+            dead = np.zeros(n, dtype=bool)
+
+            def check(q, tag, mask=None):
+                got = eng.search(q, k) if mask is None else eng.search(q, k, mask)
+                st = eng.last_stats()
+                assert st["strategy_used"] == 2 and st["bound_dtype"] == 2, (tag, st)
+                gone = dead.copy()
+                if mask is not None:
+                    gone |= mask == 0
+                assert_knn_matches(got, oracle_knn(q, rows, k, "l2", gone), f"l2 offsets cache={cache}: {tag}")
+                return got
+
+            first = check(qs, "first pass")
+            check(more_q, "other queries, same scale")
+            winners = np.unique(first[0][:, 0])
+            eng.tombstone(winners)
+            dead[winners] = True
+            check(qs, "after tombstoning the winners")
+            check(qs * 1.7, "scale up")
+            check(qs * 0.4, "scale down")
+            check(qs, "back")
+            mask = (np.random.default_rng(5153).random(n) < 0.5).astype(np.uint8)
+            check(qs, "row mask", mask)
+            check(more_q, "unmasked again")
+            check(more_q, "row mask, other queries", mask)
+            eng.append(extra)
+            rows2 = np.concatenate([rows, extra])
+            got = eng.search(qs, k)
+            assert_knn_matches(got, oracle_knn(qs, rows2, k, "l2", np.concatenate([dead, np.zeros(extra.shape[0], bool)])),
+                               f"l2 offsets cache={cache}: after an append")
+            old = eng.compact()
+            got = eng.search(more_q, k)
+            assert_knn_matches(got, oracle_knn(more_q, rows2[old], k, "l2"), f"l2 offsets cache={cache}: after compaction")
+        finally:
+            eng.close()
+
+
 def test_k_larger_than_live_rows_pads():
     rows, qs = make_case(51, 6, 64, 2)
     got, _ = run_hip(rows, qs, 10, "l2", "exact", deleted_mask(51, 6, 0.4))
