@@ -535,37 +535,8 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
     rc = prep_pass(h, s, fa, queries_raw + (size_t)q0 * h->dim, Qpad + (size_t)q0 * h->ld, qaux + q0, h->qerr.as<float>() + q0);
     if (rc) return rc;
     h->stats.bound_dtype = fa.X8 ? 2 : 1;
-    // ---- tried in round 3 for small batches on small corpora (BASELINE configs[1]: 1M x 768, batch 1), OFF by default
-    // (MLVDB_SMALL_BATCH=1): exact k-th best of a prefix of the fp32 rows (fp64 scan) -> ONE int8 scan of everything ->
-    // rescoring, instead of the rounds below.  Measured SLOWER (profiles/r03/small_batch_single_round_tried_1m.txt: 0.273 vs
-    // 0.248 ms at batch 1, 0.37-0.48 vs 0.27 ms at 4-8 queries): one scan launch takes exactly what the two rounds take
-    // together (138 us for 768 MB), the exact scan of a 12k-row prefix is a latency chain on 24 workgroups (57 us), and the
-    // ~3,500 candidates per query it leaves cost the ranking kernel 31 us -- more than the three 15 us refines it saves.
-    {
-        const bool small = fa.X8 && nq <= 8 && !h->mask_active && h->total <= (int64_t)2500000 && filter_narrow_ok(fa) &&
-                           h->tn.small_batch == 1;  // (2: the round-4 variant below)
-        if (small) {
-            const int64_t units = std::max<int64_t>(1, h->tn.small_batch_units);  // x 768 rows
-            const int64_t n_exact = std::min<int64_t>(h->total, units * kFilterTile);
-            HIP_TRY(h, h->seed_lab.ensure((size_t)kFilterQueries * k * sizeof(int64_t)));
-            HIP_TRY(h, h->seed_dist.ensure((size_t)kFilterQueries * k * sizeof(float)));
-            HIP_TRY(h, h->seed_cnt.ensure(kFilterQueries * sizeof(int32_t)));
-            HIP_TRY(h, h->seed_d64.ensure((size_t)kFilterQueries * k * sizeof(double)));
-            rc = run_exact(h, s, fa.Qpad, fa.qaux, nq, nullptr, 0, n_exact, k, h->seed_lab.as<int64_t>(), h->seed_dist.as<float>(),
-                           h->seed_cnt.as<int32_t>(), h->seed_d64.as<double>(), false);
-            if (rc) return rc;
-            HIP_TRY(h, launch_filter_seed_thr(fa, h->seed_d64.as<double>(), k, s));
-            rc = scan_event(h, s, true);
-            if (rc) return rc;
-            ScanInfo info;
-            HIP_TRY(h, launch_filter_scan(fa, 0, h->total, s, &info));  // every row, the prefix included: the lists must hold it too
-            rc = scan_event(h, s, false);
-            if (rc) return rc;
-            h->stats.scan_launches += 1;
-            h->stats.rows_scanned += h->total;
-            return finish_filter_pass(h, s, fa, q0, nq, k, out_labels, out_dist, out_counts, out_d64, defer_fallback);
-        }
-    }
+    // (Round 3 had tried a single scan round for <= 8 queries behind the generic exact scan of a 12k-row prefix: slower, 0.273 vs
+    // 0.248 ms at batch 1 -- profiles/r03/small_batch_single_round_tried_1m.txt.  Round 4's version for single queries follows.)
     // ---- one round for single queries on small corpora (round 4; SMALL_BATCH=0: the rounds below): the exact k-th best of an
     // 11,520-row prefix (prefix_exact_kernel all over the chip + the one-block selection) puts the threshold at quantile
     // k / 11,520; ONE scan launch over every row then appends ~total (k / 11,520) x band entries per query -- 1M x 768, k = 10:
@@ -576,7 +547,7 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
     {
         const int small_nq1 = std::max(0, std::min(1, h->tn.small_nq));  // (two queries: 0.214-0.220 vs 0.211-0.219 ms -- no gain)
         const int64_t m = 3 * kSeedRows;
-        const bool one_round = h->tn.small_batch == 2 && fa.X8 && nq <= small_nq1 && k <= 64 && !h->mask_active &&
+        const bool one_round = h->tn.small_batch != 0 && fa.X8 && nq <= small_nq1 && k <= 64 && !h->mask_active &&
                                filter_refine_can_fuse(fa) && h->tn.small_finish != 0 && h->tn.small_seed != 0 && h->total > 4 * m &&
                                (double)h->total * k * 6.0 <= 6000.0 * (double)m;
         if (one_round) {
