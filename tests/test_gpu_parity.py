@@ -330,10 +330,10 @@ def test_l2_offsets_plane_is_reused_across_passes_and_forgotten_on_every_mutatio
     tombstones of current winners (a dead row changes its lane group's P0), queries at other scales (up, down, back), a row-mask
     search between unmasked ones, appends, compaction -- every answer against the oracle, and the same sequence once more with
     the plane recomputed per pass (L2_OFFSET_CACHE=0)."""
-    n, d, k = 90_001, 256, 10
-    rows, qs = make_case(5150, n, d, 48, dup=True)
+    n, d, k = 50_001, 256, 10
+    rows, qs = make_case(5150, n, d, 24, dup=True)
     extra = np.random.default_rng(5151).standard_normal((4_000, d)).astype(np.float32)
-    more_q = np.random.default_rng(5152).standard_normal((48, d)).astype(np.float32)
+    more_q = np.random.default_rng(5152).standard_normal((24, d)).astype(np.float32)
     for cache in (1, 0):
         eng = HipScanEngine(d, "l2", device=0, strategy="filter")
         try:
