@@ -1035,9 +1035,12 @@ bool i8_bounds_usable(const mlvdb_index* h) { return h->i8_err <= (h->space == k
 // Is a filter body available for this index right now?  ld % 64 == 0: always (bf16 shadow, int8 shadow, or the fp32 rows
 // converted in registers).  Any other ld has only the int8 body: the (zero-padded) int8 shadow is brought up to date here
 // and its bounds must be usable (attach_i8's criterion: l2 / ip rows that quantise too badly go to the exact scan).
-int filter_ready(mlvdb_index* h, hipStream_t s, bool* ready) {
+bool use_filter(const mlvdb_index* h, int64_t nq, bool ready);
+
+int filter_ready(mlvdb_index* h, hipStream_t s, int64_t nq, bool* ready) {
     *ready = false;
     if (h->strategy == MLVDB_STRATEGY_EXACT || h->total == 0) return MLVDB_OK;
+    if (!use_filter(h, nq, true)) return MLVDB_OK;  // AUTO would take the exact scan anyway: no shadow is built for this call
     if (filter_supported(h->ld)) {
         *ready = true;
         return MLVDB_OK;
@@ -1057,6 +1060,13 @@ bool use_filter(const mlvdb_index* h, int64_t nq, bool ready) {
     if (h->strategy == MLVDB_STRATEGY_EXACT || !ready) return false;
     if (h->strategy == MLVDB_STRATEGY_FILTER) return true;
     const bool shadowed = h->Xb != nullptr || h->i8_only;
+    // dim < 64: the padded int8 shadow (256 B per row) is wider than the fp32 rows (4 ld B), and the exact scan of such short
+    // rows is bound by its per-row work, not by HBM (4M rows, d = 16 / 32 / 48: 0.16-0.21 ms for one query, 0.30-0.36 for 4,
+    // 0.45-0.58 ms per 8-query pass; the int8 chain: 0.28 ms for 5-64 queries, 0.37 ms for 256; 500k rows x 32: 0.12-0.16
+    // against 0.17 / 0.20 / 0.35 / 1.67 ms for 5 / 8 / 16 / 256 queries -- profiles/r04/dim_ab_small_dims_{4m,500k}.txt).
+    // Up to 4 queries the exact scan wins at any size; beyond, the filter wins once the exact passes (one per 8 queries)
+    // cover some 400k rows between them.
+    if (h->i8_only && h->ld8 >= 4 * h->ld) return nq > 4 && h->total >= 32768 && (nq + 7) / 8 * h->total >= 400000;
     if (nq >= 12 || (nq >= 8 && shadowed)) return h->total >= 32768;
     // small batches: the narrow filter kernel streams the bf16 shadow, half the bytes of the exact fp32 scan; below
     // ~125k rows of 768 columns the exact scan's two launches win (profiles/r01/small_batch_ab_crossover.txt)
@@ -1136,14 +1146,15 @@ int mlvdb_index_create(int device, int32_t dim, int32_t space, int64_t capacity_
     h->tn = tuning_from_env();  // the one moment the environment is consulted
     {
         // Which shadow the index keeps (decided here, once).  The int8 shadow has its own width ld8 = round_up(ld, 256), zero
-        // padded -- zero columns change neither a dot product nor a norm -- so every dim >= 64 gets the int8 body (round 4;
-        // I8_PAD=0: only dim % 256 == 0, round 3).  It is the only shadow wherever it streams fewer bytes per row than the
+        // padded -- zero columns change neither a dot product nor a norm -- so every dim gets the int8 body (round 4; dim < 64
+        // too: there the shadow is wider than the fp32 rows, it is built by the first batch large enough to want it, see
+        // use_filter; I8_PAD=0: only dim % 256 == 0, round 3).  It is the only shadow wherever it streams fewer bytes per row than the
         // bf16 one would (ld8 < 2 ld) or no bf16 body exists (ld % 64 != 0): seeding pass, small batches, scans, range and
         // row-mask searches all run on it.  ld = 64 / 128 keep the bf16 shadow (same bytes, tighter bounds).
         // SHADOW_BF16=1 (MLVDB_SHADOW=bf16) keeps the bf16 shadow as well (the bf16 bodies for A/B, I8=0).
         const Tuning& tn = h->tn;
         h->ld8 = 0;
-        if (!tn.no_shadow && dim >= 64) {
+        if (!tn.no_shadow) {
             const int32_t cand = (h->ld + 255) / 256 * 256;
             if (cand == h->ld || (tn.i8_pad && (cand < 2 * h->ld || !filter_supported(h->ld)))) h->ld8 = cand;
         }
@@ -1452,7 +1463,7 @@ static int search_device_impl(mlvdb_index* h, const float* queries_device, int64
     h->counters_stream = s;
     HIP_TRY(h, h->qerr.ensure((size_t)nq * sizeof(float)));
     bool ready = false;
-    rc = filter_ready(h, s, &ready);
+    rc = filter_ready(h, s, nq, &ready);
     if (rc) return rc;
     const bool filt = k <= MLVDB_MAX_TOPK && use_filter(h, nq, ready);
     if (!filt && k <= MLVDB_MAX_TOPK)  // (the filter passes prepare their own queries: one fused launch each)
@@ -1603,7 +1614,7 @@ int mlvdb_search_batch_ex(mlvdb_index* h, const float* queries, int64_t nq, int3
     // the int8 shadow serves masked searches too: bring it up to date with the index's own norms, then mask a copy of its
     // row pairs (8 bytes per row) exactly like the norms
     h->mask_pairs_ready = false;
-    if (i8_eligible(h)) {
+    if (i8_eligible(h) && h->strategy != MLVDB_STRATEGY_EXACT && use_filter(h, nq, true)) {  // (not for a call the exact scan takes)
         rc = update_i8_shadow(h, h->stream);
         if (rc) return rc;
         HIP_TRY(h, h->rp8_masked.ensure((size_t)h->capacity * (h->space == kSpaceL2 ? 3 : 2) * sizeof(float)));
@@ -1675,7 +1686,7 @@ static int range_batch_impl(mlvdb_index* h, const float* queries, int64_t nq, fl
     HIP_TRY(h, hipMemcpyAsync(h->io_q.p, h->pin_in.p, (size_t)nq * h->dim * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_TRY(h, h->qerr.ensure((size_t)nq * sizeof(float)));
     bool ready = false;
-    rc = filter_ready(h, s, &ready);
+    rc = filter_ready(h, s, nq, &ready);
     if (rc) return rc;
     const bool filt = use_filter(h, nq, ready);
     if (!filt)  // (the filter passes prepare their own queries: one fused launch each)
@@ -1938,7 +1949,7 @@ int mlvdb_index_set_strategy(mlvdb_index* h, int32_t strategy) {
     if (!h) return fail(nullptr, MLVDB_ERR_INVALID_ARG, "null index handle");
     if (strategy < 0 || strategy > 2) return fail(h, MLVDB_ERR_INVALID_ARG, "unknown strategy");
     if (strategy == MLVDB_STRATEGY_FILTER && !filter_supported(h->ld) && h->ld8 == 0)
-        return fail(h, MLVDB_ERR_UNSUPPORTED, "filter strategy needs dim >= 64 (or an index created with a shadow)");
+        return fail(h, MLVDB_ERR_UNSUPPORTED, "filter strategy needs an index created with a shadow (NO_SHADOW / I8_PAD=0 took it away)");
     h->strategy = strategy;
     return MLVDB_OK;
     });

@@ -1,7 +1,7 @@
 """Seeded shape fuzzing of the GPU path against the oracle (AUTO strategy, as a caller would use it).
 
-Each case draws corpus size, dimension (>= 64: the int8 filter on a shadow zero-padded to a multiple of 256 columns -- 64 and
-128 keep the bf16 shadow --; smaller dimensions take the exact scan), batch size (1 .. several 256-query passes), k (to 300:
+Each case draws corpus size, dimension (the int8 filter on a shadow zero-padded to a multiple of 256 columns -- 64 and
+128 keep the bf16 shadow --; below 64 the exact scan keeps the batches that stream fewer bytes that way), batch size (1 .. several 256-query passes), k (to 300:
 big-k passes), space, tombstone fraction and append chunking from a seeded generator, so the cases are the same on every run.  Bar: ids bit-exact, scores within 1e-5 (tests/helpers.py).
 """
 import numpy as np

@@ -118,8 +118,6 @@ def test_committed_golden_vectors(name, strategy):
 
     g = np.load(GOLDEN / f"{name}.npz")
     meta = json.loads(str(g["meta"]))
-    if strategy == "filter" and meta["d"] < 64:
-        pytest.skip("the filter path needs dim >= 64 (an int8 shadow padded to 256 columns); AUTO routes smaller dims to the exact scan")
     rows, qs, deleted = regenerate_inputs(meta)
     (labels, dist, counts), _ = run_hip(rows, qs, meta["k"], meta["space"], strategy, deleted)
     assert np.array_equal(labels, g["labels"]) and np.array_equal(counts, g["counts"])
@@ -251,11 +249,12 @@ def test_int8_only_shadow_matches_oracle(space, shadow, monkeypatch):
 
 
 @pytest.mark.parametrize("space", ["l2", "cosine", "ip"])
-@pytest.mark.parametrize("d", [65, 100, 300, 384, 1000])
+@pytest.mark.parametrize("d", [3, 20, 48, 65, 100, 300, 384, 1000])
 def test_any_dim_runs_on_the_zero_padded_int8_shadow(space, d):
     """the reference takes any dim from the first vector (index.py:54).  The int8 shadow is padded with zero
-    columns to a multiple of 256 (they change neither a dot product nor a norm), so d = 100 / 300 / 384 / 1000 run the int8
-    body: 256-query passes, 1-8 queries (narrow kernel), row masks, range queries, appends in pieces, tombstones, compaction."""
+    columns to a multiple of 256 (they change neither a dot product nor a norm), so d = 100 / 300 / 384 / 1000 -- and d < 64,
+    where the shadow is wider than the rows -- run the int8 body: 256-query passes, 1-8 queries (narrow kernel), row masks,
+    range queries, appends in pieces, tombstones, compaction."""
     n = 60_001 if d <= 384 else 30_001
     rows, qs = make_case(700 + d, n, d, 44, dup=True)
     deleted = deleted_mask(17, n, 0.07)
@@ -266,11 +265,16 @@ def test_any_dim_runs_on_the_zero_padded_int8_shadow(space, d):
         eng.tombstone(np.nonzero(deleted)[0])
         got = eng.search(qs, 10)
         st = eng.last_stats()
-        assert st["strategy_used"] == 2 and st["bound_dtype"] == 2 and st["fallback_queries"] == 0, st
+        # l2 / ip rows of a few columns quantise too coarsely for the index-wide error criterion (a short row beside a long one
+        # in its scale group: relative error > 0.03): such an index keeps to the exact scan, whatever strategy was asked for
+        i8 = st["strategy_used"] == 2
+        assert i8 or (d < 64 and space != "cosine"), st
+        # (d = 3: nearly every row of the top 10 ties within the int8 band -- a query may take its exact fallback)
+        assert not i8 or (st["bound_dtype"] == 2 and (st["fallback_queries"] == 0 or d < 16)), st
         assert_knn_matches(got, oracle_knn(qs, rows, 10, space, deleted), f"padded-int8/{space}/d{d}")
         small = eng.search(qs[:3], 7)
         st = eng.last_stats()
-        assert st["strategy_used"] == 2 and st["bound_dtype"] == 2, st
+        assert not i8 or (st["strategy_used"] == 2 and st["bound_dtype"] == 2), st
         assert_knn_matches(small, oracle_knn(qs[:3], rows, 7, space, deleted), f"padded-int8-narrow/{space}/d{d}")
         mask = (np.arange(n) % 4 != 1).astype(np.uint8)
         gm = eng.search(qs[:12], 10, mask)
@@ -283,6 +287,32 @@ def test_any_dim_runs_on_the_zero_padded_int8_shadow(space, d):
         assert_knn_matches(eng.search(qs[:16], 10), oracle_knn(qs[:16], rows[old], 10, space), f"padded-int8-compact/{space}/d{d}")
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("d", [16, 32, 40])
+def test_auto_routes_small_dims_by_measured_cost(d):
+    """dim < 64: the padded int8 shadow (256 B per row) is wider than the fp32 rows and the exact scan of short rows is cheap per
+    pass, so AUTO keeps small batches on the exact scan -- without ever building the shadow for them -- and sends a batch
+    through the int8 body once its exact passes (one per 8 queries) would cover about a million rows
+    (profiles/r04/dim_ab_small_dims_4m.txt).  Both answers are the oracle's."""
+    n = 40_000
+    rows, qs = make_case(900 + d, n, d, 256, dup=True)
+    for space in ("cosine", "l2"):
+        eng = HipScanEngine(d, space, device=0)
+        try:
+            eng.append(rows)
+            for nq in (3, 16, 64):  # 1, 2, 8 exact passes over 40k rows
+                few = eng.search(qs[:nq], 10)
+                st = eng.last_stats()
+                assert st["strategy_used"] == 1, (nq, st)
+                assert_knn_matches(few, oracle_knn(qs[:nq], rows, 10, space), f"auto-small-dim-exact/{space}/d{d}/nq{nq}")
+            many = eng.search(qs, 10)   # 32 passes x 40k rows
+            st = eng.last_stats()
+            # (l2 rows of 16 columns may fail the index-wide quantisation criterion: then the exact scan keeps every batch)
+            assert (st["strategy_used"] == 2 and st["bound_dtype"] == 2) or (space == "l2" and d < 32), st
+            assert_knn_matches(many, oracle_knn(qs, rows, 10, space), f"auto-small-dim-int8/{space}/d{d}")
+        finally:
+            eng.close()
 
 
 def test_l2_batch_with_odd_query_norms_keeps_the_rest_on_the_filter():
