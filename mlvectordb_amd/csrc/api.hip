@@ -100,6 +100,7 @@ struct mlvdb_index {
     DevBuf l2tag;  // l2: which pass scale the offsets plane behind rp8 ([0..3]) / rp8_masked ([4..7]) was computed for: filter_l2_offsets_kernel
     int64_t i8_rows = 0;      // rows [0, i8_rows) of the int8 shadow are current (0 after compact / reset / regrowth)
     float i8_err = 0.f;       // host copy of rowerr8 (read back whenever rows were converted)
+    uint32_t i8_odd_groups = 0;  // ... and of its third word: 8-row scale groups whose largest row error exceeds 0.03
     bool sqmin_fresh = false;  // fmisc was just (re)allocated: FilterArgs::sqmin[] not initialised yet
     bool mask_active = false;  // h->rn is a masked copy (mlvdb_search_batch_filtered)
     bool mask_pairs_ready = false;  // ... and rp8_masked holds the masked copy of the int8 shadow's row pairs
@@ -447,7 +448,7 @@ int update_i8_shadow(mlvdb_index* h, hipStream_t s) {
     if (h->x8.bytes < need_x8 || h->rp8.bytes < need_rp || !h->rowerr8.p) {
         HIP_TRY(h, h->x8.ensure(need_x8));
         HIP_TRY(h, h->rp8.ensure(need_rp));
-        HIP_TRY(h, h->rowerr8.ensure(2 * sizeof(float)));  // {largest relative row error, smallest row norm}
+        HIP_TRY(h, h->rowerr8.ensure(4 * sizeof(float)));  // {largest relative row error, smallest row norm, odd groups (u32)}
         h->i8_rows = 0;
     }
     if (h->i8_rows == 0) {
@@ -456,14 +457,18 @@ int update_i8_shadow(mlvdb_index* h, hipStream_t s) {
         if (int rc = forget_l2_offsets(h, 0, s)) return rc;
         HIP_TRY(h, hipMemsetAsync(h->rowerr8.p, 0, sizeof(float), s));
         HIP_TRY(h, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->rowerr8.as<float>() + 1), 0x7f800000, 1, s));  // +inf
+        HIP_TRY(h, hipMemsetAsync(h->rowerr8.as<float>() + 2, 0, sizeof(uint32_t), s));
     }
     if (h->i8_rows < h->total) {
         if (int rc = forget_l2_offsets(h, 0, s)) return rc;
         HIP_TRY(h, launch_shadow8_rows(h->X, h->rn, h->x8.p, h->rp8.as<float>(), h->rowerr8.as<float>(), h->i8_rows, h->total,
                                        h->ld, h->ld8, h->space, s));
         h->i8_rows = h->total;
-        HIP_TRY(h, hipMemcpyAsync(&h->i8_err, h->rowerr8.p, sizeof(float), hipMemcpyDeviceToHost, s));
+        uint32_t words[3] = {0u, 0u, 0u};
+        HIP_TRY(h, hipMemcpyAsync(words, h->rowerr8.p, sizeof words, hipMemcpyDeviceToHost, s));
         HIP_TRY(h, hipStreamSynchronize(s));
+        std::memcpy(&h->i8_err, &words[0], sizeof(float));
+        h->i8_odd_groups = words[2];
     }
     return MLVDB_OK;
 }
@@ -585,7 +590,9 @@ int run_filter_pass(mlvdb_index* h, hipStream_t s, const float* queries_raw, flo
         // puts all 3840 bounds of every query into the lists + the exact-threshold refine over them; the prefix rows
         // then belong to the first scan round.  Slower: 2.16 vs 2.04 ms per 256-query wave, 0.303 vs 0.288 ms at batch 1
         // (3840 x 768 x 256 fp64 multiply-adds are not free); the dense pass stays the default.
-        const bool seed_exact = h->tn.seed_exact == 1;
+        // (l2 index with a few badly quantising rows: the dense int8 pass would bound every seed row with the index-wide error,
+        // and those inflated bounds then crowd the refines' picks -- the threshold stalls at the seed's quantile)
+        const bool seed_exact = h->tn.seed_exact == 1 || (fa.X8 && h->space == kSpaceL2 && h->i8_err > 0.03f);
         // Batches of 1-2 queries (round 3): the exact k-th best of the prefix by a kernel made for it (one 16-row group per
         // wave all over the chip + a one-block selection of the k-th: 8 + 10 us) instead of the dense int8 pass + exact-threshold refine (7 + 15.5 us
         // of latency chains at batch 1); the prefix rows then belong to the first scan round.  MLVDB_SMALL_SEED=0: the dense pass.
@@ -1030,7 +1037,20 @@ __global__ void range_resolve_kernel(uint32_t* overflow, const uint32_t* cnt, co
 bool l2_int8_ok(const mlvdb_index* h) {
     return h->space != kSpaceL2 || (h->tn.scan_l2e && h->tn.scan_l2c && (uint64_t)h->capacity * 12ull < 0xfff00000ull);
 }
-bool i8_bounds_usable(const mlvdb_index* h) { return h->i8_err <= (h->space == kSpaceCosine ? 0.5f : 0.03f) && l2_int8_ok(h); }
+// One scale per row (l2 / ip: per group of 8 rows): a row with an outlier component quantises badly.  Cosine bounds carry every
+// row's own error (any index-wide maximum up to 0.5 will do).  ip bounds use the index-wide maximum: beyond 0.03 (typical data:
+// 0.008-0.015) they would admit everything.  l2 bounds carry per-group errors (round 4), so a FEW odd rows cost only their own
+// groups: the index stays on the int8 shadow while at most 64 + 0.05 % of its rows sit in groups above 0.03 (and the worst
+// stays under I8_ERR_L2 / 1000); such a pass seeds its thresholds exactly (run_filter_pass) because the dense int8 seeding
+// pass does use the index-wide maximum.  profiles/r04/outlier_row_ab_4m.txt: 5 rows with a 40-sigma component among 4M x 768
+// made every l2 wave 3.3 x slower (fp32 rows converted in registers), 54 x on d = 300 (exact scan).
+bool i8_bounds_usable(const mlvdb_index* h) {
+    if (!l2_int8_ok(h)) return false;
+    if (h->space == kSpaceCosine) return h->i8_err <= 0.5f;
+    if (h->i8_err <= 0.03f) return true;
+    if (h->space == kSpaceIp) return h->i8_err <= 0.001f * (float)h->tn.i8_err_ip;
+    return h->i8_err <= 0.001f * (float)h->tn.i8_err_l2 && (int64_t)h->i8_odd_groups * 8 <= 64 + h->total / 2000;
+}
 
 // Is a filter body available for this index right now?  ld % 64 == 0: always (bf16 shadow, int8 shadow, or the fp32 rows
 // converted in registers).  Any other ld has only the int8 body: the (zero-padded) int8 shadow is brought up to date here

@@ -1687,6 +1687,7 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
         bg = __builtin_fmaxf(bg, __shfl_xor(bg, 1));
         bg = __builtin_fmaxf(bg, __shfl_xor(bg, 2));
         const float sg = gmax > 0.f ? gmax / 127.0f : 1.0f;  // (= the sx every live row of the group was quantised with)
+        if (g == 0 && (r & 3) == 0 && bg > 0.03f) atomicAdd(row_err8 + 2, 1u);  // odd groups (api.hip: i8_bounds_usable)
         if (g == 0) {
             reinterpret_cast<float2*>(rp8)[(slab * 2) * kPanelRows + r] = make_float2(sg, nrm[0]);
             reinterpret_cast<float2*>(rp8)[(slab * 2 + 1) * kPanelRows + r] = make_float2(bg, nrm[1]);
