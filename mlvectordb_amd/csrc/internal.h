@@ -39,7 +39,7 @@ inline hipError_t ensure_dynamic_lds(std::atomic<uint64_t>& done, const void* ke
     X(no_shadow, "NO_SHADOW", 0)       /* creation: no shadow at all (the filter converts fp32 rows in registers) */   \
     X(shadow_bf16, "SHADOW_BF16", 0)   /* creation: keep the bf16 shadow beside the int8 one (MLVDB_SHADOW=bf16) */    \
     X(i8_pad, "I8_PAD", 1)             /* creation: int8 shadow zero-padded to a multiple of 256 columns for any dim */\
-    X(i8_err_l2, "I8_ERR_L2", 250)     /* l2: largest relative row error (thousandths) of the FEW odd groups an int8 index may hold (30: none) */ \
+    X(i8_err_l2, "I8_ERR_L2", 1100)    /* l2: largest relative row error (thousandths) of the FEW odd groups an int8 index may hold (30: none; a row quantised to all zeros has 1.0) */ \
     X(i8_err_ip, "I8_ERR_IP", 30)      /* ip: largest index-wide relative row error (thousandths) the int8 bounds are used with */ \
     X(small_batch, "SMALL_BATCH", 1)   /* one query on a small corpus: ONE scan round after an 11,520-row exact prefix (0: the rounds) */ \
     X(small_seed, "SMALL_SEED", 1)     /* 1-2 queries: exact prefix seed */                                             \

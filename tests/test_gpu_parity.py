@@ -328,6 +328,7 @@ def test_l2_index_with_a_few_badly_quantising_rows_stays_on_the_int8_shadow(d):
     odd = [1_001, 30_003, 90_007, 110_011]
     for i in odd:
         rows[i, i % d] = 40.0
+    rows[110_011, 7] = 1.0e6   # (its 7 neighbours quantise to zeros: relative error 1, the bound is Cauchy-Schwarz's)
     eng = HipScanEngine(d, "l2", device=0, strategy="filter")
     try:
         eng.append(rows[:70_000])

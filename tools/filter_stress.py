@@ -17,6 +17,10 @@ ap.add_argument("--max-rows", type=int, default=200_000)
 ap.add_argument("--batches", default="1,3,8,9,40,70,130,256,300", help="batch sizes drawn from")
 ap.add_argument("--dims", default="256,512,768,1024,320,128,100,300,384,1000", help="dimensions drawn from (round 4: any dim >= 64 runs the int8 body on a zero-padded shadow)")
 ap.add_argument("--ks", default="1,5,10,64,100,300", help="top_k drawn from (round 4: > 64 = big-k passes)")
+ap.add_argument("--spaces", default="cosine,l2,ip")
+ap.add_argument("--kinds", default="gauss,clustered,heavy,sparse,peaky,norms",
+                help="distributions drawn from; fewodd = Gaussian with a handful of rows that carry one 10-100 sigma component "
+                     "(an l2 index keeps its int8 bounds with few such rows since round 4: exact seed, per-group errors)")
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 
@@ -39,10 +43,17 @@ def draw(kind, n, d):
         return x
     if kind == "norms":
         return (rng.standard_normal((n, d)) * np.exp(rng.uniform(-6, 6, (n, 1)))).astype(np.float32)
+    if kind == "fewodd":
+        x = rng.standard_normal((n, d), dtype=np.float32)
+        m = int(rng.integers(1, 1 + max(1, min(60, n // 3000))))
+        at = rng.integers(0, min(n, 3840) if rng.random() < 0.3 else n, m)   # (sometimes among the seed rows)
+        mag = rng.uniform(10, 100, m) * rng.choice([1.0, 1.0, 1.0, 30.0, 1.0e4], m)   # (the neighbours of a 1e6 row quantise to zeros)
+        x[at, rng.integers(0, d, m)] = (mag * rng.choice([-1.0, 1.0], m)).astype(np.float32)
+        return x
     raise ValueError(kind)
 
 
-KINDS = ["gauss", "clustered", "heavy", "sparse", "peaky", "norms"]
+KINDS = args.kinds.split(",")
 bad = 0
 t0 = time.time()
 for case in range(args.cases):
@@ -52,7 +63,7 @@ for case in range(args.cases):
     n = max(n, 2 * 300)
     nq = int(rng.choice([int(x) for x in args.batches.split(",")]))
     k = int(rng.choice([int(x) for x in args.ks.split(",")]))
-    space = str(rng.choice(["cosine", "l2", "ip"]))
+    space = str(rng.choice(args.spaces.split(",")))
     rows = draw(kind, n, d)
     qs = draw(qkind, nq, d)
     if rng.random() < 0.3:  # queries that are (noisy) copies of rows: exact and near matches
