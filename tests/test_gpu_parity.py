@@ -953,11 +953,12 @@ def test_int8_shadow_follows_appends_tombstones_compaction_and_masks(space, d, n
         eng.close()
 
 
-@pytest.mark.parametrize("space,dtype", [("cosine", 2), ("l2", 1)])
+@pytest.mark.parametrize("space,dtype", [("cosine", 2), ("l2", 2), ("ip", 1)])
 def test_int8_shadow_and_rows_with_outlier_components(space, dtype):
     """One scale per row: a row with one component ~30x the others has a large int8 error (its scale is set by the
-    outlier, its norm is not).  Cosine bounds carry every row's own error, so only those rows are admitted more often;
-    l2 / ip use the index-wide maximum and keep to the bf16 bounds (relative per component).  Same ids either way."""
+    outlier, its norm is not).  Cosine bounds carry every row's own error, so only those rows are admitted more often; l2 bounds
+    carry per-group errors (round 4: until then l2 left the int8 shadow here, bound_dtype 1); ip still uses the index-wide
+    maximum and keeps to the fp32-in-register / bf16 bounds (relative per component).  Same ids either way."""
     rows, qs = make_case(77, 20_000, 768, 24)
     rows[123, 5] = 30.0
     rows[9_000, 700] = -25.0
