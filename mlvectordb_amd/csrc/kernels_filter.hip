@@ -1592,7 +1592,8 @@ __device__ __forceinline__ int64_t layout_offset_i8(int64_t row, int32_t col, in
 // max_j(b_j K) >= T) as sharp as the 8 exact tests it stands for.
 __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const float* rn, int8_t* X8, float* rp8,
                                                            unsigned int* row_err8, int64_t slab_begin, int64_t slab_end,
-                                                           int64_t panel_end, int32_t ld, int32_t ld8, int32_t space) {
+                                                           int64_t panel_end, int64_t full_slabs, int32_t ld, int32_t ld8,
+                                                           int32_t space) {
     const int lane = threadIdx.x & 63;
     const int64_t slab = slab_begin + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slab >= slab_end) return;
@@ -1687,7 +1688,9 @@ __global__ __launch_bounds__(256) void shadow8_rows_kernel(const float* X, const
         bg = __builtin_fmaxf(bg, __shfl_xor(bg, 1));
         bg = __builtin_fmaxf(bg, __shfl_xor(bg, 2));
         const float sg = gmax > 0.f ? gmax / 127.0f : 1.0f;  // (= the sx every live row of the group was quantised with)
-        if (g == 0 && (r & 3) == 0 && bg > 0.03f) atomicAdd(row_err8 + 2, 1u);  // odd groups (api.hip: i8_bounds_usable)
+        // odd groups (api.hip: i8_bounds_usable).  Counted once: when the slab is complete -- a partly filled last slab is
+        // converted again by the next update (single-row inserts: up to 31 times) and counts then.
+        if (g == 0 && (r & 3) == 0 && bg > 0.03f && slab < full_slabs) atomicAdd(row_err8 + 2, 1u);
         if (g == 0) {
             reinterpret_cast<float2*>(rp8)[(slab * 2) * kPanelRows + r] = make_float2(sg, nrm[0]);
             reinterpret_cast<float2*>(rp8)[(slab * 2 + 1) * kPanelRows + r] = make_float2(bg, nrm[1]);
@@ -1828,7 +1831,8 @@ hipError_t launch_shadow8_rows(const float* X, const float* rn, void* X8, float*
     const int64_t sb = row_begin / (2 * kPanelRows), se = (pe + 1) / 2;
     if (se <= sb) return hipSuccess;
     shadow8_rows_kernel<<<(unsigned)((se - sb + 3) / 4), 256, 0, s>>>(X, rn, static_cast<int8_t*>(X8), rp8,
-                                                                       reinterpret_cast<unsigned int*>(row_err8), sb, se, pe, ld, ld8, space);
+                                                                       reinterpret_cast<unsigned int*>(row_err8), sb, se, pe,
+                                                                       row_end / (2 * kPanelRows), ld, ld8, space);
     return hipGetLastError();
 }
 

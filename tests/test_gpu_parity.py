@@ -359,6 +359,21 @@ def test_l2_index_with_a_few_badly_quantising_rows_stays_on_the_int8_shadow(d):
         assert np.array_equal(old[0], got[0]) and np.array_equal(old[1], got[1])
     finally:
         eng.close()
+    # rows trickling in one at a time with a search after each: the partly filled last slab -- here with an odd row in it -- is
+    # converted again by every update, and its odd group must be counted once, not 31 times (the index would leave the shadow)
+    eng = HipScanEngine(d, "l2", device=0, strategy="filter")
+    try:
+        base = 50_016
+        trickle = rows[:base + 31].copy()
+        trickle[base + 1, 3] = 40.0
+        eng.append(trickle[:base])
+        for i in range(31):
+            eng.append(trickle[base + i: base + i + 1])
+            got = eng.search(qs[:9], 10)
+        assert eng.last_stats()["bound_dtype"] == 2
+        assert_knn_matches(got, oracle_knn(qs[:9], trickle, 10, "l2"), f"odd-rows-trickle/l2/d{d}")
+    finally:
+        eng.close()
     many = rows.copy()
     for i in range(0, n, 50):
         many[i, i % d] = 40.0
