@@ -448,7 +448,7 @@ int update_i8_shadow(mlvdb_index* h, hipStream_t s) {
     if (h->x8.bytes < need_x8 || h->rp8.bytes < need_rp || !h->rowerr8.p) {
         HIP_TRY(h, h->x8.ensure(need_x8));
         HIP_TRY(h, h->rp8.ensure(need_rp));
-        HIP_TRY(h, h->rowerr8.ensure(4 * sizeof(float)));  // {largest relative row error, smallest row norm, odd groups (u32)}
+        HIP_TRY(h, h->rowerr8.ensure(4 * sizeof(float)));  // {largest relative row error, smallest row norm, odd groups (u32), -}
         h->i8_rows = 0;
     }
     if (h->i8_rows == 0) {
@@ -1039,11 +1039,13 @@ bool l2_int8_ok(const mlvdb_index* h) {
 }
 // One scale per row (l2 / ip: per group of 8 rows): a row with an outlier component quantises badly.  Cosine bounds carry every
 // row's own error (any index-wide maximum up to 0.5 will do).  ip bounds use the index-wide maximum: beyond 0.03 (typical data:
-// 0.008-0.015) they would admit everything.  l2 bounds carry per-group errors (round 4), so a FEW odd rows cost only their own
-// groups: the index stays on the int8 shadow while at most 64 + 0.05 % of its rows sit in groups above 0.03 (and the worst
-// stays under I8_ERR_L2 / 1000); such a pass seeds its thresholds exactly (run_filter_pass) because the dense int8 seeding
-// pass does use the index-wide maximum.  profiles/r04/outlier_row_ab_4m.txt: 5 rows with a 40-sigma component among 4M x 768
-// made every l2 wave 3.3 x slower (fp32 rows converted in registers), 54 x on d = 300 (exact scan).
+// 0.008-0.015) they would admit everything (I8_ERR_IP, thousandths).  l2 bounds carry per-group errors (round 4), so a FEW odd
+// rows cost only their own groups: the index stays on the int8 shadow while at most 64 + 0.05 % of its rows sit in groups above
+// 0.03 (shadow8_rows_kernel counts them) and the worst stays under I8_ERR_L2 thousandths (1100: any finite row -- a group
+// quantised to zeros has error 1 and Cauchy-Schwarz's bound; 30: round 3's index-wide rule); such a pass seeds its thresholds
+// exactly (run_filter_pass) because the dense int8 seeding pass does use the index-wide maximum.
+// profiles/r04/outlier_row_ab_l2_ip_4m_before.txt: 5 rows with a 40-sigma component among 4M x 768 made every l2 / ip wave
+// 3.3 x slower (fp32 rows converted in registers), 54 x on d = 300 (exact scan); outlier_row_ab_l2_4m.txt: l2 now 1.1-1.2 x.
 bool i8_bounds_usable(const mlvdb_index* h) {
     if (!l2_int8_ok(h)) return false;
     if (h->space == kSpaceCosine) return h->i8_err <= 0.5f;
