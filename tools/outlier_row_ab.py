@@ -22,25 +22,27 @@ def main():
     ap.add_argument("--limits", default="30,250")
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--waves", type=int, default=10)
+    ap.add_argument("--k", type=int, default=10, help="top_k (> 64: big-k passes -- their dense seed is the open item of DESIGN 10)")
+    ap.add_argument("--odd-value", type=float, default=40.0, help="the component planted in the odd rows (1e6: their neighbours quantise to zeros)")
     args = ap.parse_args()
     import torch
 
     from mlvectordb_amd import synth
     from mlvectordb_amd.engine import HipScanEngine
 
-    k = 10
+    k = args.k
     for d in [int(x) for x in args.dims.split(",")]:
         pieces = [rows for _, rows in synth.iter_corpus(0, args.rows, d, threads=16)]
         odd = np.random.default_rng(5).integers(0, args.rows, 5)
         for space in args.spaces.split(","):
-            for corpus in ("clean", "5 rows with a 40-sigma component"):
+            for corpus in ("clean", f"5 rows with a {args.odd_value:g}-sigma component"):
                 eng = HipScanEngine(d, space, device=0, capacity_hint=args.rows)
                 off = 0
                 for rows in pieces:
                     if corpus != "clean":
                         rows = rows.copy()
                         for r in odd[(odd >= off) & (odd < off + len(rows))]:
-                            rows[r - off, int(r) % d] = 40.0
+                            rows[r - off, int(r) % d] = args.odd_value
                     eng.append(rows)
                     off += len(rows)
                 eng.set_profiling(True)
